@@ -1,0 +1,84 @@
+"""ctypes binding of libcotr_hip.so (include/cotr_hip.h).
+
+The product path has no fallback: if the shared library is missing or does not
+load, every model call raises.  ``import torch`` happens before the library is
+opened so that the HIP runtime torch bundles (same soname, libamdhip64.so.7) is
+the one instance in the process - stream handles from torch are then valid here.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported before the HIP library is opened)
+
+from .build import LIB
+
+c_float_p = ctypes.c_void_p  # raw device/host addresses from tensor.data_ptr()
+
+_PROTOS = {
+    'cotr_abi_version': (ctypes.c_int, []),
+    'cotr_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]),
+    'cotr_destroy': (None, [ctypes.c_void_p]),
+    'cotr_last_error': (ctypes.c_char_p, [ctypes.c_void_p]),
+    'cotr_load_weights': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
+                                         ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
+    'cotr_encode': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_decode': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p]),
+    'cotr_forward': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p,
+                                    ctypes.c_void_p]),
+    'cotr_workspace_bytes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    'cotr_debug_tap': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_float_p, ctypes.c_size_t,
+                                      ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]),
+    'cotr_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'cotr_get_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
+                                        ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    'cotr_op_linear': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p,
+                                      ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_conv': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_stem': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_maxpool': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p]),
+    'cotr_op_attention': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int, c_float_p,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_layernorm': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_posenc': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+_lib = None
+
+
+class CotrHipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Open libcotr_hip.so and declare every prototype; raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        raise CotrHipError(
+            f'{LIB} is missing: build it with `python -m cotr_amd.build` (or __graft_entry__.build()). '
+            'cotr_amd has no CPU or PyTorch fallback for the forward path.')
+    lib = ctypes.CDLL(LIB)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cotr_abi_version() != 1:
+        raise CotrHipError('libcotr_hip.so ABI version mismatch; rebuild with `python -m cotr_amd.build --force`')
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None, what=''):
+    if rc != 0:
+        lib = load_library()
+        msg = lib.cotr_last_error(handle)
+        raise CotrHipError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def current_stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,724 @@
+// libcotr_hip.so - C ABI (include/cotr_hip.h), weight packing and the launch schedule of the COTR
+// correspondence-query forward path on one MI355X.
+//
+// Path and reference call sites (relative to /root/reference):
+//   encode: COTR/models/backbone.py:79-92 (two halves -> torchvision resnet50 to layer3, FrozenBN :46-56)
+//           COTR/models/cotr_model.py:37 (input_proj) ; position_encoding.py:60-72 (image grid encoding)
+//           COTR/models/transformer.py:143-159 x6 (encoder) ; :192-195 (decoder K/V projections, hoisted:
+//           they depend on the memory only, not on the queries)
+//   decode: cotr_model.py:34-36 (query encoding) ; transformer.py:185-201 x6 ; :110-111 (decoder.norm)
+//           position_encoding.py:23-26 (corr_embed) - on the last layer only, the reference keeps [-1]
+//
+// HBM layout: activations are NHWC "side-by-side" [B, H, 2W, C] - both 256x256 halves of a pair share
+// one tensor (the reference concatenates them on W only after layer3, backbone.py:85), convolutions
+// pad each half on its own; after layer3 the tensor IS the [B*512, 1024] token matrix.  Tokens are
+// batch-major [B*512, 256] (the reference is sequence-first [512,B,256]; internal only).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cotr_hip.h"
+#include "common.h"
+
+int init_attention_attributes();
+
+namespace {
+
+constexpr int D = 256, HEADS = 8, FFN = 1024, TOK = 512, CFEAT = 1024;
+constexpr int ENC_CHUNK = 32;     // pairs per backbone/encoder pass (scratch ~50 MB per pair)
+constexpr int DEC_ROWS = 32768;   // query rows per decoder pass (scratch ~9 KB per row)
+constexpr float QSCALE = 0.17677669529663687f;  // 32^-0.5, float(head_dim) ** -0.5 in torch
+
+struct ConvW {
+  const float *w, *scale, *bias;
+  int cin, cout, k, stride;
+};
+struct EncW {
+  const float *in_w, *in_b, *out_w, *out_b, *l1w, *l1b, *l2w, *l2b, *n1w, *n1b, *n2w, *n2b;
+};
+struct DecW {
+  const float *q_w, *q_b, *out_w, *out_b, *l1w, *l1b, *l2w, *l2b, *n2w, *n2b, *n3w, *n3b;
+};
+struct StageSpec {
+  int planes, blocks, stride;
+};
+const StageSpec kStages[3] = {{64, 3, 1}, {128, 4, 2}, {256, 6, 2}};
+
+struct Arena {
+  float* ptr = nullptr;
+  size_t cap = 0;  // floats
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct cotr_ctx {
+  int device = 0;
+  std::string err;
+  // weights
+  float* wbuf = nullptr;
+  size_t wfloats = 0;
+  bool loaded = false;
+  std::vector<ConvW> convs;  // execution order: stem, then per block conv1, conv2, conv3, [downsample]
+  const float *ip_w = nullptr, *ip_b = nullptr;
+  std::vector<EncW> enc;
+  std::vector<DecW> dec;
+  const float *kv_w = nullptr, *kv_b = nullptr;  // [L*512][256], [L*512]
+  const float *dn_w = nullptr, *dn_b = nullptr;
+  const float* mlp_w[3] = {nullptr, nullptr, nullptr};
+  const float* mlp_b[3] = {nullptr, nullptr, nullptr};
+  float* pos = nullptr;  // [512][256]
+  // cached encode
+  Arena memkv;  // memory [B*512*256] then kv [B*512*L*512]
+  int enc_B = 0;
+  // scratch
+  Arena enc_scr, dec_scr;
+  // taps (pointers into scratch of the last call)
+  std::map<std::string, std::pair<const float*, size_t>> taps;
+  // profiling
+  bool prof = false;
+  std::vector<std::string> prof_names;
+  std::vector<hipEvent_t> prof_ev;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                      \
+      return COTR_ERR_HIP;                                                               \
+    }                                                                                    \
+  } while (0)
+
+#define KCHK(h, expr, what)                                                              \
+  do {                                                                                   \
+    int r_ = (expr);                                                                     \
+    if (r_ != 0) {                                                                       \
+      (h)->err = std::string("launch failed: ") + (what) + (r_ == -1 ? " (bad shape)" : " (hip error)"); \
+      return r_ == -1 ? COTR_ERR_ARG : COTR_ERR_HIP;                                     \
+    }                                                                                    \
+  } while (0)
+
+int ensure(cotr_ctx* h, Arena& a, size_t floats) {
+  if (a.cap >= floats) return COTR_OK;
+  if (a.ptr) HIPCHK(h, hipFree(a.ptr));
+  a.ptr = nullptr;
+  a.cap = 0;
+  HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&a.ptr), floats * sizeof(float)));
+  a.cap = floats;
+  return COTR_OK;
+}
+
+void prof_mark(cotr_ctx* h, const char* name, hipStream_t s) {
+  if (!h->prof) return;
+  hipEvent_t ev;
+  if (hipEventCreate(&ev) != hipSuccess) return;
+  hipEventRecord(ev, s);
+  h->prof_names.push_back(name);
+  h->prof_ev.push_back(ev);
+}
+
+void prof_reset(cotr_ctx* h) {
+  for (auto ev : h->prof_ev) hipEventDestroy(ev);
+  h->prof_ev.clear();
+  h->prof_names.clear();
+}
+
+GemmParams base_params() {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.colscale = 1.f;
+  p.a2_period = 1;
+  return p;
+}
+
+// y[M,N] = epi(x (+x2) . w^T)
+int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_period, int a2_width,
+           const float* w, const float* bias, const float* residual, int relu, float colscale, int colscale_n,
+           float* y, int M, int N, int K, hipStream_t s) {
+  GemmParams p = base_params();
+  p.M = M; p.N = N; p.K = K;
+  p.A = x; p.lda = K;
+  p.A2 = x2; p.lda2 = K; p.a2_row_mod = x2_row_mod; p.a2_period = a2_period; p.a2_width = a2_width;
+  p.W = w; p.C = y; p.ldc = N;
+  p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
+  p.colscale = colscale; p.colscale_n = colscale_n;
+  KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
+  return COTR_OK;
+}
+
+int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int relu, float* y, int B,
+         int Hin, int Win, hipStream_t s) {
+  GemmParams p = base_params();
+  const int pad = c.k / 2;
+  p.Hin = Hin; p.Win = Win; p.Cin = c.cin;
+  p.Hout = (Hin + 2 * pad - c.k) / c.stride + 1;
+  p.Wout = (Win + 2 * pad - c.k) / c.stride + 1;
+  p.ksize = c.k; p.stride = c.stride; p.pad = pad;
+  p.M = B * p.Hout * 2 * p.Wout; p.N = c.cout; p.K = c.k * c.k * c.cin;
+  p.A = x; p.lda = c.cin;
+  p.W = c.w; p.C = y; p.ldc = c.cout;
+  p.scale = c.scale; p.bias = c.bias; p.residual = residual; p.ldr = c.cout; p.relu = relu;
+  KCHK(h, launch_gemm(GEMM_CONV, p, s), "conv");
+  return COTR_OK;
+}
+
+int stem(cotr_ctx* h, const ConvW& c, const float* img, float* y, int B, hipStream_t s) {
+  GemmParams p = base_params();
+  p.M = B * 128 * 256; p.N = 64; p.K = 160;
+  p.A = img; p.W = c.w; p.C = y; p.ldc = 64;
+  p.scale = c.scale; p.bias = c.bias; p.relu = 1;
+  KCHK(h, launch_gemm(GEMM_STEM, p, s), "stem");
+  return COTR_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int cotr_abi_version(void) { return COTR_HIP_ABI_VERSION; }
+
+const char* cotr_last_error(cotr_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int cotr_create(cotr_handle* out, int device) {
+  if (!out) return COTR_ERR_ARG;
+  *out = nullptr;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return COTR_ERR_HIP;
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+    return COTR_ERR_HIP;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("libcotr_hip is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName;
+    return COTR_ERR_HIP;
+  }
+  if (init_attention_attributes() != 0) {
+    g_create_error = "hipFuncSetAttribute(attention, 139 KB dynamic LDS) failed";
+    return COTR_ERR_HIP;
+  }
+  cotr_ctx* h = new cotr_ctx();
+  h->device = device;
+  if (hipMalloc(reinterpret_cast<void**>(&h->pos), (size_t)TOK * D * sizeof(float)) != hipSuccess ||
+      launch_pos_table(h->pos, nullptr) != 0 || hipStreamSynchronize(nullptr) != hipSuccess) {
+    g_create_error = "building the image position table failed";
+    delete h;
+    return COTR_ERR_HIP;
+  }
+  *out = h;
+  return COTR_OK;
+}
+
+void cotr_destroy(cotr_handle h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  prof_reset(h);
+  if (h->wbuf) hipFree(h->wbuf);
+  if (h->pos) hipFree(h->pos);
+  if (h->memkv.ptr) hipFree(h->memkv.ptr);
+  if (h->enc_scr.ptr) hipFree(h->enc_scr.ptr);
+  if (h->dec_scr.ptr) hipFree(h->dec_scr.ptr);
+  delete h;
+}
+
+int cotr_load_weights(cotr_handle h, const char* const* names, const float* const* ptrs,
+                      const int64_t* numels, int n) {
+  if (!h || !names || !ptrs || !numels || n <= 0) return COTR_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::map<std::string, int> idx;
+  for (int i = 0; i < n; ++i) idx[names[i]] = i;
+
+  int n_enc = 0, n_dec = 0;
+  while (idx.count("transformer.encoder.layers." + std::to_string(n_enc) + ".linear1.weight")) ++n_enc;
+  while (idx.count("transformer.decoder.layers." + std::to_string(n_dec) + ".linear1.weight")) ++n_dec;
+  if (n_enc == 0 || n_dec == 0) {
+    h->err = "state dict has no transformer.encoder/decoder layers";
+    return COTR_ERR_WEIGHTS;
+  }
+
+  std::vector<float> host;  // packed image of every tensor, 64-float aligned
+  host.reserve(19u << 20);
+  std::string missing;
+  std::vector<float> tmp;
+  auto fetch = [&](const std::string& name, size_t expect) -> const float* {
+    auto it = idx.find(name);
+    if (it == idx.end() || (size_t)numels[it->second] != expect) {
+      if (missing.empty()) missing = name + (it == idx.end() ? " (missing)" : " (wrong size)");
+      tmp.assign(expect, 0.f);
+      return tmp.data();
+    }
+    tmp.resize(expect);
+    if (hipMemcpy(tmp.data(), ptrs[it->second], expect * sizeof(float), hipMemcpyDefault) != hipSuccess) {
+      if (missing.empty()) missing = name + " (hipMemcpy failed)";
+      tmp.assign(expect, 0.f);
+    }
+    return tmp.data();
+  };
+  auto reserve = [&](size_t nfl) -> size_t {
+    size_t off = (host.size() + 63) & ~size_t(63);
+    host.resize(off + nfl, 0.f);
+    return off;
+  };
+  auto put = [&](const std::string& name, size_t nfl) -> size_t {
+    const float* src = fetch(name, nfl);
+    size_t off = reserve(nfl);
+    memcpy(&host[off], src, nfl * sizeof(float));
+    return off;
+  };
+
+  struct ConvOff {
+    size_t w, scale, bias;
+    int cin, cout, k, stride;
+  };
+  std::vector<ConvOff> convs;
+  auto put_conv = [&](const std::string& conv, const std::string& bn, int cout, int cin, int k, int stride) {
+    ConvOff c;
+    c.cin = cin; c.cout = cout; c.k = k; c.stride = stride;
+    const std::string p = "backbone.0.body.";
+    if (cin == 3) {  // stem: [64][3][7][7] -> [64][160], k = c*49 + ky*7 + kx, zero padded
+      const float* src = fetch(p + conv + ".weight", (size_t)cout * 147);
+      c.w = reserve((size_t)cout * 160);
+      for (int o = 0; o < cout; ++o) memcpy(&host[c.w + (size_t)o * 160], src + (size_t)o * 147, 147 * sizeof(float));
+    } else {  // [Cout][Cin][k][k] -> [Cout][k][k][Cin]
+      const float* src = fetch(p + conv + ".weight", (size_t)cout * cin * k * k);
+      c.w = reserve((size_t)cout * cin * k * k);
+      for (int o = 0; o < cout; ++o)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int t = 0; t < k * k; ++t)
+            host[c.w + ((size_t)o * k * k + t) * cin + ci] = src[((size_t)o * cin + ci) * k * k + t];
+    }
+    // FrozenBatchNorm2d.forward, COTR/models/backbone.py:46-56
+    std::vector<float> bw(cout), bb(cout), rm(cout), rv(cout);
+    memcpy(bw.data(), fetch(p + bn + ".weight", cout), cout * sizeof(float));
+    memcpy(bb.data(), fetch(p + bn + ".bias", cout), cout * sizeof(float));
+    memcpy(rm.data(), fetch(p + bn + ".running_mean", cout), cout * sizeof(float));
+    memcpy(rv.data(), fetch(p + bn + ".running_var", cout), cout * sizeof(float));
+    c.scale = reserve(cout);
+    c.bias = reserve(cout);
+    for (int o = 0; o < cout; ++o) {
+      const float scale = bw[o] * (1.0f / sqrtf(rv[o] + 1e-5f));
+      host[c.scale + o] = scale;
+      host[c.bias + o] = bb[o] - rm[o] * scale;
+    }
+    convs.push_back(c);
+  };
+  put_conv("conv1", "bn1", 64, 3, 7, 2);
+  int inplanes = 64;
+  for (int st = 0; st < 3; ++st) {
+    for (int b = 0; b < kStages[st].blocks; ++b) {
+      const int planes = kStages[st].planes, s = (b == 0) ? kStages[st].stride : 1;
+      const std::string p = "layer" + std::to_string(st + 1) + "." + std::to_string(b) + ".";
+      put_conv(p + "conv1", p + "bn1", planes, inplanes, 1, 1);
+      put_conv(p + "conv2", p + "bn2", planes, planes, 3, s);
+      put_conv(p + "conv3", p + "bn3", planes * 4, planes, 1, 1);
+      if (b == 0) put_conv(p + "downsample.0", p + "downsample.1", planes * 4, inplanes, 1, s);
+      inplanes = planes * 4;
+    }
+  }
+  const size_t ip_w = put("input_proj.weight", (size_t)D * CFEAT), ip_b = put("input_proj.bias", D);
+
+  struct EncOff { size_t v[12]; };
+  std::vector<EncOff> enc(n_enc), dec(n_dec);
+  for (int i = 0; i < n_enc; ++i) {
+    const std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
+    size_t* v = enc[i].v;
+    v[0] = put(p + "self_attn.in_proj_weight", (size_t)3 * D * D);
+    v[1] = put(p + "self_attn.in_proj_bias", 3 * D);
+    v[2] = put(p + "self_attn.out_proj.weight", (size_t)D * D);
+    v[3] = put(p + "self_attn.out_proj.bias", D);
+    v[4] = put(p + "linear1.weight", (size_t)FFN * D);
+    v[5] = put(p + "linear1.bias", FFN);
+    v[6] = put(p + "linear2.weight", (size_t)D * FFN);
+    v[7] = put(p + "linear2.bias", D);
+    v[8] = put(p + "norm1.weight", D);
+    v[9] = put(p + "norm1.bias", D);
+    v[10] = put(p + "norm2.weight", D);
+    v[11] = put(p + "norm2.bias", D);
+  }
+  // decoder: q projection per layer; K|V projections of all layers concatenated [L*512][256]
+  const size_t kv_w = reserve((size_t)n_dec * 2 * D * D), kv_b = reserve((size_t)n_dec * 2 * D);
+  for (int i = 0; i < n_dec; ++i) {
+    const std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
+    size_t* v = dec[i].v;
+    {
+      const float* w = fetch(p + "multihead_attn.in_proj_weight", (size_t)3 * D * D);
+      v[0] = reserve((size_t)D * D);
+      memcpy(&host[v[0]], w, (size_t)D * D * sizeof(float));
+      memcpy(&host[kv_w + (size_t)i * 2 * D * D], w + (size_t)D * D, (size_t)2 * D * D * sizeof(float));
+      const float* bq = fetch(p + "multihead_attn.in_proj_bias", 3 * D);
+      v[1] = reserve(D);
+      memcpy(&host[v[1]], bq, D * sizeof(float));
+      memcpy(&host[kv_b + (size_t)i * 2 * D], bq + D, 2 * D * sizeof(float));
+    }
+    v[2] = put(p + "multihead_attn.out_proj.weight", (size_t)D * D);
+    v[3] = put(p + "multihead_attn.out_proj.bias", D);
+    v[4] = put(p + "linear1.weight", (size_t)FFN * D);
+    v[5] = put(p + "linear1.bias", FFN);
+    v[6] = put(p + "linear2.weight", (size_t)D * FFN);
+    v[7] = put(p + "linear2.bias", D);
+    v[8] = put(p + "norm2.weight", D);
+    v[9] = put(p + "norm2.bias", D);
+    v[10] = put(p + "norm3.weight", D);
+    v[11] = put(p + "norm3.bias", D);
+  }
+  const size_t dn_w = put("transformer.decoder.norm.weight", D), dn_b = put("transformer.decoder.norm.bias", D);
+  size_t mw[3], mb[3];
+  for (int i = 0; i < 3; ++i) {
+    const int o = (i == 2) ? 2 : D;
+    mw[i] = put("corr_embed.layers." + std::to_string(i) + ".weight", (size_t)o * D);
+    mb[i] = put("corr_embed.layers." + std::to_string(i) + ".bias", o);
+  }
+  if (!missing.empty()) {
+    h->err = "state dict: " + missing;
+    return COTR_ERR_WEIGHTS;
+  }
+
+  HIPCHK(h, hipDeviceSynchronize());
+  if (h->wbuf && h->wfloats < host.size()) {
+    HIPCHK(h, hipFree(h->wbuf));
+    h->wbuf = nullptr;
+  }
+  if (!h->wbuf) {
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->wbuf), host.size() * sizeof(float)));
+    h->wfloats = host.size();
+  }
+  HIPCHK(h, hipMemcpy(h->wbuf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  const float* base = h->wbuf;
+  h->convs.clear();
+  for (const auto& c : convs) h->convs.push_back({base + c.w, base + c.scale, base + c.bias, c.cin, c.cout, c.k, c.stride});
+  h->ip_w = base + ip_w; h->ip_b = base + ip_b;
+  h->enc.clear();
+  for (const auto& e : enc)
+    h->enc.push_back({base + e.v[0], base + e.v[1], base + e.v[2], base + e.v[3], base + e.v[4], base + e.v[5],
+                      base + e.v[6], base + e.v[7], base + e.v[8], base + e.v[9], base + e.v[10], base + e.v[11]});
+  h->dec.clear();
+  for (const auto& e : dec)
+    h->dec.push_back({base + e.v[0], base + e.v[1], base + e.v[2], base + e.v[3], base + e.v[4], base + e.v[5],
+                      base + e.v[6], base + e.v[7], base + e.v[8], base + e.v[9], base + e.v[10], base + e.v[11]});
+  h->kv_w = base + kv_w; h->kv_b = base + kv_b;
+  h->dn_w = base + dn_w; h->dn_b = base + dn_b;
+  for (int i = 0; i < 3; ++i) { h->mlp_w[i] = base + mw[i]; h->mlp_b[i] = base + mb[i]; }
+  h->loaded = true;
+  h->enc_B = 0;  // a cached encode belongs to the old weights
+  return COTR_OK;
+}
+
+int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
+  if (!h) return COTR_ERR_ARG;
+  if (!h->loaded) { h->err = "cotr_encode before cotr_load_weights"; return COTR_ERR_STATE; }
+  if (!img || B <= 0) { h->err = "cotr_encode: null image or B <= 0"; return COTR_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIPCHK(h, hipSetDevice(h->device));
+  const int L = (int)h->dec.size();
+  const size_t KVLD = (size_t)L * 2 * D;
+  h->enc_B = 0;
+  h->taps.clear();
+  {
+    int r = ensure(h, h->memkv, (size_t)B * TOK * (D + KVLD));
+    if (r) return r;
+  }
+  float* memory = h->memkv.ptr;
+  float* kv = h->memkv.ptr + (size_t)B * TOK * D;
+
+  const int Bc_max = B < ENC_CHUNK ? B : ENC_CHUNK;
+  // scratch carve (floats per pair)
+  const size_t n_stem = (size_t)128 * 256 * 64, n_pool = (size_t)64 * 128 * 64, n_act = (size_t)64 * 128 * 256;
+  const size_t n_tok = (size_t)TOK * D;
+  const size_t per_pair = n_stem + n_pool + 5 * n_act + 4 * n_tok + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
+  {
+    int r = ensure(h, h->enc_scr, per_pair * Bc_max);
+    if (r) return r;
+  }
+  float* p = h->enc_scr.ptr;
+  float* b_stem = p; p += n_stem * Bc_max;
+  float* b_pool = p; p += n_pool * Bc_max;
+  float* b_x = p; p += n_act * Bc_max;
+  float* b_y = p; p += n_act * Bc_max;
+  float* b_t1 = p; p += n_act * Bc_max;
+  float* b_t2 = p; p += n_act * Bc_max;
+  float* b_d = p; p += n_act * Bc_max;
+  float* t_src = p; p += n_tok * Bc_max;
+  float* t_alt = p; p += n_tok * Bc_max;
+  float* t_tmp = p; p += n_tok * Bc_max;
+  float* t_ao = p; p += n_tok * Bc_max;
+  float* t_qkv = p; p += (size_t)TOK * 3 * D * Bc_max;
+  float* t_hid = p; p += (size_t)TOK * FFN * Bc_max;
+
+  if (h->prof) prof_reset(h);
+  prof_mark(h, "begin", s);
+  for (int b0 = 0; b0 < B; b0 += ENC_CHUNK) {
+    const int Bc = (B - b0) < ENC_CHUNK ? (B - b0) : ENC_CHUNK;
+    const float* img_c = img + (size_t)b0 * 3 * 256 * 512;
+    // ---- backbone -------------------------------------------------------------------------
+    int ci = 0;
+    { int r = stem(h, h->convs[ci++], img_c, b_stem, Bc, s); if (r) return r; }
+    KCHK(h, launch_maxpool(b_stem, b_pool, Bc, 128, 128, 64, s), "maxpool");
+    prof_mark(h, "stem+pool", s);
+    const float* x = b_pool;
+    float* outbuf[2] = {b_x, b_y};
+    int flip = 0, H = 64, W = 64;
+    for (int st = 0; st < 3; ++st) {
+      for (int b = 0; b < kStages[st].blocks; ++b) {
+        const int stride = (b == 0) ? kStages[st].stride : 1;
+        const int Ho = H / stride, Wo = W / stride;
+        const ConvW& c1 = h->convs[ci++];
+        const ConvW& c2 = h->convs[ci++];
+        const ConvW& c3 = h->convs[ci++];
+        float* y = outbuf[flip];
+        flip ^= 1;
+        int r;
+        if ((r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
+        if ((r = conv(h, c2, b_t1, nullptr, 1, b_t2, Bc, H, W, s))) return r;
+        const float* idt = x;
+        if (b == 0) {
+          const ConvW& cd = h->convs[ci++];
+          if ((r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
+          idt = b_d;
+        }
+        if ((r = conv(h, c3, b_t2, idt, 1, y, Bc, Ho, Wo, s))) return r;
+        x = y;
+        H = Ho; W = Wo;
+      }
+      const char* names[3] = {"layer1", "layer2", "layer3"};
+      h->taps[names[st]] = {x, (size_t)Bc * H * 2 * W * kStages[st].planes * 4};
+      prof_mark(h, names[st], s);
+    }
+    h->taps["stem"] = {b_stem, n_stem * Bc};
+    h->taps["pool"] = {b_pool, n_pool * Bc};
+    // ---- input_proj: x is [Bc*512, 1024] --------------------------------------------------
+    const int M = Bc * TOK;
+    int r;
+    if ((r = linear(h, x, nullptr, 0, 1, 0, h->ip_w, h->ip_b, nullptr, 0, 1.f, 0, t_src, M, D, CFEAT, s))) return r;
+    h->taps["src"] = {t_src, (size_t)M * D};
+    prof_mark(h, "input_proj", s);
+    // ---- encoder --------------------------------------------------------------------------
+    float* cur = t_src;
+    float* mem_c = memory + (size_t)b0 * TOK * D;
+    for (size_t li = 0; li < h->enc.size(); ++li) {
+      const EncW& e = h->enc[li];
+      // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
+      if ((r = linear(h, cur, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
+      KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
+      if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, cur, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
+      KCHK(h, launch_layernorm(t_tmp, e.n1w, e.n1b, t_tmp, M, s), "layernorm");
+      if ((r = linear(h, t_tmp, nullptr, 0, 1, 0, e.l1w, e.l1b, nullptr, 1, 1.f, 0, t_hid, M, FFN, D, s))) return r;
+      float* nxt = (li + 1 == h->enc.size()) ? mem_c : (cur == t_src ? t_alt : t_src);
+      if ((r = linear(h, t_hid, nullptr, 0, 1, 0, e.l2w, e.l2b, t_tmp, 0, 1.f, 0, nxt, M, D, FFN, s))) return r;
+      KCHK(h, launch_layernorm(nxt, e.n2w, e.n2b, nxt, M, s), "layernorm");
+      cur = nxt;
+    }
+    prof_mark(h, "encoder", s);
+    // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195)
+    float* kv_c = kv + (size_t)b0 * TOK * KVLD;
+    if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
+    prof_mark(h, "dec_kv", s);
+  }
+  h->taps["memory"] = {memory, (size_t)B * TOK * D};
+  h->taps["kv"] = {kv, (size_t)B * TOK * KVLD};
+  h->taps["pos"] = {h->pos, (size_t)TOK * D};
+  h->enc_B = B;
+  return COTR_OK;
+}
+
+int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, cotr_stream stream) {
+  if (!h) return COTR_ERR_ARG;
+  if (!h->loaded) { h->err = "cotr_decode before cotr_load_weights"; return COTR_ERR_STATE; }
+  if (B <= 0 || Q < 0) { h->err = "cotr_decode: B <= 0 or Q < 0"; return COTR_ERR_ARG; }
+  if (h->enc_B != B) {
+    h->err = "cotr_decode: no cached encode for this batch size (call cotr_encode first)";
+    return COTR_ERR_STATE;
+  }
+  if (Q == 0) return COTR_OK;
+  if (!queries || !out) { h->err = "cotr_decode: null queries/out"; return COTR_ERR_ARG; }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIPCHK(h, hipSetDevice(h->device));
+  const int L = (int)h->dec.size();
+  const int KVLD = L * 2 * D;
+  const float* kv = h->memkv.ptr + (size_t)B * TOK * D;
+
+  const int q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
+  const int pairs_per = Q < DEC_ROWS ? (DEC_ROWS / Q) : 1;
+  const int nb_max = B < pairs_per ? B : pairs_per;
+  const size_t Rmax = (size_t)nb_max * q_chunk;
+  {
+    int r = ensure(h, h->dec_scr, Rmax * (5 * D + FFN));
+    if (r) return r;
+  }
+  float* p = h->dec_scr.ptr;
+  float* d_qpos = p; p += Rmax * D;
+  float* d_tgt = p; p += Rmax * D;
+  float* d_q = p; p += Rmax * D;
+  float* d_ao = p; p += Rmax * D;
+  float* d_tmp = p; p += Rmax * D;
+  float* d_hid = p; p += Rmax * FFN;
+
+  prof_mark(h, "dec_begin", s);
+  for (int b0 = 0; b0 < B; b0 += nb_max) {
+    const int nb = (B - b0) < nb_max ? (B - b0) : nb_max;
+    for (int q0 = 0; q0 < Q; q0 += q_chunk) {
+      const int nq = (Q - q0) < q_chunk ? (Q - q0) : q_chunk;
+      const int R = nb * nq;
+      const float* qsrc = queries + ((size_t)b0 * Q + q0) * 2;
+      float* odst = out + ((size_t)b0 * Q + q0) * 2;
+      const float* kv_c = kv + (size_t)b0 * TOK * KVLD;
+      KCHK(h, launch_posenc(qsrc, d_qpos, nb, nq, Q, s), "posenc");
+      int r;
+      for (int li = 0; li < L; ++li) {
+        const DecW& w = h->dec[li];
+        // q = Wq(tgt + query_pos) * 32^-0.5 ; tgt == 0 at layer 0 (transformer.py:54)
+        if (li == 0) {
+          if ((r = linear(h, d_qpos, nullptr, 0, 1, 0, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d_q, R, D, D, s))) return r;
+        } else {
+          if ((r = linear(h, d_tgt, d_qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d_q, R, D, D, s))) return r;
+        }
+        KCHK(h, launch_attention(d_q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d_ao, D, nb, nq, s),
+             "attention");
+        if ((r = linear(h, d_ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d_tgt, 0, 1.f, 0, d_tmp, R, D, D, s))) return r;
+        KCHK(h, launch_layernorm(d_tmp, w.n2w, w.n2b, d_tmp, R, s), "layernorm");
+        if ((r = linear(h, d_tmp, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d_hid, R, FFN, D, s))) return r;
+        if ((r = linear(h, d_hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d_tmp, 0, 1.f, 0, d_tgt, R, D, FFN, s))) return r;
+        KCHK(h, launch_layernorm(d_tgt, w.n3w, w.n3b, d_tgt, R, s), "layernorm");
+      }
+      // decoder.norm + corr_embed on the last layer only
+      KCHK(h, launch_layernorm(d_tgt, h->dn_w, h->dn_b, d_tmp, R, s), "layernorm");
+      if ((r = linear(h, d_tmp, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d_ao, R, D, D, s))) return r;
+      if ((r = linear(h, d_ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d_q, R, D, D, s))) return r;
+      KCHK(h, launch_head2(d_q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
+      h->taps["query_pos"] = {d_qpos, (size_t)R * D};
+      h->taps["hs"] = {d_tmp, (size_t)R * D};
+    }
+  }
+  prof_mark(h, "decoder", s);
+  return COTR_OK;
+}
+
+int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, int Q, float* out,
+                 cotr_stream stream) {
+  int r = cotr_encode(h, img, B, stream);
+  if (r) return r;
+  return cotr_decode(h, queries, B, Q, out, stream);
+}
+
+int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
+  if (!h || !bytes || B <= 0 || Q < 0) return COTR_ERR_ARG;
+  const size_t L = h->dec.empty() ? 6 : h->dec.size();
+  const size_t Bc = B < ENC_CHUNK ? B : ENC_CHUNK;
+  const size_t per_pair = (size_t)128 * 256 * 64 + (size_t)64 * 128 * 64 + 5 * (size_t)64 * 128 * 256 +
+                          4 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
+  const size_t q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
+  const size_t pairs_per = (Q > 0 && Q < DEC_ROWS) ? (DEC_ROWS / Q) : 1;
+  const size_t nb = (size_t)B < pairs_per ? B : pairs_per;
+  size_t fl = h->wfloats + (size_t)TOK * D + (size_t)B * TOK * (D + L * 2 * D) + per_pair * Bc +
+              nb * q_chunk * (5 * D + FFN);
+  *bytes = fl * sizeof(float);
+  return COTR_OK;
+}
+
+int cotr_debug_tap(cotr_handle h, const char* name, float* dst, size_t max_elems, size_t* n_elems,
+                   cotr_stream stream) {
+  if (!h || !name) return COTR_ERR_ARG;
+  auto it = h->taps.find(name);
+  if (it == h->taps.end()) { h->err = std::string("no tap named ") + name; return COTR_ERR_ARG; }
+  if (n_elems) *n_elems = it->second.second;
+  if (!dst) return COTR_OK;
+  if (max_elems < it->second.second) { h->err = "tap buffer too small"; return COTR_ERR_ARG; }
+  HIPCHK(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  HIPCHK(h, hipMemcpy(dst, it->second.first, it->second.second * sizeof(float), hipMemcpyDefault));
+  return COTR_OK;
+}
+
+int cotr_set_profiling(cotr_handle h, int enable) {
+  if (!h) return COTR_ERR_ARG;
+  h->prof = enable != 0;
+  if (!h->prof) prof_reset(h);
+  return COTR_OK;
+}
+
+int cotr_get_profile(cotr_handle h, const char** names, float* ms, int max_entries, int* n_entries) {
+  if (!h || !n_entries) return COTR_ERR_ARG;
+  *n_entries = 0;
+  if (h->prof_ev.size() < 2) return COTR_OK;
+  HIPCHK(h, hipEventSynchronize(h->prof_ev.back()));
+  int n = 0;
+  for (size_t i = 1; i < h->prof_ev.size() && n < max_entries; ++i) {
+    if (h->prof_names[i] == "dec_begin") continue;  // interval between encode and decode calls
+    float t = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&t, h->prof_ev[i - 1], h->prof_ev[i]));
+    if (names) names[n] = h->prof_names[i].c_str();
+    if (ms) ms[n] = t;
+    ++n;
+  }
+  *n_entries = n;
+  return COTR_OK;
+}
+
+// ---- op-level entry points (tests) --------------------------------------------------------------
+static int op_ret(int r) { return r == 0 ? COTR_OK : (r == -1 ? COTR_ERR_ARG : COTR_ERR_HIP); }
+
+int cotr_op_linear(const float* x, const float* x2, int x2_row_mod, const float* w, const float* scale,
+                   const float* bias, const float* residual, int relu, float* y, int M, int N, int K,
+                   cotr_stream stream) {
+  GemmParams p = base_params();
+  p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K;
+  p.A2 = x2; p.lda2 = K; p.a2_row_mod = x2_row_mod; p.a2_period = 1; p.a2_width = 1;
+  p.W = w; p.C = y; p.ldc = N; p.scale = scale; p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
+  return op_ret(launch_gemm(GEMM_DENSE, p, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_conv(const float* x, const float* w, const float* scale, const float* bias,
+                 const float* residual, int relu, float* y, int B, int Hin, int Win, int Cin, int Cout,
+                 int ksize, int stride, cotr_stream stream) {
+  GemmParams p = base_params();
+  const int pad = ksize / 2;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin;
+  p.Hout = (Hin + 2 * pad - ksize) / stride + 1;
+  p.Wout = (Win + 2 * pad - ksize) / stride + 1;
+  p.ksize = ksize; p.stride = stride; p.pad = pad;
+  p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
+  p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout;
+  p.scale = scale; p.bias = bias; p.residual = residual; p.ldr = Cout; p.relu = relu;
+  return op_ret(launch_gemm(GEMM_CONV, p, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_stem(const float* img, const float* w, const float* scale, const float* bias, float* y, int B,
+                 cotr_stream stream) {
+  GemmParams p = base_params();
+  p.M = B * 128 * 256; p.N = 64; p.K = 160; p.A = img; p.W = w; p.C = y; p.ldc = 64;
+  p.scale = scale; p.bias = bias; p.relu = 1;
+  return op_ret(launch_gemm(GEMM_STEM, p, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, cotr_stream stream) {
+  return op_ret(launch_maxpool(x, y, B, Hin, Win, C, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
+                      int nb, int nq, cotr_stream stream) {
+  if (init_attention_attributes() != 0) return COTR_ERR_HIP;
+  return op_ret(launch_attention(q, ldq, k, v, ldkv, o, ldo, nb, nq, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, int rows, cotr_stream stream) {
+  return op_ret(launch_layernorm(x, w, b, y, rows, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream) {
+  return op_ret(launch_posenc(pts, y, 1, n, n, static_cast<hipStream_t>(stream)));
+}
+
+}  // extern "C"

@@ -1,0 +1,62 @@
+// Shared declarations of the gfx950 kernels behind libcotr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// C[M,N] = epilogue( A'[M,K] . W[N,K]^T )
+//   A' row m, column k:
+//     mode DENSE : A[m*lda + k]  (+ A2[(m % a2_row_mod)*lda2 + k] when the tile's first column n0
+//                  satisfies (n0 % a2_period) < a2_width; a2_row_mod == 0 -> row m)
+//     mode CONV  : implicit im2col of an NHWC "side-by-side" activation [B,Hin,2*Win,Cin]
+//                  (the two 256x256 halves of a pair sit next to each other on W, each padded
+//                  on its own: a tap never crosses the seam), k = (ky*ks + kx)*Cin + c
+//     mode STEM  : implicit im2col of the NCHW input image [B,3,256,512], 7x7/2 pad 3,
+//                  k = c*49 + ky*7 + kx, K padded to 160 with zero weights
+//   epilogue, per element (m,n):  v = acc
+//     scale != null : v = v*scale[n] + bias[n]        (FrozenBN, COTR/models/backbone.py:54-56)
+//     else bias     : v = v + bias[n]
+//     n < colscale_n: v = v * colscale                (q * head_dim^-0.5 of nn.MultiheadAttention)
+//     residual      : v = v + residual[m*ldr + n]
+//     relu          : v = max(v, 0)
+// ---------------------------------------------------------------------------------------------
+enum { GEMM_DENSE = 0, GEMM_CONV = 1, GEMM_STEM = 2 };
+
+struct GemmParams {
+  int M, N, K;
+  const float* A;
+  int lda;
+  const float* A2;
+  int lda2, a2_row_mod, a2_period, a2_width;
+  const float* W;  // [N][K]
+  float* C;
+  int ldc;
+  // conv geometry (per half)
+  int Hin, Win, Cin, Hout, Wout, ksize, stride, pad;
+  // epilogue
+  const float* scale;
+  const float* bias;
+  const float* residual;
+  int ldr;
+  int relu;
+  float colscale;
+  int colscale_n;
+};
+
+int launch_gemm(int mode, const GemmParams& p, hipStream_t s);
+
+// softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]
+int launch_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
+                     int nb, int nq, hipStream_t s);
+
+int launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s);
+// lin_sine encoding; point (bi, qi) read from pts[((bi*q_total) + qi)*2], written to row bi*nq+qi
+int launch_posenc(const float* pts, float* y, int nb, int nq, int q_total, hipStream_t s);
+int launch_pos_table(float* y /*[512][256]*/, hipStream_t s);
+int launch_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, hipStream_t s);
+// y[(bi*q_total + qi)*2 + j] = x[bi*nq+qi, :] . w[j, :] + b[j]   (last corr_embed layer, 256 -> 2)
+int launch_head2(const float* x, const float* w, const float* b, float* y, int nb, int nq, int q_total,
+                 hipStream_t s);

@@ -1,0 +1,315 @@
+"""The COTR model object, MI355X edition.
+
+Same seam as the reference (``COTR/models/cotr_model.py:15-51``): ``build(args)`` returns an
+``nn.Module`` whose ``state_dict()`` has the reference's keys (a reference checkpoint loads
+with ``utils.safe_load_weights``), which exposes ``.transformer .corr_embed .query_proj
+.input_proj .backbone`` (``train_cotr.py:49-55``) and whose
+``forward(samples, queries) -> {'pred_corrs': [B,Q,2]}`` is what ``SparseEngine.infer_batch``
+(``COTR/inference/sparse_engine.py:47-56``) and friends call.
+
+The sub-modules here are PARAMETER CONTAINERS only.  All arithmetic of ``forward`` runs in
+``libcotr_hip.so`` (hand-written gfx950 kernels, ``cotr_amd/csrc``) through the C ABI of
+``include/cotr_hip.h``; there is no PyTorch or CPU fallback - calling the model with CPU
+tensors, or without the built library, raises.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .misc import NestedTensor
+from .spec import LAYER_CHANNELS, resnet_stages
+
+MAX_SIZE = 256  # COTR/utils/constants.py:2
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Four fixed buffers per norm (COTR/models/backbone.py:21-44); applied inside the HIP
+    convolution epilogue as x*scale+bias with scale = w*rsqrt(var+1e-5) (backbone.py:46-56)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer('weight', torch.ones(n))
+        self.register_buffer('bias', torch.zeros(n))
+        self.register_buffer('running_mean', torch.zeros(n))
+        self.register_buffer('running_var', torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, *rest):
+        state_dict.pop(prefix + 'num_batches_tracked', None)  # torchvision checkpoints carry it
+        super()._load_from_state_dict(state_dict, prefix, *rest)
+
+
+def _conv(cin, cout, k, stride):
+    return nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False)
+
+
+class _Bottleneck(nn.Module):
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(inplanes, planes, 1, 1), FrozenBatchNorm2d(planes)
+        self.conv2, self.bn2 = _conv(planes, planes, 3, stride), FrozenBatchNorm2d(planes)
+        self.conv3, self.bn3 = _conv(planes, planes * 4, 1, 1), FrozenBatchNorm2d(planes * 4)
+        if downsample:
+            self.downsample = nn.Sequential(_conv(inplanes, planes * 4, 1, stride), FrozenBatchNorm2d(planes * 4))
+
+
+class _ResNetBody(nn.Module):
+    """Parameters of torchvision resnet50 children conv1 .. ``layer`` (what the reference's
+    IntermediateLayerGetter keeps, COTR/models/backbone.py:71)."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.conv1, self.bn1 = _conv(3, 64, 7, 2), FrozenBatchNorm2d(64)
+        inplanes = 64
+        for name, planes, blocks, stride in resnet_stages(layer):
+            seq = nn.Sequential(*[_Bottleneck(inplanes if b == 0 else planes * 4, planes,
+                                              stride if b == 0 else 1, b == 0) for b in range(blocks)])
+            setattr(self, name, seq)
+            inplanes = planes * 4
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+
+class _Backbone(nn.Module):
+    def __init__(self, layer, train_backbone):
+        super().__init__()
+        self.body = _ResNetBody(layer)
+        self.num_channels = LAYER_CHANNELS[layer]
+        for name, p in self.body.named_parameters():  # COTR/models/backbone.py:66-69
+            if not train_backbone or ('layer2' not in name and 'layer3' not in name and 'layer4' not in name):
+                p.requires_grad_(False)
+
+
+class _NoParams(nn.Module):
+    """Stand-in for the parameter-free encodings (``query_proj``, ``backbone[1]``)."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return self.what
+
+
+class _EncoderLayer(nn.Module):
+    def __init__(self, d, heads, ffn, dropout):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d, heads, dropout=dropout)
+        self.linear1, self.linear2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
+        self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
+
+
+class _DecoderLayer(nn.Module):
+    def __init__(self, d, heads, ffn, dropout):
+        super().__init__()
+        self.multihead_attn = nn.MultiheadAttention(d, heads, dropout=dropout)
+        self.linear1, self.linear2 = nn.Linear(d, ffn), nn.Linear(ffn, d)
+        # norm1 is a parameter of the reference that its forward never applies (transformer.py:173)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
+
+
+class _Stack(nn.Module):
+    def __init__(self, layers, norm=None):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        if norm is not None:
+            self.norm = norm
+
+
+class _Transformer(nn.Module):
+    def __init__(self, d, heads, enc_layers, dec_layers, ffn, dropout):
+        super().__init__()
+        self.encoder = _Stack([_EncoderLayer(d, heads, ffn, dropout) for _ in range(enc_layers)])
+        self.decoder = _Stack([_DecoderLayer(d, heads, ffn, dropout) for _ in range(dec_layers)], nn.LayerNorm(d))
+        self.d_model, self.nhead = d, heads
+        for p in self.parameters():  # COTR/models/transformer.py:42-45
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+
+class _MLP(nn.Module):
+    def __init__(self, dims):
+        super().__init__()
+        self.num_layers = len(dims) - 1
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+
+class COTR(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        d = args.hidden_dim
+        layer = getattr(args, 'layer', 'layer3')
+        ffn = args.dim_feedforward
+        unsupported = []
+        if args.backbone != 'resnet50': unsupported.append(f'backbone={args.backbone}')
+        if layer != 'layer3' or ffn != 1024: unsupported.append(f'layer={layer}/dim_feedforward={ffn}')
+        if d != 256 or args.nheads != 8: unsupported.append(f'hidden_dim={d}/nheads={args.nheads}')
+        if args.dilation: unsupported.append('dilation')
+        if args.position_embedding != 'lin_sine': unsupported.append(f'position_embedding={args.position_embedding}')
+        if unsupported:
+            raise NotImplementedError(
+                'libcotr_hip implements COTR\'s published configuration (resnet50/layer3, hidden 256, 8 heads, '
+                'lin_sine; COTR/options/options.py:41-51); not: ' + ', '.join(unsupported))
+        self.transformer = _Transformer(d, args.nheads, args.enc_layers, args.dec_layers, ffn, args.dropout)
+        self.corr_embed = _MLP([d, d, d, 2])
+        self.query_proj = _NoParams('lin_sine, depth 64')
+        self.input_proj = nn.Conv2d(LAYER_CHANNELS[layer], d, kernel_size=1)
+        train_backbone = getattr(args, 'lr_backbone', 0) > 0
+        self.backbone = nn.Sequential(_Backbone(layer, train_backbone), _NoParams('lin_sine image grid encoding'))
+        self.backbone.num_channels = LAYER_CHANNELS[layer]
+        self._handle = None
+        self._handle_device = None
+        self._weights_dirty = True
+        self._encoded_batch = 0
+
+    # ------------------------------------------------------------------ weight synchronisation
+    def _apply(self, fn, *a, **kw):  # .cuda() / .to() / .float() move or replace the storage
+        self._weights_dirty = True
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._weights_dirty = True
+        return super().load_state_dict(*a, **kw)
+
+    def refresh_weights(self):
+        """Re-pack the weights into the HIP library at the next call (needed only after
+        modifying parameters in place; .to()/.cuda()/load_state_dict() do it themselves)."""
+        self._weights_dirty = True
+
+    def _ensure_ready(self, device):
+        lib = _lib.load_library()
+        if device.type != 'cuda':
+            raise _lib.CotrHipError(
+                'cotr_amd runs the COTR forward path on an MI355X only (HIP kernels, no CPU/PyTorch '
+                f'fallback); got tensors on {device}. Move the model and inputs with .cuda().')
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        if self._handle is None or self._handle_device != index:
+            self._release()
+            handle = ctypes.c_void_p()
+            _lib.check(lib.cotr_create(ctypes.byref(handle), index), None, 'cotr_create')
+            self._handle, self._handle_device = handle, index
+            self._weights_dirty = True
+        if self._weights_dirty:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            bad = [k for k, v in sd.items() if v.dtype != torch.float32]
+            if bad:
+                raise _lib.CotrHipError(f'libcotr_hip is fp32 (1e-3 px parity bar); non-fp32 tensors: {bad[:3]}...')
+            keep = [v.contiguous() for v in sd.values()]
+            n = len(keep)
+            names = (ctypes.c_char_p * n)(*[k.encode() for k in sd])
+            ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in keep])
+            numels = (ctypes.c_int64 * n)(*[t.numel() for t in keep])
+            torch.cuda.synchronize(index)
+            _lib.check(lib.cotr_load_weights(self._handle, names, ptrs, numels, n), self._handle, 'cotr_load_weights')
+            self._weights_dirty = False
+            self._encoded_batch = 0
+        return lib
+
+    def _release(self):
+        if self._handle is not None:
+            try:
+                _lib.load_library().cotr_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    def __del__(self):
+        self._release()
+
+    def __getstate__(self):  # the HIP handle is per process: never pickled / deep-copied
+        state = self.__dict__.copy()
+        state['_handle'], state['_handle_device'], state['_weights_dirty'], state['_encoded_batch'] = None, None, True, 0
+        return state
+
+    # ------------------------------------------------------------------ the path
+    def _check_mode(self):
+        if self.training:
+            raise NotImplementedError(
+                'cotr_amd implements the inference forward (model.eval()); the training step is the next '
+                'scope row (SURVEY.md 8f).')
+
+    @staticmethod
+    def _as_batch(samples):
+        if isinstance(samples, NestedTensor):
+            samples = samples.tensors
+        elif isinstance(samples, (list, tuple)):
+            samples = torch.stack(list(samples))
+        # same hard shape contract as COTR/models/backbone.py:80
+        assert samples.ndim == 4 and tuple(samples.shape[-2:]) == (MAX_SIZE, MAX_SIZE * 2) and samples.shape[1] == 3
+        return samples
+
+    @torch.no_grad()
+    def encode(self, samples):
+        """Query-independent half (backbone, input_proj, encoder, decoder K/V), cached in the
+        HIP handle; follow with any number of ``decode(queries)``."""
+        self._check_mode()
+        img = self._as_batch(samples)
+        lib = self._ensure_ready(img.device)
+        img = img.contiguous().float()
+        with torch.cuda.device(img.device):
+            _lib.check(lib.cotr_encode(self._handle, img.data_ptr(), img.shape[0], _lib.current_stream_ptr()),
+                       self._handle, 'cotr_encode')
+        self._encoded_batch = img.shape[0]
+        return self
+
+    @torch.no_grad()
+    def decode(self, queries):
+        """pred_corrs [B,Q,2] for ``queries`` [B,Q,2] against the last ``encode``."""
+        self._check_mode()
+        b, q, two = queries.shape
+        assert two == 2
+        if self._encoded_batch != b:
+            raise _lib.CotrHipError(f'decode of {b} pairs but the cached encode holds {self._encoded_batch}')
+        lib = self._ensure_ready(queries.device)
+        qs = queries.contiguous().float()
+        out = torch.empty((b, q, 2), dtype=torch.float32, device=qs.device)
+        with torch.cuda.device(qs.device):
+            _lib.check(lib.cotr_decode(self._handle, qs.data_ptr(), b, q, out.data_ptr(), _lib.current_stream_ptr()),
+                       self._handle, 'cotr_decode')
+        return out
+
+    @torch.no_grad()
+    def forward(self, samples, queries):
+        self._check_mode()
+        img = self._as_batch(samples)
+        b, q, two = queries.shape
+        assert two == 2 and b == img.shape[0]
+        if img.device != queries.device:
+            raise _lib.CotrHipError(f'samples on {img.device} but queries on {queries.device}')
+        lib = self._ensure_ready(img.device)
+        img = img.contiguous().float()
+        qs = queries.contiguous().float()
+        out = torch.empty((b, q, 2), dtype=torch.float32, device=img.device)
+        with torch.cuda.device(img.device):
+            _lib.check(lib.cotr_forward(self._handle, img.data_ptr(), qs.data_ptr(), b, q, out.data_ptr(),
+                                        _lib.current_stream_ptr()), self._handle, 'cotr_forward')
+        self._encoded_batch = b
+        return {'pred_corrs': out}
+
+    # ------------------------------------------------------------------ test / profiling hooks
+    def debug_tap(self, name):
+        lib = _lib.load_library()
+        n = ctypes.c_size_t()
+        _lib.check(lib.cotr_debug_tap(self._handle, name.encode(), None, 0, ctypes.byref(n), None), self._handle, 'tap')
+        out = torch.empty(n.value, dtype=torch.float32, device=f'cuda:{self._handle_device}')
+        _lib.check(lib.cotr_debug_tap(self._handle, name.encode(), out.data_ptr(), n.value, ctypes.byref(n),
+                                      _lib.current_stream_ptr()), self._handle, 'tap')
+        return out
+
+    def set_profiling(self, enable=True):
+        self._ensure_ready(next(self.parameters()).device)
+        _lib.check(_lib.load_library().cotr_set_profiling(self._handle, int(enable)), self._handle, 'profiling')
+
+    def get_profile(self):
+        lib = _lib.load_library()
+        names = (ctypes.c_char_p * 64)()
+        ms = (ctypes.c_float * 64)()
+        n = ctypes.c_int()
+        _lib.check(lib.cotr_get_profile(self._handle, names, ms, 64, ctypes.byref(n)), self._handle, 'profile')
+        return [(names[i].decode(), ms[i]) for i in range(n.value)]
+
+
+def build(args):
+    return COTR(args)

@@ -1,0 +1,125 @@
+/*
+ * cotr_hip.h - C ABI of libcotr_hip.so: the MI355X (gfx950) implementation of COTR's
+ * batched correspondence-query forward path.
+ *
+ * The reference (ubc-vision/COTR) has no FFI: its seam is the Python call
+ *     COTR.forward(samples, queries) -> {'pred_corrs'}      (COTR/models/cotr_model.py:26-40)
+ * made by SparseEngine.infer_batch (COTR/inference/sparse_engine.py:47-56),
+ * FasterSparseEngine.infer_batch_grouped (:277-282), cotr_patch_flow_exhaustive
+ * (COTR/inference/inference_helper.py:106-145) and cotr_corr_base (:186-204).
+ * This header is what a binding for that seam binds to; cotr_amd/models (ctypes) is
+ * the binding this repository ships, INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *  - plain C, no exceptions; every call returns COTR_OK (0) or a negative COTR_ERR_* and
+ *    leaves a message retrievable with cotr_last_error().
+ *  - all tensors are fp32, contiguous; `img`, `queries`, `out` are DEVICE pointers owned by
+ *    the caller (torch tensors' data_ptr()); weight pointers may be host or device.
+ *  - `stream` is a hipStream_t (NULL = the default stream).  All work is enqueued on it;
+ *    nothing synchronises the device except cotr_load_weights / cotr_destroy / cotr_debug_tap.
+ *  - packed weights and scratch live in memory owned by the handle (grow-only arenas).
+ *  - one handle per device per caller thread; a handle is not thread-safe.
+ *  - a NaN in the inputs/weights yields NaN outputs, never a trap: the reference's engines
+ *    raise ValueError('NaN in prediction') themselves (sparse_engine.py:54-55).
+ *
+ * Model geometry is COTR's default and only published configuration
+ * (COTR/options/options.py:41-51): resnet50 to layer3, hidden 256, 8 heads, FFN 1024,
+ * lin_sine; the number of encoder/decoder layers is read from the weight names.
+ */
+#ifndef COTR_HIP_H
+#define COTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COTR_HIP_ABI_VERSION 1
+
+#define COTR_OK 0
+#define COTR_ERR_ARG (-1)    /* bad argument (null pointer, bad shape)                     */
+#define COTR_ERR_HIP (-2)    /* a HIP runtime call failed; see cotr_last_error()            */
+#define COTR_ERR_STATE (-3)  /* weights not loaded / decode without a matching encode       */
+#define COTR_ERR_WEIGHTS (-4) /* a required tensor is missing or has the wrong element count */
+
+typedef struct cotr_ctx* cotr_handle;
+typedef void* cotr_stream; /* hipStream_t */
+
+int cotr_abi_version(void);
+
+/* Per-device context.  Replaces: model = build_model(opt).cuda()  (demo_single_pair.py:26-27) */
+int cotr_create(cotr_handle* out, int device);
+void cotr_destroy(cotr_handle h);
+const char* cotr_last_error(cotr_handle h); /* h may be NULL: last error of cotr_create */
+
+/* Load a state-dict: n tensors, names as in the reference's checkpoints
+ * ('backbone.0.body.layer1.0.conv1.weight', 'transformer.encoder.layers.0.self_attn.in_proj_weight',
+ * ...; full table: cotr_amd/models/spec.py).  Re-lays-out conv weights to [Cout][kh][kw][Cin],
+ * folds the four FrozenBN buffers into (scale, bias) exactly as COTR/models/backbone.py:46-56
+ * computes them, concatenates the decoder K/V projections.  Unknown names are ignored
+ * (e.g. decoder norm1, never applied: COTR/models/transformer.py:173,185-201).
+ * Replaces: utils.safe_load_weights(model, weights)  (COTR/utils/utils.py:164-193). */
+int cotr_load_weights(cotr_handle h, const char* const* names, const float* const* ptrs,
+                      const int64_t* numels, int n);
+
+/* Query-independent half: backbone on both 256x256 halves, input_proj, 6 encoder layers and the
+ * K/V projections of every decoder layer; result cached in the handle for cotr_decode.
+ * img: [B,3,256,512] NCHW, ImageNet-normalised side-by-side pair.
+ * Follows COTR/models/backbone.py:79-92,114-123, cotr_model.py:37, transformer.py:49-55,143-159,192-195. */
+int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream);
+
+/* Query-dependent half against the cached encode: lin_sine query encoding, 6 cross-attention
+ * decoder layers, decoder.norm and the corr_embed MLP on the LAST layer only (the reference runs
+ * them on all 6 and keeps [-1]: transformer.py:107-117, cotr_model.py:38-39).
+ * queries, out: [B,Q,2]; may be called repeatedly per encode (cycle pass of
+ * inference_helper.py:197-198, query chunks of :131-136).  Q == 0 is a no-op. */
+int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, cotr_stream stream);
+
+/* cotr_encode + cotr_decode: the drop-in for COTR.forward (cotr_model.py:26-40). */
+int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, int Q, float* out,
+                 cotr_stream stream);
+
+/* Bytes of handle-owned device memory after a call of that size (weights + scratch). */
+int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes);
+
+/* ---- test / profiling hooks (not needed by a binding) ------------------------------------ */
+
+/* Copy an intermediate of the LAST cotr_encode / cotr_decode to dst (device or host pointer).
+ * names: "stem" "pool" "layer1" "layer2" "layer3" (NHWC side-by-side [B,H,2W,C]),
+ * "src" "memory" ([B*512,256]), "pos" ([512,256]), "kv" ([B*512, L*512]),
+ * "query_pos" "hs" ([B*Q,256] of the last decode chunk).  Synchronises the stream. */
+int cotr_debug_tap(cotr_handle h, const char* name, float* dst, size_t max_elems, size_t* n_elems,
+                   cotr_stream stream);
+
+/* Per-stage HIP-event timings (ms) of the last cotr_forward when enabled; see bench.py. */
+int cotr_set_profiling(cotr_handle h, int enable);
+int cotr_get_profile(cotr_handle h, const char** names, float* ms, int max_entries, int* n_entries);
+
+/* Single-kernel entry points used by tests/test_ops_gpu.py for op-level parity.
+ * All pointers are device pointers. */
+/* y[M,N] = epilogue(x[M,K] (+ x2[M % x2_row_mod, K]) . w[N,K]^T) ; any of scale/bias/residual may be NULL */
+int cotr_op_linear(const float* x, const float* x2, int x2_row_mod, const float* w, const float* scale,
+                   const float* bias, const float* residual, int relu, float* y, int M, int N, int K,
+                   cotr_stream stream);
+/* NHWC side-by-side conv + FrozenBN(scale,bias) (+residual) (+ReLU):
+ * x [B,Hin,2*Win,Cin], w [Cout][k][k][Cin], y [B,Hout,2*Wout,Cout] */
+int cotr_op_conv(const float* x, const float* w, const float* scale, const float* bias,
+                 const float* residual, int relu, float* y, int B, int Hin, int Win, int Cin, int Cout,
+                 int ksize, int stride, cotr_stream stream);
+/* stem: img NCHW [B,3,256,512] -> y [B,128,256,64]; w [64][160] (k = c*49+ky*7+kx, zero padded) */
+int cotr_op_stem(const float* img, const float* w, const float* scale, const float* bias, float* y, int B,
+                 cotr_stream stream);
+int cotr_op_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, cotr_stream stream);
+/* q [nb*nq, ldq] (pre-scaled), k/v [nb*512, ldkv]; 8 heads x 32; o [nb*nq, ldo] */
+int cotr_op_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
+                      int nb, int nq, cotr_stream stream);
+int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, int rows, cotr_stream stream);
+/* lin_sine encoding of pts [n,2] -> y [n,256] (COTR/models/position_encoding.py:41-45) */
+int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COTR_HIP_H */

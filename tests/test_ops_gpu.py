@@ -1,0 +1,122 @@
+"""Op-level parity: each HIP kernel against the torch CPU op it replaces, same seeded inputs.
+fp32 MFMA accumulates in a different order than the CPU, so the bar is a relative error of a
+few fp32 ulps times sqrt(K), stated per test."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import gpu_helpers as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 256, 256), (512, 768, 256), (130, 1024, 256), (77, 256, 1024),
+                                   (65536, 128, 64), (24576, 128, 64), (1, 64, 32)])
+def test_linear_bias_relu_residual(M, N, K):
+    g = _g(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = F.relu(F.linear(x, w, b) + r)
+    d = G.dev()
+    y = G.op_linear(x.to(d), w.to(d), bias=b.to(d), residual=r.to(d), relu=True)
+    assert G.rel_err(y, ref) < 2e-5
+
+
+def test_linear_pos_prologue_and_bn_epilogue():
+    g = _g(5)
+    M, N, K = 1024, 256, 256
+    x, pos = torch.randn(M, K, generator=g), torch.randn(512, K, generator=g)
+    w = torch.randn(N, K, generator=g) / 16
+    sc, b = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    ref = F.linear(x + pos.repeat(2, 1), w) * sc + b
+    d = G.dev()
+    y = G.op_linear(x.to(d), w.to(d), x2=pos.to(d), x2_row_mod=512, scale=sc.to(d), bias=b.to(d))
+    assert G.rel_err(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,stride', [(1, 16, 64, 64, 3, 1), (2, 16, 128, 128, 3, 2), (1, 32, 256, 512, 1, 2),
+                                                   (1, 64, 64, 256, 1, 1), (1, 16, 256, 256, 3, 1), (3, 8, 64, 64, 3, 1)])
+def test_conv_frozenbn_residual_relu(B, H, cin, cout, k, stride):
+    g = _g(B * 1000 + H + cin + cout + k)
+    x = torch.randn(B, cin, H, 2 * H, generator=g)                      # two HxH halves side by side
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    sc, b = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    conv = lambda t: F.conv2d(t, w, stride=stride, padding=k // 2)
+    pre = G.per_half(conv, x) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    res = torch.randn(pre.shape, generator=g)
+    ref = F.relu(pre + res)
+    d = G.dev()
+    y = G.op_conv(G.nchw_to_sbs(x).to(d), G.pack_conv_weight(w).to(d), sc.to(d), b.to(d), G.nchw_to_sbs(res).to(d), True,
+                  cout, k, stride)
+    assert G.rel_err(G.sbs_to_nchw(y.cpu()), ref) < 3e-5
+
+
+def test_stem_conv7x7_and_maxpool():
+    from cotr_amd import _lib
+    g = _g(11)
+    img = torch.randn(2, 3, 256, 512, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)
+    sc, b = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    stem = lambda t: F.relu(F.conv2d(t, w, stride=2, padding=3) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+    ref = G.per_half(stem, img)
+    ref_pool = G.per_half(lambda t: F.max_pool2d(t, 3, stride=2, padding=1), ref)
+    d = G.dev()
+    wp = torch.zeros(64, 160)
+    wp[:, :147] = w.reshape(64, 147)
+    lib = _lib.load_library()
+    y = torch.empty(2, 128, 256, 64, device=d)
+    assert lib.cotr_op_stem(G.P(img.to(d)), G.P(wp.to(d)), G.P(sc.to(d)), G.P(b.to(d)), G.P(y), 2, G.sptr()) == 0
+    assert G.rel_err(G.sbs_to_nchw(y.cpu()), ref) < 2e-5
+    yp = torch.empty(2, 64, 128, 64, device=d)
+    assert lib.cotr_op_maxpool(G.P(y), G.P(yp), 2, 128, 128, 64, G.sptr()) == 0
+    assert G.rel_err(G.sbs_to_nchw(yp.cpu()), ref_pool) < 2e-5
+
+
+@pytest.mark.parametrize('nb,nq,gain', [(2, 200, 1.0), (1, 512, 1.0), (3, 1, 1.0), (1, 129, 6.0)])
+def test_attention(nb, nq, gain):
+    from cotr_amd import _lib
+    g = _g(nb * 100 + nq)
+    q = torch.randn(nb * nq, 256, generator=g) * gain / math.sqrt(32)   # pre-scaled q
+    kv = torch.randn(nb * 512, 1024, generator=g)                        # k at col 256, v at col 640 of a wider matrix
+    k, v = kv[:, 256:512], kv[:, 640:896]
+    qh = q.view(nb, nq, 8, 32).permute(0, 2, 1, 3)
+    kh = k.reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    vh = v.reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).permute(0, 2, 1, 3).reshape(nb * nq, 256)
+    d = G.dev()
+    qd, kvd = q.to(d), kv.to(d)
+    o = torch.empty(nb * nq, 256, device=d)
+    lib = _lib.load_library()
+    rc = lib.cotr_op_attention(G.P(qd), 256, G.P(kvd[:, 256:]), G.P(kvd[:, 640:]), 1024, G.P(o), 256, nb, nq, G.sptr())
+    assert rc == 0
+    assert G.rel_err(o, ref) < 2e-5
+
+
+def test_layernorm():
+    from cotr_amd import _lib
+    g = _g(3)
+    x = torch.randn(1001, 256, generator=g) * 3 + 1
+    w, b = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
+    ref = F.layer_norm(x, (256,), w, b, 1e-5)
+    d = G.dev()
+    y = torch.empty(1001, 256, device=d)
+    assert _lib.load_library().cotr_op_layernorm(G.P(x.to(d)), G.P(w.to(d)), G.P(b.to(d)), G.P(y), 1001, G.sptr()) == 0
+    assert G.rel_err(y, ref) < 5e-6
+
+
+def test_lin_sine_encoding():
+    from cotr_amd import _lib
+    g = _g(4)
+    pts = torch.rand(777, 2, generator=g) * 2 - 0.5        # includes out-of-range coordinates
+    ref = torch.cat([torch.sin(i * math.pi * pts) for i in range(1, 65)] +
+                    [torch.cos(i * math.pi * pts) for i in range(1, 65)], dim=-1)
+    d = G.dev()
+    y = torch.empty(777, 256, device=d)
+    assert _lib.load_library().cotr_op_posenc(G.P(pts.to(d)), G.P(y), 777, G.sptr()) == 0
+    assert float((y.cpu() - ref).abs().max()) < 1e-6

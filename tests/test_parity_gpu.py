@@ -1,0 +1,151 @@
+"""Whole-path parity on the MI355X: libcotr_hip (through the C ABI, via the model object) against
+the CPU oracle on the same seeded inputs and against the committed golden vectors generated from
+the reference itself.  Bar: 1e-3 px (BASELINE.json north_star), px = |d| * (512, 256)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cotr_amd
+from cotr_amd.models import build_model
+from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+from oracle import cotr_oracle
+from tests import gpu_helpers as G
+
+pytestmark = pytest.mark.gpu
+
+_spec = importlib.util.spec_from_file_location(
+    'make_golden', os.path.join(os.path.dirname(__file__), 'golden', 'make_golden.py'))
+make_golden = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(make_golden)
+
+PX_BAR = 1e-3
+_models = {}
+
+
+def hip_model(seed=0, gain=1.0):
+    key = (seed, gain)
+    if key not in _models:
+        m = build_model(cotr_amd.default_args()).cuda().eval()
+        m.load_state_dict(synth_state_dict(seed, attn_gain=gain))
+        _models[key] = m
+    return _models[key]
+
+
+@pytest.mark.parametrize('name', list(make_golden.CASES))
+def test_golden_vectors_from_the_reference(name, golden_dir):
+    wseed, gain = make_golden.CASES[name][:2]
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    sd, img, qs = make_golden.case_inputs(name)
+    m = hip_model(wseed, gain)
+    out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    assert out.shape == g['pred_f32'].shape
+    assert not torch.isnan(out).any()
+    e64 = cotr_oracle.px_err(out, torch.from_numpy(g['pred_f64']))
+    e32 = cotr_oracle.px_err(out, torch.from_numpy(g['pred_f32']))
+    assert e64 < PX_BAR and e32 < PX_BAR, (e64, e32)
+    mem = m.debug_tap('memory').cpu().view(img.shape[0], 512, 256)[:, ::8]
+    assert float((mem - torch.from_numpy(g['memory'])).abs().max()) < 1e-4
+
+
+def test_stage_taps_against_oracle():
+    sd, img, qs = make_golden.case_inputs('ragged_b2_q257')
+    taps = {}
+    ref = cotr_oracle.cotr_forward(sd, img, qs, taps=taps)
+    m = hip_model()
+    out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    B = img.shape[0]
+    checks = {
+        'stem': G.nchw_to_sbs(taps['stem']), 'pool': G.nchw_to_sbs(taps['pool']),
+        'layer1': G.nchw_to_sbs(taps['layer1.2']), 'layer2': G.nchw_to_sbs(taps['layer2.3']),
+        'layer3': G.nchw_to_sbs(taps['layer3.5']), 'src': G.seq_to_rows(taps['src']),
+        'pos': taps['pos'][:, 0], 'memory': G.seq_to_rows(taps['enc.5']),
+        'query_pos': G.seq_to_rows(taps['query_pos']),
+    }
+    errs = {k: G.rel_err(m.debug_tap(k).cpu().view(v.shape), v) for k, v in checks.items()}
+    assert all(e < 5e-5 for e in errs.values()), errs
+    assert cotr_oracle.px_err(out, ref) < PX_BAR
+
+
+def test_engine_batch_shape_b32_q1():
+    """SparseEngine.infer_batch feeds img[<=32,3,256,512], q[<=32,1,2] (sparse_engine.py:47-56)."""
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(32, 1, seed=9)
+    out = hip_model()(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    assert cotr_oracle.px_err(out, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
+
+
+def test_encode_chunking_b40():
+    """More pairs than one backbone pass (ENC_CHUNK = 32): results must not depend on the chunking."""
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(40, 3, seed=10)
+    m = hip_model()
+    out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    tail = m(img[33:35].cuda(), qs[33:35].cuda())['pred_corrs'].cpu()
+    assert torch.equal(out[33:35], tail)                       # pairs never interact: bit-identical
+    assert cotr_oracle.px_err(tail, cotr_oracle.cotr_forward(sd, img[33:35], qs[33:35])) < PX_BAR
+
+
+def test_decode_chunking_q40000_and_query_independence():
+    """Q above one decoder pass (DEC_ROWS = 32768), as the dense pass does (inference_helper.py:116-127);
+    every query is independent of the others, so any subset must reproduce bit-for-bit."""
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(1, 40000, seed=11)
+    m = hip_model()
+    out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    sub = torch.cat([qs[:, :100], qs[:, 39000:39100]], 1)
+    out_sub = m(img.cuda(), sub.cuda())['pred_corrs'].cpu()
+    assert torch.equal(out_sub[:, :100], out[:, :100]) and torch.equal(out_sub[:, 100:], out[:, 39000:39100])
+    assert cotr_oracle.px_err(out_sub, cotr_oracle.cotr_forward(sd, img, sub)) < PX_BAR
+    assert not torch.isnan(out).any()
+
+
+def test_encode_once_decode_twice_cycle_pass():
+    """cotr_corr_base runs model(img, q) then model(img, pred) on the same image
+    (inference_helper.py:197-198): the encode is reusable."""
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(2, 50, seed=12)
+    m = hip_model()
+    m.encode(img.cuda())
+    fwd = m.decode(qs.cuda())
+    cyc = m.decode(fwd)
+    ref_fwd = cotr_oracle.cotr_forward(sd, img, qs)
+    ref_cyc = cotr_oracle.cotr_forward(sd, img, ref_fwd)
+    assert cotr_oracle.px_err(fwd.cpu(), ref_fwd) < PX_BAR
+    assert cotr_oracle.px_err(cyc.cpu(), ref_cyc) < 2 * PX_BAR      # second pass inherits the first's error
+    assert torch.equal(m(img.cuda(), qs.cuda())['pred_corrs'], fwd)
+
+
+def test_edge_cases():
+    m = hip_model()
+    img, qs = synth_inputs(1, 4, seed=13)
+    assert m(img.cuda(), qs[:, :0].cuda())['pred_corrs'].shape == (1, 0, 2)          # no queries
+    with pytest.raises(AssertionError):                                               # backbone.py:80
+        m(img[..., :255, :].cuda(), qs.cuda())
+    bad = qs.clone()
+    bad[0, 1, 0] = float('nan')
+    out = m(img.cuda(), bad.cuda())['pred_corrs'].cpu()
+    assert torch.isnan(out[0, 1]).all() and not torch.isnan(out[0, [0, 2, 3]]).any()  # NaN stays in its query
+    # non-contiguous views and NestedTensor / list inputs
+    from cotr_amd.models import NestedTensor
+    wide = torch.randn(1, 3, 256, 1024)
+    ref = m(wide[..., 256:768].contiguous().cuda(), qs.cuda())['pred_corrs']
+    assert torch.equal(m(wide.cuda()[..., 256:768], qs.cuda())['pred_corrs'], ref)
+    assert torch.equal(m(NestedTensor(wide[..., 256:768].cuda(), None), qs.cuda())['pred_corrs'], ref)
+    assert torch.equal(m([wide[0, :, :, 256:768].cuda()], qs.cuda())['pred_corrs'], ref)
+
+
+def test_state_dict_round_trip_and_reload():
+    m = hip_model()
+    img, qs = synth_inputs(1, 8, seed=14)
+    a = m(img.cuda(), qs.cuda())['pred_corrs'].clone()
+    sd2 = synth_state_dict(3)
+    m2 = build_model(cotr_amd.default_args()).cuda().eval()
+    m2.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    assert torch.equal(m2(img.cuda(), qs.cuda())['pred_corrs'], a)
+    m2.load_state_dict(sd2)                                                         # new weights re-pack
+    b = m2(img.cuda(), qs.cuda())['pred_corrs']
+    assert cotr_oracle.px_err(b.cpu(), cotr_oracle.cotr_forward(sd2, img, qs)) < PX_BAR
+    assert not torch.equal(a, b)
