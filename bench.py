@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""Headline benchmark: query-correspondences/sec of the COTR forward path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "primary"): one 256x512 side-by-side pair,
+1000 queries, zoom disabled -> one ``model(img[1,3,256,512], q[1,1000,2])`` call per step, per GPU.
+Synthetic data and seeded random weights of the COTR architecture (no checkpoint exists offline).
+Inputs are resident in HBM before the timed region.  N > 1 (launched by torch.distributed.run, one
+rank per GPU, RCCL): every rank runs its own pair(s) (weak scaling), the predicted (x,y) of every
+step are all-gathered over xGMI on RCCL's stream, overlapped with the next step.
+
+Prints ONE JSON line on rank 0.  ``roofline`` is for the whole forward launch sequence (one "launch"
+= one cotr_forward = the ~150 kernels of one step): achieved = FLOP(B,Q) / mean step time measured
+with HIP events on the launch stream, against the fp32 MFMA peak (parity forces fp32 operands).
+``cpu_baseline`` is the CPU oracle (a torch-CPU restatement of the reference, kind "port") timed on
+this box's host cores on a bounded number of the same forward calls - rank 0, N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PAIRS_PER_GPU = 1
+QUERIES = 1000
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CUs
+HBM_PEAK_GBS = 8000.0
+
+
+def flop(b, q):
+    """Algorithmic work of the path, SURVEY.md 2.2 / 8(d): per pair 24.641 GFLOP (backbone, input_proj,
+    encoder, decoder K/V), per query 11.273 MFLOP (6 decoder layers + final norm + corr MLP once)."""
+    return b * 24.641e9 + b * q * 11.273e6
+
+
+def min_hbm_bytes(b, q):
+    """Minimum HBM traffic per call: weights once + image + queries in / predictions out."""
+    return 73.8e6 + b * (1.573e6 + 16 * q)
+
+
+def cpu_baseline(budget_s=12.0):
+    from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+    from oracle import cotr_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1)
+    cotr_oracle.cotr_forward(sd, img, qs)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        cotr_oracle.cotr_forward(sd, img, qs)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    return {'value': PAIRS_PER_GPU * QUERIES * n / dt, 'unit': 'query-correspondences/s', 'cores': cores,
+            'kind': 'port',
+            'sample': f'{n} forward calls of the same workload (1 pair x {QUERIES} queries, fp32) by oracle/cotr_oracle.py '
+                      f'(torch CPU, {cores} threads), {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs the MI355X (no CPU fallback of the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import cotr_amd
+    from cotr_amd.models import build_model
+    from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+
+    model = build_model(cotr_amd.default_args()).to(dev).eval()
+    model.load_state_dict(synth_state_dict(0))
+    img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1 + rank)
+    img, qs = img.to(dev), qs.to(dev)
+    gathered = torch.empty((world * PAIRS_PER_GPU, QUERIES, 2), device=dev) if world > 1 else None
+
+    def step():
+        out = model(img, qs)['pred_corrs']
+        if world > 1:  # RCCL all-gather of the predicted (x,y), asynchronous w.r.t. the next step's kernels
+            return dist.all_gather_into_tensor(gathered, out, async_op=True)
+        return None
+
+    for _ in range(args.warmup):
+        w = step()
+        if w is not None:
+            w.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    works = []
+    for i in range(args.steps):
+        works.append(step())
+        ev[i + 1].record()
+    for w in works:
+        if w is not None:
+            w.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)) / args.steps  # HIP events, launch stream
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        units = world * PAIRS_PER_GPU * QUERIES * args.steps
+        achieved = flop(PAIRS_PER_GPU, QUERIES) / (kernel_ms * 1e-3) / 1e12
+        line = {
+            'metric': 'query-correspondences/sec at 256x512 SBS, 1k queries',
+            'value': units / elapsed,
+            'unit': 'query-correspondences/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: 1 pair 256x512 side-by-side x 1000 queries per GPU per step, '
+                                   'zoom disabled, model(img[1,3,256,512], q[1,1000,2]); seeded random COTR weights',
+                       'pairs_per_gpu': PAIRS_PER_GPU, 'queries_per_pair': QUERIES,
+                       'parallelism': f'pairs sharded x{world}, all-gather of pred_corrs' if world > 1 else 'single GPU'},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'launch': 'one cotr_forward (all kernels of a step)', 'launch_ms_hip_events': kernel_ms,
+                         'algorithmic_gflop_per_launch': flop(PAIRS_PER_GPU, QUERIES) / 1e9,
+                         'min_hbm_gbs': min_hbm_bytes(PAIRS_PER_GPU, QUERIES) / (kernel_ms * 1e-3) / 1e9,
+                         'hbm_peak_gbs': HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -28,6 +28,7 @@ _PROTOS = {
     'cotr_workspace_bytes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     'cotr_debug_tap': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_float_p, ctypes.c_size_t,
                                       ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]),
+    'cotr_set_debug_taps': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'cotr_set_profiling': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'cotr_get_profile': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                         ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),

@@ -29,7 +29,7 @@ int init_attention_attributes();
 
 namespace {
 
-constexpr int D = 256, HEADS = 8, FFN = 1024, TOK = 512, CFEAT = 1024;
+constexpr int D = 256, FFN = 1024, TOK = 512, CFEAT = 1024;
 constexpr int ENC_CHUNK = 32;     // pairs per backbone/encoder pass (scratch ~50 MB per pair)
 constexpr int DEC_ROWS = 32768;   // query rows per decoder pass (scratch ~9 KB per row)
 constexpr float QSCALE = 0.17677669529663687f;  // 32^-0.5, float(head_dim) ** -0.5 in torch
@@ -79,8 +79,11 @@ struct cotr_ctx {
   int enc_B = 0;
   // scratch
   Arena enc_scr, dec_scr;
-  // taps (pointers into scratch of the last call)
+  // taps: name -> (pointer, floats).  Persistent buffers (memory, kv, pos) are referenced in place;
+  // scratch intermediates are only kept when debug taps are on (copied aside as they are produced)
   std::map<std::string, std::pair<const float*, size_t>> taps;
+  bool keep_taps = false;
+  std::map<std::string, Arena> tap_store;
   // profiling
   bool prof = false;
   std::vector<std::string> prof_names;
@@ -121,15 +124,26 @@ void prof_mark(cotr_ctx* h, const char* name, hipStream_t s) {
   if (!h->prof) return;
   hipEvent_t ev;
   if (hipEventCreate(&ev) != hipSuccess) return;
-  hipEventRecord(ev, s);
+  (void)hipEventRecord(ev, s);
   h->prof_names.push_back(name);
   h->prof_ev.push_back(ev);
 }
 
 void prof_reset(cotr_ctx* h) {
-  for (auto ev : h->prof_ev) hipEventDestroy(ev);
+  for (auto ev : h->prof_ev) (void)hipEventDestroy(ev);
   h->prof_ev.clear();
   h->prof_names.clear();
+}
+
+// remember an intermediate for cotr_debug_tap: scratch is recycled by later stages, so it is copied
+int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStream_t s) {
+  if (!h->keep_taps) return COTR_OK;
+  Arena& a = h->tap_store[name];
+  int r = ensure(h, a, n);
+  if (r) return r;
+  HIPCHK(h, hipMemcpyAsync(a.ptr, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  h->taps[name] = {a.ptr, n};
+  return COTR_OK;
 }
 
 GemmParams base_params() {
@@ -225,14 +239,16 @@ int cotr_create(cotr_handle* out, int device) {
 
 void cotr_destroy(cotr_handle h) {
   if (!h) return;
-  hipSetDevice(h->device);
-  hipDeviceSynchronize();
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
   prof_reset(h);
-  if (h->wbuf) hipFree(h->wbuf);
-  if (h->pos) hipFree(h->pos);
-  if (h->memkv.ptr) hipFree(h->memkv.ptr);
-  if (h->enc_scr.ptr) hipFree(h->enc_scr.ptr);
-  if (h->dec_scr.ptr) hipFree(h->dec_scr.ptr);
+  if (h->wbuf) (void)hipFree(h->wbuf);
+  if (h->pos) (void)hipFree(h->pos);
+  if (h->memkv.ptr) (void)hipFree(h->memkv.ptr);
+  if (h->enc_scr.ptr) (void)hipFree(h->enc_scr.ptr);
+  if (h->dec_scr.ptr) (void)hipFree(h->dec_scr.ptr);
+  for (auto& kv : h->tap_store)
+    if (kv.second.ptr) (void)hipFree(kv.second.ptr);
   delete h;
 }
 
@@ -469,6 +485,8 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
     { int r = stem(h, h->convs[ci++], img_c, b_stem, Bc, s); if (r) return r; }
     KCHK(h, launch_maxpool(b_stem, b_pool, Bc, 128, 128, 64, s), "maxpool");
     prof_mark(h, "stem+pool", s);
+    if (int r = tap_save(h, "stem", b_stem, n_stem * Bc, s)) return r;
+    if (int r = tap_save(h, "pool", b_pool, n_pool * Bc, s)) return r;
     const float* x = b_pool;
     float* outbuf[2] = {b_x, b_y};
     int flip = 0, H = 64, W = 64;
@@ -495,16 +513,14 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
         H = Ho; W = Wo;
       }
       const char* names[3] = {"layer1", "layer2", "layer3"};
-      h->taps[names[st]] = {x, (size_t)Bc * H * 2 * W * kStages[st].planes * 4};
+      if (int r = tap_save(h, names[st], x, (size_t)Bc * H * 2 * W * kStages[st].planes * 4, s)) return r;
       prof_mark(h, names[st], s);
     }
-    h->taps["stem"] = {b_stem, n_stem * Bc};
-    h->taps["pool"] = {b_pool, n_pool * Bc};
     // ---- input_proj: x is [Bc*512, 1024] --------------------------------------------------
     const int M = Bc * TOK;
     int r;
     if ((r = linear(h, x, nullptr, 0, 1, 0, h->ip_w, h->ip_b, nullptr, 0, 1.f, 0, t_src, M, D, CFEAT, s))) return r;
-    h->taps["src"] = {t_src, (size_t)M * D};
+    if ((r = tap_save(h, "src", t_src, (size_t)M * D, s))) return r;
     prof_mark(h, "input_proj", s);
     // ---- encoder --------------------------------------------------------------------------
     float* cur = t_src;
@@ -599,8 +615,8 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
       if ((r = linear(h, d_tmp, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d_ao, R, D, D, s))) return r;
       if ((r = linear(h, d_ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d_q, R, D, D, s))) return r;
       KCHK(h, launch_head2(d_q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
-      h->taps["query_pos"] = {d_qpos, (size_t)R * D};
-      h->taps["hs"] = {d_tmp, (size_t)R * D};
+      if ((r = tap_save(h, "query_pos", d_qpos, (size_t)R * D, s))) return r;
+      if ((r = tap_save(h, "hs", d_tmp, (size_t)R * D, s))) return r;
     }
   }
   prof_mark(h, "decoder", s);
@@ -639,6 +655,12 @@ int cotr_debug_tap(cotr_handle h, const char* name, float* dst, size_t max_elems
   if (max_elems < it->second.second) { h->err = "tap buffer too small"; return COTR_ERR_ARG; }
   HIPCHK(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   HIPCHK(h, hipMemcpy(dst, it->second.first, it->second.second * sizeof(float), hipMemcpyDefault));
+  return COTR_OK;
+}
+
+int cotr_set_debug_taps(cotr_handle h, int enable) {
+  if (!h) return COTR_ERR_ARG;
+  h->keep_taps = enable != 0;
   return COTR_OK;
 }
 

@@ -69,12 +69,14 @@ int launch_posenc(const float* pts, float* y, int nb, int nq, int q_total, hipSt
 }
 
 // Image grid encoding, COTR/models/position_encoding.py:60-72 with an all-False mask on the 16x32
-// feature map: x = (j + 0.5)/32, y = (i + 0.5)/16 exactly (32 + 1e-6 rounds to 32 in fp32).
+// feature map: x = (j + 0.5)/(32 + 1e-6), y = (i + 0.5)/(16 + 1e-6) evaluated in fp32 as the reference
+// does: 32 + 1e-6 rounds to 32, but 16 + 1e-6 rounds UP to 16.0000019 (half an ulp of 16 is 0.95e-6),
+// which moves sin(64*pi*y) by 2e-5 - so the sums are formed in fp32, not simplified.
 // Token l = i*32 + j (flatten of [16,32], transformer.py:50-51).  Constant -> built once per handle.
 __global__ __launch_bounds__(256) void pos_table_kernel(float* __restrict__ y) {
   const int l = blockIdx.x;
-  const float px = ((float)(l & 31) + 0.5f) / 32.f;
-  const float py = ((float)(l >> 5) + 0.5f) / 16.f;
+  const float px = __fdiv_rn((float)(l & 31) + 0.5f, 32.f + 1e-6f);
+  const float py = __fdiv_rn((float)(l >> 5) + 0.5f, 16.f + 1e-6f);
   y[(size_t)l * 256 + threadIdx.x] = lin_sine(px, py, threadIdx.x);
 }
 

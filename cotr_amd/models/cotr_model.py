@@ -298,6 +298,10 @@ class COTR(nn.Module):
                                       _lib.current_stream_ptr()), self._handle, 'tap')
         return out
 
+    def set_debug_taps(self, enable=True):
+        self._ensure_ready(next(self.parameters()).device)
+        _lib.check(_lib.load_library().cotr_set_debug_taps(self._handle, int(enable)), self._handle, 'debug taps')
+
     def set_profiling(self, enable=True):
         self._ensure_ready(next(self.parameters()).device)
         _lib.check(_lib.load_library().cotr_set_profiling(self._handle, int(enable)), self._handle, 'profiling')

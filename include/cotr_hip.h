@@ -86,10 +86,14 @@ int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes);
 
 /* ---- test / profiling hooks (not needed by a binding) ------------------------------------ */
 
+/* Keep copies of scratch intermediates for cotr_debug_tap (off by default: costs D2D copies). */
+int cotr_set_debug_taps(cotr_handle h, int enable);
+
 /* Copy an intermediate of the LAST cotr_encode / cotr_decode to dst (device or host pointer).
- * names: "stem" "pool" "layer1" "layer2" "layer3" (NHWC side-by-side [B,H,2W,C]),
- * "src" "memory" ([B*512,256]), "pos" ([512,256]), "kv" ([B*512, L*512]),
- * "query_pos" "hs" ([B*Q,256] of the last decode chunk).  Synchronises the stream. */
+ * always available: "memory" ([B*512,256]), "kv" ([B*512, L*512]), "pos" ([512,256]);
+ * with debug taps on: "stem" "pool" "layer1" "layer2" "layer3" (NHWC side-by-side [B,H,2W,C] of the
+ * last encode chunk), "src" ([B*512,256]), "query_pos" "hs" ([rows,256] of the last decode chunk).
+ * Synchronises the stream. */
 int cotr_debug_tap(cotr_handle h, const char* name, float* dst, size_t max_elems, size_t* n_elems,
                    cotr_stream stream);
 

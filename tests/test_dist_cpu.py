@@ -1,0 +1,62 @@
+"""world_size-2 gloo test of the pair/query sharding + all-gather (cotr_amd/dist.py) on CPU.
+The model behind the wrapper is the CPU oracle (test infrastructure): what is under test is the
+partitioning and the gather, which are device independent."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cotr_amd.dist import PairShardedModel, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 5, 8, 9, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, B, Q, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+    from oracle import cotr_oracle
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(B, Q, seed=30)
+    calls = []
+
+    def model(samples, queries):
+        calls.append(tuple(queries.shape))
+        return {'pred_corrs': cotr_oracle.cotr_forward(sd, samples, queries)}
+
+    out = PairShardedModel(model)(img, qs)['pred_corrs']
+    torch.save({'out': out, 'calls': calls}, os.path.join(out_dir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('B,Q', [(3, 5), (1, 7)])
+def test_sharded_equals_single_process(tmp_path, B, Q):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, B, Q, str(tmp_path)), nprocs=2, join=True)
+    from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+    from oracle import cotr_oracle
+    img, qs = synth_inputs(B, Q, seed=30)
+    torch.set_num_threads(2)
+    ref = cotr_oracle.cotr_forward(synth_state_dict(0), img, qs)
+    r0, r1 = (torch.load(tmp_path / f'r{r}.pt') for r in range(2))
+    assert r0['out'].shape == (B, Q, 2)
+    assert torch.equal(r0['out'], r1['out'])                   # every rank holds the full result
+    assert float((r0['out'] - ref).abs().max()) < 1e-5          # == unsharded (same CPU arithmetic, different batching)
+    if B >= 2:
+        assert r0['calls'] == [(2, Q, 2)] and r1['calls'] == [(1, Q, 2)]     # pairs sharded 2 + 1
+    else:
+        assert r0['calls'] == [(1, 4, 2)] and r1['calls'] == [(1, 3, 2)]     # queries sharded 4 + 3

@@ -25,7 +25,8 @@ def test_linear_bias_relu_residual(M, N, K):
     ref = F.relu(F.linear(x, w, b) + r)
     d = G.dev()
     y = G.op_linear(x.to(d), w.to(d), bias=b.to(d), residual=r.to(d), relu=True)
-    assert G.rel_err(y, ref) < 2e-5
+    e = G.rel_err(y, ref)
+    assert e < 2e-5, e
 
 
 def test_linear_pos_prologue_and_bn_epilogue():
@@ -37,7 +38,8 @@ def test_linear_pos_prologue_and_bn_epilogue():
     ref = F.linear(x + pos.repeat(2, 1), w) * sc + b
     d = G.dev()
     y = G.op_linear(x.to(d), w.to(d), x2=pos.to(d), x2_row_mod=512, scale=sc.to(d), bias=b.to(d))
-    assert G.rel_err(y, ref) < 2e-5
+    e = G.rel_err(y, ref)
+    assert e < 2e-5, e
 
 
 @pytest.mark.parametrize('B,H,cin,cout,k,stride', [(1, 16, 64, 64, 3, 1), (2, 16, 128, 128, 3, 2), (1, 32, 256, 512, 1, 2),
@@ -54,7 +56,8 @@ def test_conv_frozenbn_residual_relu(B, H, cin, cout, k, stride):
     d = G.dev()
     y = G.op_conv(G.nchw_to_sbs(x).to(d), G.pack_conv_weight(w).to(d), sc.to(d), b.to(d), G.nchw_to_sbs(res).to(d), True,
                   cout, k, stride)
-    assert G.rel_err(G.sbs_to_nchw(y.cpu()), ref) < 3e-5
+    e = G.rel_err(G.sbs_to_nchw(y.cpu()), ref)
+    assert e < 3e-5, e
 
 
 def test_stem_conv7x7_and_maxpool():
@@ -71,11 +74,14 @@ def test_stem_conv7x7_and_maxpool():
     wp[:, :147] = w.reshape(64, 147)
     lib = _lib.load_library()
     y = torch.empty(2, 128, 256, 64, device=d)
-    assert lib.cotr_op_stem(G.P(img.to(d)), G.P(wp.to(d)), G.P(sc.to(d)), G.P(b.to(d)), G.P(y), 2, G.sptr()) == 0
-    assert G.rel_err(G.sbs_to_nchw(y.cpu()), ref) < 2e-5
+    img_d, wp_d, sc_d, b_d = img.to(d), wp.to(d), sc.to(d), b.to(d)   # keep alive until the kernel ran
+    assert lib.cotr_op_stem(G.P(img_d), G.P(wp_d), G.P(sc_d), G.P(b_d), G.P(y), 2, G.sptr()) == 0
+    e = G.rel_err(G.sbs_to_nchw(y.cpu()), ref)
+    assert e < 2e-5, e
     yp = torch.empty(2, 64, 128, 64, device=d)
     assert lib.cotr_op_maxpool(G.P(y), G.P(yp), 2, 128, 128, 64, G.sptr()) == 0
-    assert G.rel_err(G.sbs_to_nchw(yp.cpu()), ref_pool) < 2e-5
+    e = G.rel_err(G.sbs_to_nchw(yp.cpu()), ref_pool)
+    assert e < 2e-5, e
 
 
 @pytest.mark.parametrize('nb,nq,gain', [(2, 200, 1.0), (1, 512, 1.0), (3, 1, 1.0), (1, 129, 6.0)])
@@ -95,7 +101,8 @@ def test_attention(nb, nq, gain):
     lib = _lib.load_library()
     rc = lib.cotr_op_attention(G.P(qd), 256, G.P(kvd[:, 256:]), G.P(kvd[:, 640:]), 1024, G.P(o), 256, nb, nq, G.sptr())
     assert rc == 0
-    assert G.rel_err(o, ref) < 2e-5
+    e = G.rel_err(o, ref)
+    assert e < 2e-5, e
 
 
 def test_layernorm():
@@ -106,8 +113,10 @@ def test_layernorm():
     ref = F.layer_norm(x, (256,), w, b, 1e-5)
     d = G.dev()
     y = torch.empty(1001, 256, device=d)
-    assert _lib.load_library().cotr_op_layernorm(G.P(x.to(d)), G.P(w.to(d)), G.P(b.to(d)), G.P(y), 1001, G.sptr()) == 0
-    assert G.rel_err(y, ref) < 5e-6
+    x_d, w_d, b_d = x.to(d), w.to(d), b.to(d)
+    assert _lib.load_library().cotr_op_layernorm(G.P(x_d), G.P(w_d), G.P(b_d), G.P(y), 1001, G.sptr()) == 0
+    e = G.rel_err(y, ref)
+    assert e < 5e-6, e
 
 
 def test_lin_sine_encoding():
@@ -118,5 +127,7 @@ def test_lin_sine_encoding():
                     [torch.cos(i * math.pi * pts) for i in range(1, 65)], dim=-1)
     d = G.dev()
     y = torch.empty(777, 256, device=d)
-    assert _lib.load_library().cotr_op_posenc(G.P(pts.to(d)), G.P(y), 777, G.sptr()) == 0
-    assert float((y.cpu() - ref).abs().max()) < 1e-6
+    pts_d = pts.to(d)
+    assert _lib.load_library().cotr_op_posenc(G.P(pts_d), G.P(y), 777, G.sptr()) == 0
+    e = float((y.cpu() - ref).abs().max())
+    assert e < 1e-6, e

@@ -55,8 +55,8 @@ def test_stage_taps_against_oracle():
     taps = {}
     ref = cotr_oracle.cotr_forward(sd, img, qs, taps=taps)
     m = hip_model()
+    m.set_debug_taps(True)
     out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    B = img.shape[0]
     checks = {
         'stem': G.nchw_to_sbs(taps['stem']), 'pool': G.nchw_to_sbs(taps['pool']),
         'layer1': G.nchw_to_sbs(taps['layer1.2']), 'layer2': G.nchw_to_sbs(taps['layer2.3']),
@@ -65,6 +65,7 @@ def test_stage_taps_against_oracle():
         'query_pos': G.seq_to_rows(taps['query_pos']),
     }
     errs = {k: G.rel_err(m.debug_tap(k).cpu().view(v.shape), v) for k, v in checks.items()}
+    m.set_debug_taps(False)
     assert all(e < 5e-5 for e in errs.values()), errs
     assert cotr_oracle.px_err(out, ref) < PX_BAR
 

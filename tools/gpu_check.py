@@ -62,6 +62,8 @@ def main():
     ref = cotr_oracle.cotr_forward(sd, img, qs, taps=taps)
     out = [None]
 
+    m.set_debug_taps(True)
+
     def fwd():
         out[0] = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
         return 'ok'
@@ -75,6 +77,7 @@ def main():
     }
     for k, v in checks.items():
         record('tap.' + k, lambda k=k, v=v: f'rel_err {G.rel_err(m.debug_tap(k).cpu().view(v.shape), v):.3e}')
+    m.set_debug_taps(False)
     if out[0] is not None:
         record('model.px_err(2,257)', lambda: f'{cotr_oracle.px_err(out[0], ref):.3e} px')
     img1, q1 = synth_inputs(1, 1000, seed=1)
