@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
           v = p.scale ? fmaf(v, sc, bi) : v + bi;
           v *= cs;
           if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
-          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.relu) v = (v < 0.f) ? 0.f : v;  // NaN passes through like torch.relu (fmaxf would drop it)
           p.C[(size_t)m * p.ldc + n] = v;
         }
       }
