@@ -44,6 +44,16 @@ _PROTOS = {
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_layernorm': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_posenc': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_gemm_num_configs': (ctypes.c_int, []),
+    'cotr_set_attention_splits': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
+    'cotr_bench_conv': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 9 +
+                        [ctypes.POINTER(ctypes.c_float)]),
+    'cotr_op_linear_cfg': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_conv_cfg': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p] +
+                         [ctypes.c_int] * 8 + [ctypes.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -14,7 +14,7 @@ import sys
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcotr_hip.so')
 SOURCES = ['gemm.hip', 'attention.hip', 'pointwise.hip', 'api.hip']
-HEADERS = ['common.h', os.path.join('..', '..', 'include', 'cotr_hip.h')]
+HEADERS = ['common.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
 # code-object v5: loadable by the ROCm 7.0 runtime torch bundles as well as by ROCm 7.2's
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-mcode-object-version=5',
          '-Wall', '-Wno-unused-function']

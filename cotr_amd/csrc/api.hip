@@ -26,6 +26,7 @@
 #include "common.h"
 
 int init_attention_attributes();
+void set_attention_splits(int ns);
 
 namespace {
 
@@ -741,6 +742,103 @@ int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, 
 
 int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream) {
   return op_ret(launch_posenc(pts, y, 1, n, n, static_cast<hipStream_t>(stream)));
+}
+
+// ---- tuning hooks (tools/tune_gemm.py): time one GEMM/conv shape under an explicit config -------
+static int bench_launches(int mode, int cfg, const GemmParams& p, int iters, float* us) {
+  if (!us || iters <= 0) return COTR_ERR_ARG;
+  hipStream_t s;
+  if (hipStreamCreate(&s) != hipSuccess) return COTR_ERR_HIP;
+  int rc = COTR_OK;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3 && rc == COTR_OK; ++i) rc = op_ret(launch_gemm_cfg(mode, cfg, p, s));  // warm-up (+ attribute opt-in)
+  if (rc == COTR_OK && hipStreamSynchronize(s) != hipSuccess) rc = COTR_ERR_HIP;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (rc == COTR_OK) {
+    // a captured chain of `iters` dependent launches: GPU-paced, no host launch cost in the timing
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = COTR_ERR_HIP;
+    for (int i = 0; i < iters && rc == COTR_OK; ++i) rc = op_ret(launch_gemm_cfg(mode, cfg, p, s));
+    if (hipStreamEndCapture(s, &graph) != hipSuccess) rc = rc ? rc : COTR_ERR_HIP;
+    if (rc == COTR_OK && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = COTR_ERR_HIP;
+  }
+  if (rc == COTR_OK) {
+    (void)hipGraphLaunch(exec, s);  // warm
+    (void)hipStreamSynchronize(s);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      (void)hipEventRecord(e0, s);
+      (void)hipGraphLaunch(exec, s);
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) { rc = COTR_ERR_HIP; break; }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best) best = ms;
+    }
+    *us = best * 1000.f / iters;
+  }
+  if (exec) (void)hipGraphExecDestroy(exec);
+  if (graph) (void)hipGraphDestroy(graph);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipStreamDestroy(s);
+  return rc;
+}
+
+int cotr_gemm_num_configs(void) { return gemm_num_configs(); }
+
+int cotr_set_attention_splits(int ns) {
+  if (ns != 0 && ns != 4 && ns != 8 && ns != 16) return COTR_ERR_ARG;
+  set_attention_splits(ns);
+  return COTR_OK;
+}
+
+int cotr_bench_linear(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int cfg,
+                      int iters, float* us) {
+  GemmParams p = base_params();
+  p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K; p.W = w; p.C = y; p.ldc = N; p.bias = bias;
+  if (cfg < 0) cfg = gemm_pick_config(GEMM_DENSE, p);
+  return bench_launches(GEMM_DENSE, cfg, p, iters, us);
+}
+
+int cotr_bench_conv(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int Hin,
+                    int Win, int Cin, int Cout, int ksize, int stride, int cfg, int iters, float* us) {
+  GemmParams p = base_params();
+  const int pad = ksize / 2;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin;
+  p.Hout = (Hin + 2 * pad - ksize) / stride + 1;
+  p.Wout = (Win + 2 * pad - ksize) / stride + 1;
+  p.ksize = ksize; p.stride = stride; p.pad = pad;
+  p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
+  p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout; p.scale = scale; p.bias = bias; p.relu = 1;
+  if (cfg < 0) cfg = gemm_pick_config(GEMM_CONV, p);
+  return bench_launches(GEMM_CONV, cfg, p, iters, us);
+}
+
+// explicit-config variants of the op entry points (tests check every config against torch)
+int cotr_op_linear_cfg(const float* x, const float* w, const float* bias, const float* residual, int relu, float* y,
+                       int M, int N, int K, int cfg, cotr_stream stream) {
+  GemmParams p = base_params();
+  p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K; p.W = w; p.C = y; p.ldc = N;
+  p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
+  return op_ret(launch_gemm_cfg(GEMM_DENSE, cfg, p, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                     int relu, float* y, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int cfg,
+                     cotr_stream stream) {
+  GemmParams p = base_params();
+  const int pad = ksize / 2;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin;
+  p.Hout = (Hin + 2 * pad - ksize) / stride + 1;
+  p.Wout = (Win + 2 * pad - ksize) / stride + 1;
+  p.ksize = ksize; p.stride = stride; p.pad = pad;
+  p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
+  p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout;
+  p.scale = scale; p.bias = bias; p.residual = residual; p.ldr = Cout; p.relu = relu;
+  return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
 }
 
 }  // extern "C"

@@ -46,7 +46,10 @@ struct GemmParams {
   int colscale_n;
 };
 
-int launch_gemm(int mode, const GemmParams& p, hipStream_t s);
+int launch_gemm(int mode, const GemmParams& p, hipStream_t s);            // tuned / modelled config
+int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s);  // explicit config (tuning, tests)
+int gemm_pick_config(int mode, const GemmParams& p);
+int gemm_num_configs();
 
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]
 int launch_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,

@@ -217,6 +217,216 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// K-split variant for the small-M regime (one image pair: M = 512 .. 8192 rows, 1000 query rows).
+// There the spatial tiling above leaves most of the 256 CUs idle (32 .. 128 workgroups) and every
+// wavefront walks the whole K serially.  Here ALL NWK wavefronts of a workgroup compute the SAME
+// (TM*32) x (TN*32) output tile, each over its own 32-wide slice of a (NWK*32)-deep K step, so a
+// K = 2304 contraction is 9 steps of 16 MFMAs per wavefront instead of 72; the NWK partial
+// accumulators are summed through LDS in a fixed order (deterministic, no atomics, no second
+// launch) and the same fused epilogue is applied.
+// ---------------------------------------------------------------------------------------------
+template <int NWK, int TM, int TN, int MODE>
+__global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
+  constexpr int NT = NWK * 64;
+  constexpr int BM = TM * 32, BN = TN * 32;
+  constexpr int KS = NWK * BK;        // K elements per step
+  constexpr int LD = KS + 4;          // padded LDS row
+  constexpr int C4 = NWK * 8;         // float4 per row per step
+  constexpr int PA = BM / 8, PW = BN / 8;  // passes: 8 rows per pass (NT / C4 == 8)
+  constexpr int NB = TM * TN;
+  static_assert(NT / C4 == 8, "8 rows per pass");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Ws = smem + BM * LD;
+
+  const int t = threadIdx.x;
+  const int tiles_n = p.N / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM;
+  const int n0 = (blockIdx.x % tiles_n) * BN;
+  const int lr = t / C4, lc4 = t % C4;
+  const int ktl = lc4 >> 3;            // which 32-wide k-tile of the step this thread loads
+  const int lcc = (lc4 & 7) * 4;       // column inside that k-tile
+  const int KT = p.K / BK;
+  const int steps = (KT + NWK - 1) / NWK;
+
+  const float* a_ptr[PA];
+  const float* a2_ptr[PA];
+  bool a_ok[PA];
+  int c_hi0[PA], c_wi0[PA];
+  const bool use_a2 = (MODE == GEMM_DENSE) && p.A2 != nullptr && (n0 % p.a2_period) < p.a2_width;
+  if constexpr (MODE == GEMM_DENSE) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int m = m0 + lr + 8 * i;
+      a_ok[i] = m < p.M;
+      const int mm = a_ok[i] ? m : 0;
+      a_ptr[i] = p.A + (size_t)mm * p.lda + lc4 * 4;
+      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? mm % p.a2_row_mod : mm) * p.lda2 + lc4 * 4 : nullptr;
+    }
+  } else {
+    const int W2o = 2 * p.Wout;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int m = m0 + lr + 8 * i;
+      a_ok[i] = m < p.M;
+      const int mm = a_ok[i] ? m : 0;
+      const int b = mm / (p.Hout * W2o);
+      const int rem = mm - b * (p.Hout * W2o);
+      const int ho = rem / W2o;
+      const int wo = rem - ho * W2o;
+      const int side = wo / p.Wout;
+      const int wl = wo - side * p.Wout;
+      c_hi0[i] = ho * p.stride - p.pad;
+      c_wi0[i] = wl * p.stride - p.pad;
+      a_ptr[i] = p.A + ((size_t)b * p.Hin * (2 * p.Win) + (size_t)side * p.Win) * p.Cin + lcc;
+      a2_ptr[i] = nullptr;
+    }
+  }
+  const float* w_ptr[PW];
+#pragma unroll
+  for (int i = 0; i < PW; ++i) w_ptr[i] = p.W + (size_t)(n0 + lr + 8 * i) * p.K + lc4 * 4;
+
+  f32x4 ra[PA], rw[PW];
+  const int tiles_per_tap = (MODE == GEMM_CONV) ? p.Cin / BK : 1;
+
+  auto load_tile = [&](int st) {
+    const int kt = st * NWK + ktl;
+    const bool k_ok = kt < KT;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == GEMM_DENSE) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        f32x4 v = z;
+        if (a_ok[i] && k_ok) {
+          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + st * KS);
+          if (use_a2) v += *reinterpret_cast<const f32x4*>(a2_ptr[i] + st * KS);
+        }
+        ra[i] = v;
+      }
+    } else {
+      const int tap = kt / tiles_per_tap;
+      const int c0 = (kt - tap * tiles_per_tap) * BK;
+      const int ky = tap / p.ksize;
+      const int kx = tap - ky * p.ksize;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int hi = c_hi0[i] + ky, wi = c_wi0[i] + kx;
+        f32x4 v = z;
+        if (a_ok[i] && k_ok && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win)
+          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((size_t)hi * (2 * p.Win) + wi) * p.Cin + c0);
+        ra[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) rw[i] = k_ok ? *reinterpret_cast<const f32x4*>(w_ptr[i] + st * KS) : z;
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(&As[(lr + 8 * i) * LD + lc4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) *reinterpret_cast<f32x4*>(&Ws[(lr + 8 * i) * LD + lc4 * 4]) = rw[i];
+  };
+
+  const int lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  load_tile(0);
+  for (int st = 0; st < steps; ++st) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (st + 1 < steps) load_tile(st + 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        af[a] = *reinterpret_cast<const f32x4*>(&As[(a * 32 + l31) * LD + wave * BK + j * 8 + hh * 4]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        bf[b] = *reinterpret_cast<const f32x4*>(&Ws[(b * 32 + l31) * LD + wave * BK + j * 8 + hh * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- cross-wave reduction through LDS: red[wave][block][r][lane] ----------------------------
+  __syncthreads();
+  float* red = smem;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * NB + a * TN + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+  __syncthreads();
+  // wave w finishes accumulator rows r = w, w+NWK, ... of every block
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + b * 32 + l31;
+      const float sc = p.scale ? p.scale[n] : 1.f;
+      const float bi = p.bias ? p.bias[n] : 0.f;
+      const float cs = (n < p.colscale_n) ? p.colscale : 1.f;
+#pragma unroll
+      for (int rr = 0; rr < 16 / NWK; ++rr) {
+        const int r = wave + rr * NWK;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWK; ++w) v += red[((w * NB + a * TN + b) * 16 + r) * 64 + lane];
+        const int m = m0 + a * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
+        if (m < p.M) {
+          v = p.scale ? fmaf(v, sc, bi) : v + bi;
+          v *= cs;
+          if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
+          if (p.relu) v = (v < 0.f) ? 0.f : v;
+          p.C[(size_t)m * p.ldc + n] = v;
+        }
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch configurations; the per-shape choice comes from a table measured on the MI355X
+// (tools/tune_gemm.py -> gemm_tuned.inc) with a heuristic for shapes not in the table.
+// ---------------------------------------------------------------------------------------------
+struct GemmCfg {
+  int kind;  // 0 = spatial (WM=WN=2), 1 = k-split
+  int a, tm, tn;  // spatial: a unused; k-split: a = NWK
+};
+static const GemmCfg kCfgs[] = {
+    {0, 0, 2, 2},   // 0  spatial 128x128
+    {0, 0, 2, 1},   // 1  spatial 128x64
+    {0, 0, 1, 1},   // 2  spatial 64x64
+    {1, 8, 1, 1},   // 3  k-split 8 waves, 32x32
+    {1, 4, 1, 1},   // 4  k-split 4 waves, 32x32
+    {1, 4, 2, 2},   // 5  k-split 4 waves, 64x64
+    {1, 2, 2, 2},   // 6  k-split 2 waves, 64x64
+    {1, 8, 2, 1},   // 7  k-split 8 waves, 64x32
+    {1, 16, 1, 1},  // 8  k-split 16 waves, 32x32
+    {1, 4, 2, 1},   // 9  k-split 4 waves, 64x32
+    {1, 8, 1, 2},   // 10 k-split 8 waves, 32x64
+    {1, 2, 1, 1},   // 11 k-split 2 waves, 32x32
+    {1, 8, 2, 2},   // 12 k-split 8 waves, 64x64
+};
+static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+int gemm_num_configs() { return kNumCfgs; }
+
 template <int WM, int WN, int TM, int TN, int MODE>
 static int launch_t(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -226,28 +436,118 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int MODE>
-static int launch_mode(const GemmParams& p, hipStream_t s) {
-  const long tm128 = (p.M + 127) / 128, tm64 = (p.M + 63) / 64;
-  if (p.N % 128 == 0 && tm128 * (p.N / 128) >= 512) return launch_t<2, 2, 2, 2, MODE>(p, s);
-  if (tm128 * (p.N / 64) >= 384) return launch_t<2, 2, 2, 1, MODE>(p, s);
-  (void)tm64;
-  return launch_t<2, 2, 1, 1, MODE>(p, s);
+template <int NWK, int TM, int TN>
+static constexpr size_t ks_smem() {
+  size_t tile = (size_t)(TM + TN) * 32 * (NWK * BK + 4) * sizeof(float);
+  size_t red = (size_t)NWK * TM * TN * 16 * 64 * sizeof(float);
+  return tile > red ? tile : red;
 }
 
-int launch_gemm(int mode, const GemmParams& p, hipStream_t s) {
-  if (p.N % 64 != 0) return -1;
+template <int NWK, int TM, int TN, int MODE>
+static int launch_ks(const GemmParams& p, hipStream_t s) {
+  constexpr int BM = TM * 32, BN = TN * 32;
+  if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
+  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  constexpr size_t smem = ks_smem<NWK, TM, TN>();
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_kernel<NWK, TM, TN, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return -2;
+    attr_set = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE>), dim3(tiles), dim3(NWK * 64), smem, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int MODE>
+static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
+  switch (cfg) {
+    case 0: return launch_t<2, 2, 2, 2, MODE>(p, s);
+    case 1: return launch_t<2, 2, 2, 1, MODE>(p, s);
+    case 2: return launch_t<2, 2, 1, 1, MODE>(p, s);
+    case 3: return launch_ks<8, 1, 1, MODE>(p, s);
+    case 4: return launch_ks<4, 1, 1, MODE>(p, s);
+    case 5: return launch_ks<4, 2, 2, MODE>(p, s);
+    case 6: return launch_ks<2, 2, 2, MODE>(p, s);
+    case 7: return launch_ks<8, 2, 1, MODE>(p, s);
+    case 8: return launch_ks<16, 1, 1, MODE>(p, s);
+    case 9: return launch_ks<4, 2, 1, MODE>(p, s);
+    case 10: return launch_ks<8, 1, 2, MODE>(p, s);
+    case 11: return launch_ks<2, 1, 1, MODE>(p, s);
+    case 12: return launch_ks<8, 2, 2, MODE>(p, s);
+    default: return -1;
+  }
+}
+
+struct TunedEntry {
+  int mode, M, N, K, cfg;
+};
+static const TunedEntry kTuned[] = {
+#include "gemm_tuned.inc"
+    {-1, 0, 0, 0, 0}};
+
+static bool cfg_fits(int cfg, const GemmParams& p) {
+  const GemmCfg& c = kCfgs[cfg];
+  const int bn = (c.kind == 0 ? 2 : 1) * c.tn * 32;
+  return p.N % bn == 0;
+}
+
+// rough cost model (cycles) for shapes outside the tuned table
+static double model_cost(const GemmCfg& c, const GemmParams& p) {
+  const int waves = c.kind == 0 ? 4 : c.a;
+  const int bm = (c.kind == 0 ? 2 : 1) * c.tm * 32, bn = (c.kind == 0 ? 2 : 1) * c.tn * 32;
+  const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
+  const int kt = p.K / BK;
+  const int steps = c.kind == 0 ? kt : (kt + c.a - 1) / c.a;
+  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)(c.tm + c.tn) * 32 * (c.a * 32 + 4) * 4.0;
+  double per_cu = floor(163840.0 / lds);
+  if (per_cu > 32.0 / waves) per_cu = 32.0 / waves;
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  const double rounds = ceil(wgs / (256.0 * per_cu));
+  const double resident = wgs < 256.0 * per_cu ? ceil(wgs / 256.0) : per_cu;
+  const double share = (waves * resident) / 4.0 > 1.0 ? (waves * resident) / 4.0 : 1.0;
+  const double step = c.tm * c.tn * 16 * 64.0 * share + 700.0;
+  return rounds * (steps * step + 2500.0 + (c.kind == 1 ? 600.0 : 0.0));
+}
+
+int gemm_pick_config(int mode, const GemmParams& p) {
+  if (mode == GEMM_STEM) return 1;
+  for (const TunedEntry* e = kTuned; e->mode >= 0; ++e)
+    if (e->mode == mode && e->M == p.M && e->N == p.N && e->K == p.K && cfg_fits(e->cfg, p)) return e->cfg;
+  int best = -1;
+  double best_cost = 0;
+  for (int i = 0; i < kNumCfgs; ++i) {
+    if (!cfg_fits(i, p)) continue;
+    const double c = model_cost(kCfgs[i], p);
+    if (best < 0 || c < best_cost) {
+      best = i;
+      best_cost = c;
+    }
+  }
+  return best;
+}
+
+int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s) {
+  if (p.N % 32 != 0 || cfg < 0 || cfg >= kNumCfgs || !cfg_fits(cfg, p)) return -1;
   switch (mode) {
     case GEMM_DENSE:
       if (p.lda % 4 != 0 || (p.A2 && p.lda2 % 4 != 0)) return -1;
-      return launch_mode<GEMM_DENSE>(p, s);
+      return launch_cfg<GEMM_DENSE>(cfg, p, s);
     case GEMM_CONV:
       if (p.Cin % BK != 0 || p.K != p.ksize * p.ksize * p.Cin) return -1;
-      return launch_mode<GEMM_CONV>(p, s);
+      return launch_cfg<GEMM_CONV>(cfg, p, s);
     case GEMM_STEM:
       if (p.N != 64 || p.K != 160) return -1;
       return launch_t<2, 2, 2, 1, GEMM_STEM>(p, s);  // BM must be 128
     default:
       return -1;
   }
+}
+
+int launch_gemm(int mode, const GemmParams& p, hipStream_t s) {
+  const int cfg = gemm_pick_config(mode, p);
+  if (cfg < 0) return -1;
+  return launch_gemm_cfg(mode, cfg, p, s);
 }

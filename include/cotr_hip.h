@@ -123,6 +123,23 @@ int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, 
 /* lin_sine encoding of pts [n,2] -> y [n,256] (COTR/models/position_encoding.py:41-45) */
 int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
 
+
+/* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
+int cotr_gemm_num_configs(void);
+/* key splits (wavefronts per workgroup) of the attention kernel: 4, 8, 16, or 0 = automatic */
+int cotr_set_attention_splits(int ns);
+/* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured
+ * with HIP events around a captured graph of `iters` launches on a private stream */
+int cotr_bench_linear(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int cfg,
+                      int iters, float* us);
+int cotr_bench_conv(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int Hin,
+                    int Win, int Cin, int Cout, int ksize, int stride, int cfg, int iters, float* us);
+int cotr_op_linear_cfg(const float* x, const float* w, const float* bias, const float* residual, int relu, float* y,
+                       int M, int N, int K, int cfg, cotr_stream stream);
+int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
+                     int relu, float* y, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int cfg,
+                     cotr_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

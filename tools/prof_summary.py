@@ -32,7 +32,7 @@ def main():
                      f'd.workgroup_size_x, s.arch_vgpr_count, s.accum_vgpr_count, d.group_segment_size '
                      f'from {kd} d join {ks} s on d.kernel_id = s.id order by d.start').fetchall()
     # keep only our kernels (drop torch fill/copy kernels of the setup)
-    ours = [r for r in rows if any(k in r[0] for k in ('gemm_kernel', 'attention_kernel', 'layernorm_kernel',
+    ours = [r for r in rows if any(k in r[0] for k in ('gemm_kernel', 'gemm_ks_kernel', 'attention', 'attention_kernel', 'layernorm_kernel',
                                                        'posenc_kernel', 'maxpool_kernel', 'head2_kernel', 'fused'))]
     n_steps = a.steps + a.warmup
     per_step = len(ours) // n_steps if n_steps else len(ours)

@@ -1,0 +1,28 @@
+"""Time model forward at (B,Q) for attention split settings; prints ms per forward. GPU box."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cotr_amd
+from cotr_amd import _lib
+from cotr_amd.models import build_model
+from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+
+def main():
+    m = build_model(cotr_amd.default_args()).cuda().eval()
+    m.load_state_dict(synth_state_dict(0))
+    lib = _lib.load_library()
+    shapes = [(1, 1000), (32, 1), (8, 1000)]
+    for ns in [0, 4, 8, 16]:
+        lib.cotr_set_attention_splits(ns)
+        for (b, q) in shapes:
+            img, qs = synth_inputs(b, q, seed=1)
+            img, qs = img.cuda(), qs.cuda()
+            for _ in range(5): m(img, qs)
+            torch.cuda.synchronize()
+            n = 30
+            t = time.perf_counter()
+            for _ in range(n): m(img, qs)
+            torch.cuda.synchronize()
+            print(f'ns={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
+    lib.cotr_set_attention_splits(0)
+main()

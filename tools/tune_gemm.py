@@ -1,0 +1,141 @@
+"""Measure every GEMM launch configuration on every contraction shape of the COTR forward path
+and write the winners to cotr_amd/csrc/gemm_tuned.inc (rebuild the library afterwards).
+
+    python tools/tune_gemm.py [--pairs 1,32] [--rows 1000,32,32768] [--out gpurun_out/gemm_tuned.inc]
+
+Runs on the MI355X (through gpurun); each config is first checked against config 2 (the plain
+64x64 spatial tiling) on the same data, then timed GPU-paced (captured graph of launches).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from cotr_amd import _lib  # noqa: E402
+from cotr_amd.models.spec import conv_bn_list  # noqa: E402
+
+GEMM_DENSE, GEMM_CONV = 0, 1
+
+
+def P(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def shapes(pairs, rows):
+    convs, lins = [], []
+    for B in pairs:
+        H = 64  # spatial size per half after the max-pool
+        size = {'layer1': 64, 'layer2': 64, 'layer3': 32}
+        for conv, bn, cout, cin, k, stride in conv_bn_list('layer3')[1:]:
+            stage = conv.split('.')[0]
+            blk = int(conv.split('.')[1])
+            hin = size[stage]
+            if blk > 0 or conv.endswith('conv3'):
+                hin = size[stage] // (2 if stage != 'layer1' else 1)
+            if blk == 0 and (conv.endswith('conv1') or conv.endswith('conv2') or 'downsample' in conv):
+                hin = size[stage]
+            if blk == 0 and conv.endswith('conv3'):
+                hin = size[stage] // (2 if stage != 'layer1' else 1)
+            convs.append((B, hin, cin, cout, k, stride))
+        M = 512 * B
+        lins += [(M, 256, 1024), (M, 768, 256), (M, 256, 256), (M, 1024, 256), (M, 256, 1024), (M, 3072, 256)]
+    for R in rows:
+        lins += [(R, 256, 256), (R, 1024, 256), (R, 256, 1024)]
+    return sorted(set(convs)), sorted(set(lins))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--pairs', default='1,32')
+    ap.add_argument('--rows', default='1000,32,32768')
+    ap.add_argument('--iters', type=int, default=30)
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'gemm_tuned.inc'))
+    a = ap.parse_args()
+    lib = _lib.load_library()
+    ncfg = lib.cotr_gemm_num_configs()
+    dev = torch.device('cuda:0')
+    convs, lins = shapes([int(x) for x in a.pairs.split(',')], [int(x) for x in a.rows.split(',')])
+    g = torch.Generator().manual_seed(0)
+    table, report = [], []
+    us = ctypes.c_float()
+
+    def sweep(kind, key, run_ref, run_cfg, bench_cfg, M, N, K):
+        ref = run_ref()
+        best = None
+        row = {}
+        for cfg in range(ncfg):
+            out = run_cfg(cfg)
+            if out is None:
+                continue
+            torch.cuda.synchronize()
+            err = float((out - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+            if not err < 1e-4:
+                row[cfg] = f'WRONG({err:.1e})'
+                continue
+            if bench_cfg(cfg) != 0:
+                continue
+            row[cfg] = round(us.value, 2)
+            if best is None or us.value < best[1]:
+                best = (cfg, us.value)
+        report.append({'kind': kind, 'shape': key, 'M': M, 'N': N, 'K': K, 'us': row, 'best': best})
+        print(kind, key, 'M,N,K=', (M, N, K), 'best', best, row, flush=True)
+        if best:
+            table.append((GEMM_CONV if kind == 'conv' else GEMM_DENSE, M, N, K, best[0], best[1]))
+
+    for (B, hin, cin, cout, k, stride) in convs:
+        pad = k // 2
+        ho = (hin + 2 * pad - k) // stride + 1
+        x = torch.randn(B, hin, 2 * hin, cin, generator=g).to(dev)
+        w = (torch.randn(cout, k, k, cin, generator=g) / (cin * k * k) ** 0.5).to(dev)
+        sc, bi = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+        y = torch.empty(B, ho, 2 * ho, cout, device=dev)
+        M, N, K = B * ho * 2 * ho, cout, k * k * cin
+
+        def run(cfg, y=y, x=x, w=w, sc=sc, bi=bi):
+            rc = lib.cotr_op_conv_cfg(P(x), P(w), P(sc), P(bi), None, 1, P(y), B, hin, hin, cin, cout, k, stride, cfg, None)
+            torch.cuda.synchronize()
+            return y.clone() if rc == 0 else None
+
+        def bench(cfg, y=y, x=x, w=w, sc=sc, bi=bi):
+            return lib.cotr_bench_conv(P(x), P(w), P(sc), P(bi), P(y), B, hin, hin, cin, cout, k, stride, cfg, a.iters,
+                                       ctypes.byref(us))
+        sweep('conv', (B, hin, cin, cout, k, stride), lambda: run(2), run, bench, M, N, K)
+
+    for (M, N, K) in lins:
+        x = torch.randn(M, K, generator=g).to(dev)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        bi = torch.randn(N, generator=g).to(dev)
+        y = torch.empty(M, N, device=dev)
+
+        def run(cfg, y=y, x=x, w=w, bi=bi):
+            rc = lib.cotr_op_linear_cfg(P(x), P(w), P(bi), None, 0, P(y), M, N, K, cfg, None)
+            torch.cuda.synchronize()
+            return y.clone() if rc == 0 else None
+
+        def bench(cfg, y=y, x=x, w=w, bi=bi):
+            return lib.cotr_bench_linear(P(x), P(w), P(bi), P(y), M, N, K, cfg, a.iters, ctypes.byref(us))
+        sweep('linear', (M, N, K), lambda: run(2), run, bench, M, N, K)
+
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    seen = set()
+    with open(a.out, 'w') as f:
+        f.write('// {mode, M, N, K, cfg} - fastest launch configuration per contraction shape, measured on MI355X\n')
+        f.write('// by tools/tune_gemm.py (GPU-paced graph of launches, random data); mode 0 = dense, 1 = conv\n')
+        for mode, M, N, K, cfg, t in table:
+            if (mode, M, N, K) in seen:
+                continue
+            seen.add((mode, M, N, K))
+            f.write(f'{{{mode}, {M}, {N}, {K}, {cfg}}},  // {t:.2f} us\n')
+    with open(a.out.replace('.inc', '.json'), 'w') as f:
+        json.dump(report, f, indent=1)
+    print('wrote', a.out)
+
+
+if __name__ == '__main__':
+    main()
