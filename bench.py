@@ -46,12 +46,24 @@ def min_hbm_bytes(b, q):
     return 73.8e6 + b * (1.573e6 + 16 * q)
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU
+    box reports 256 CPUs but grants 16; running OpenMP on 128+ threads there is ~10x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(budget_s=12.0):
     from cotr_amd.utils.synth import synth_state_dict, synth_inputs
     from oracle import cotr_oracle
-    # torch's own default honours the affinity mask / cgroup of the box; forcing os.cpu_count() threads
-    # on a CPU-limited container oversubscribes OpenMP and is ~100x slower
-    cores = torch.get_num_threads()
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     sd = synth_state_dict(0)
     img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1)
     cotr_oracle.cotr_forward(sd, img, qs)  # warm-up

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 // accumulators are summed through LDS in a fixed order (deterministic, no atomics, no second
 // launch) and the same fused epilogue is applied.
 // ---------------------------------------------------------------------------------------------
-template <int NWK, int TM, int TN, int MODE>
+template <int NWK, int TM, int TN, int MODE, int DB>
 __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
   constexpr int NT = NWK * 64;
   constexpr int BM = TM * 32, BN = TN * 32;
@@ -237,9 +237,8 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
   constexpr int PA = BM / 8, PW = BN / 8;  // passes: 8 rows per pass (NT / C4 == 8)
   constexpr int NB = TM * TN;
   static_assert(NT / C4 == 8, "8 rows per pass");
+  constexpr int TILE = (BM + BN) * LD;  // floats per LDS stage (A rows then W rows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;
-  float* Ws = smem + BM * LD;
 
   const int t = threadIdx.x;
   const int tiles_n = p.N / BN;
@@ -292,6 +291,9 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
   const int tiles_per_tap = (MODE == GEMM_CONV) ? p.Cin / BK : 1;
 
   auto load_tile = [&](int st) {
+#if defined(COTR_ABL) && COTR_ABL == 1  // ablation: only the first global load
+    if (st > 0) return;
+#endif
     const int kt = st * NWK + ktl;
     const bool k_ok = kt < KT;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -322,7 +324,9 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < PW; ++i) rw[i] = k_ok ? *reinterpret_cast<const f32x4*>(w_ptr[i] + st * KS) : z;
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    float* As = smem + buf * TILE;
+    float* Ws = As + BM * LD;
 #pragma unroll
     for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(&As[(lr + 8 * i) * LD + lc4 * 4]) = ra[i];
 #pragma unroll
@@ -339,12 +343,12 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  load_tile(0);
-  for (int st = 0; st < steps; ++st) {
-    __syncthreads();
-    store_tile();
-    __syncthreads();
-    if (st + 1 < steps) load_tile(st + 1);
+  auto compute = [&](int buf) {
+    const float* As = smem + buf * TILE;
+    const float* Ws = As + BM * LD;
+#if defined(COTR_ABL) && COTR_ABL == 2  // ablation: no LDS reads / MFMAs
+    if (p.M > 0) return;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 af[TM], bf[TN];
@@ -362,10 +366,36 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
     }
+  };
+
+  load_tile(0);
+  if constexpr (DB) {
+    // two LDS stages, ONE barrier per K step: a wavefront that has finished its MFMAs of step st
+    // writes the tile of step st+1 into the other stage while slower wavefronts still compute,
+    // and the global loads of step st+2 are in flight across the whole step.
+    store_tile(0);
+    if (steps > 1) load_tile(1);
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+      compute(st & 1);
+      if (st + 1 < steps) {
+        store_tile((st + 1) & 1);          // registers hold tile st+1 (loaded during step st-1 / prologue)
+        if (st + 2 < steps) load_tile(st + 2);
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int st = 0; st < steps; ++st) {
+      __syncthreads();
+      store_tile(0);
+      __syncthreads();
+      if (st + 1 < steps) load_tile(st + 1);
+      compute(0);
+    }
+    __syncthreads();
   }
 
   // ---- cross-wave reduction through LDS: red[wave][block][r][lane] ----------------------------
-  __syncthreads();
   float* red = smem;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -406,7 +436,7 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 // (tools/tune_gemm.py -> gemm_tuned.inc) with a heuristic for shapes not in the table.
 // ---------------------------------------------------------------------------------------------
 struct GemmCfg {
-  int kind;  // 0 = spatial (WM=WN=2), 1 = k-split
+  int kind;  // 0 = spatial (WM=WN=2), 1 = k-split, 2 = k-split with two LDS stages
   int a, tm, tn;  // spatial: a unused; k-split: a = NWK
 };
 static const GemmCfg kCfgs[] = {
@@ -423,6 +453,12 @@ static const GemmCfg kCfgs[] = {
     {1, 8, 1, 2},   // 10 k-split 8 waves, 32x64
     {1, 2, 1, 1},   // 11 k-split 2 waves, 32x32
     {1, 8, 2, 2},   // 12 k-split 8 waves, 64x64
+    {2, 8, 1, 1},   // 13 k-split 8 waves, 32x32, double-buffered LDS
+    {2, 4, 1, 1},   // 14 k-split 4 waves, 32x32, double-buffered
+    {2, 4, 2, 2},   // 15 k-split 4 waves, 64x64, double-buffered
+    {2, 8, 1, 2},   // 16 k-split 8 waves, 32x64, double-buffered
+    {2, 4, 2, 1},   // 17 k-split 4 waves, 64x32, double-buffered
+    {2, 2, 2, 2},   // 18 k-split 2 waves, 64x64, double-buffered
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -436,27 +472,27 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int NWK, int TM, int TN>
+template <int NWK, int TM, int TN, int DB>
 static constexpr size_t ks_smem() {
-  size_t tile = (size_t)(TM + TN) * 32 * (NWK * BK + 4) * sizeof(float);
+  size_t tile = (size_t)(DB ? 2 : 1) * (TM + TN) * 32 * (NWK * BK + 4) * sizeof(float);
   size_t red = (size_t)NWK * TM * TN * 16 * 64 * sizeof(float);
   return tile > red ? tile : red;
 }
 
-template <int NWK, int TM, int TN, int MODE>
+template <int NWK, int TM, int TN, int MODE, int DB = 0>
 static int launch_ks(const GemmParams& p, hipStream_t s) {
   constexpr int BM = TM * 32, BN = TN * 32;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  constexpr size_t smem = ks_smem<NWK, TM, TN>();
+  constexpr size_t smem = ks_smem<NWK, TM, TN, DB>();
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_kernel<NWK, TM, TN, MODE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_kernel<NWK, TM, TN, MODE, DB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE>), dim3(tiles), dim3(NWK * 64), smem, s, p);
+  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles), dim3(NWK * 64), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -476,6 +512,12 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 10: return launch_ks<8, 1, 2, MODE>(p, s);
     case 11: return launch_ks<2, 1, 1, MODE>(p, s);
     case 12: return launch_ks<8, 2, 2, MODE>(p, s);
+    case 13: return launch_ks<8, 1, 1, MODE, 1>(p, s);
+    case 14: return launch_ks<4, 1, 1, MODE, 1>(p, s);
+    case 15: return launch_ks<4, 2, 2, MODE, 1>(p, s);
+    case 16: return launch_ks<8, 1, 2, MODE, 1>(p, s);
+    case 17: return launch_ks<4, 2, 1, MODE, 1>(p, s);
+    case 18: return launch_ks<2, 2, 2, MODE, 1>(p, s);
     default: return -1;
   }
 }
@@ -490,6 +532,11 @@ static const TunedEntry kTuned[] = {
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
   const int bn = (c.kind == 0 ? 2 : 1) * c.tn * 32;
+  if (c.kind != 0) {  // dynamic LDS of the k-split kernels must fit the CU's 160 KB
+    const size_t tile = (size_t)c.kind * (c.tm + c.tn) * 32 * (c.a * BK + 4) * sizeof(float);
+    const size_t red = (size_t)c.a * c.tm * c.tn * 16 * 64 * sizeof(float);
+    if ((tile > red ? tile : red) > 163840) return false;
+  }
   return p.N % bn == 0;
 }
 
@@ -500,7 +547,7 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
   const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
   const int kt = p.K / BK;
   const int steps = c.kind == 0 ? kt : (kt + c.a - 1) / c.a;
-  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)(c.tm + c.tn) * 32 * (c.a * 32 + 4) * 4.0;
+  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)c.kind * (c.tm + c.tn) * 32 * (c.a * 32 + 4) * 4.0;
   double per_cu = floor(163840.0 / lds);
   if (per_cu > 32.0 / waves) per_cu = 32.0 / waves;
   if (per_cu > 4) per_cu = 4;
@@ -508,8 +555,8 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
   const double rounds = ceil(wgs / (256.0 * per_cu));
   const double resident = wgs < 256.0 * per_cu ? ceil(wgs / 256.0) : per_cu;
   const double share = (waves * resident) / 4.0 > 1.0 ? (waves * resident) / 4.0 : 1.0;
-  const double step = c.tm * c.tn * 16 * 64.0 * share + 700.0;
-  return rounds * (steps * step + 2500.0 + (c.kind == 1 ? 600.0 : 0.0));
+  const double step = c.tm * c.tn * 16 * 64.0 * share + (c.kind == 2 ? 300.0 : 700.0);
+  return rounds * (steps * step + 2500.0 + (c.kind != 0 ? 600.0 : 0.0));
 }
 
 int gemm_pick_config(int mode, const GemmParams& p) {

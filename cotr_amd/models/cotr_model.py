@@ -208,7 +208,7 @@ class COTR(nn.Module):
         return lib
 
     def _release(self):
-        if self._handle is not None:
+        if self.__dict__.get('_handle') is not None:
             try:
                 _lib.load_library().cotr_destroy(self._handle)
             except Exception:

@@ -22,6 +22,7 @@ make_golden = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(make_golden)
 
 PX_BAR = 1e-3
+SHAPE_NOISE_PX = 3e-4  # same math, different fp32 summation order between launch configurations
 _models = {}
 
 
@@ -85,20 +86,25 @@ def test_encode_chunking_b40():
     m = hip_model()
     out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
     tail = m(img[33:35].cuda(), qs[33:35].cuda())['pred_corrs'].cpu()
-    assert torch.equal(out[33:35], tail)                       # pairs never interact: bit-identical
+    # pairs never interact; only the fp32 summation order differs (the GEMM launch configuration, hence the
+    # K-split, is chosen per problem shape), so the two runs agree to rounding, not bit for bit
+    assert cotr_oracle.px_err(out[33:35], tail) < SHAPE_NOISE_PX
+    again = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    assert torch.equal(out, again)                             # same shape -> deterministic, bit-identical
     assert cotr_oracle.px_err(tail, cotr_oracle.cotr_forward(sd, img[33:35], qs[33:35])) < PX_BAR
 
 
 def test_decode_chunking_q40000_and_query_independence():
     """Q above one decoder pass (DEC_ROWS = 32768), as the dense pass does (inference_helper.py:116-127);
-    every query is independent of the others, so any subset must reproduce bit-for-bit."""
+    every query is independent of the others, so any subset must reproduce (to fp32 summation order)."""
     sd = synth_state_dict(0)
     img, qs = synth_inputs(1, 40000, seed=11)
     m = hip_model()
     out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
     sub = torch.cat([qs[:, :100], qs[:, 39000:39100]], 1)
     out_sub = m(img.cuda(), sub.cuda())['pred_corrs'].cpu()
-    assert torch.equal(out_sub[:, :100], out[:, :100]) and torch.equal(out_sub[:, 100:], out[:, 39000:39100])
+    assert cotr_oracle.px_err(out_sub[:, :100], out[:, :100]) < SHAPE_NOISE_PX
+    assert cotr_oracle.px_err(out_sub[:, 100:], out[:, 39000:39100]) < SHAPE_NOISE_PX
     assert cotr_oracle.px_err(out_sub, cotr_oracle.cotr_forward(sd, img, sub)) < PX_BAR
     assert not torch.isnan(out).any()
 
