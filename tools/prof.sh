@@ -1,11 +1,12 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the benchmark command; summaries land in gpurun_out/prof_<tag>/
+# rocprofv3 kernel trace + stats of the benchmark command; outputs land in gpurun_out/prof_<tag>/
 tag=${1:-r1}
 shift
 export TMPDIR=/tmp
-out=$PWD/gpurun_out/prof_$tag
+root=$PWD
+out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $out -o $tag -- python $OLDPWD/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $out/run.log 2>&1
-cd $OLDPWD
-ls -R $out | head -30
+rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $out -o $tag -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $out/run.log 2>&1
+cd $root
+ls $out | head -30
