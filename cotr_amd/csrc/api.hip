@@ -155,10 +155,20 @@ GemmParams base_params() {
   return p;
 }
 
-// y[M,N] = epi(x (+x2) . w^T)
+// LayerNorm(s) applied to the rows of x before the contraction (nn.LayerNorm(256), eps 1e-5):
+// w/b = first norm, w2/b2 = optional second norm (decoder.norm after norm3), out = where the normalised
+// rows are materialised (the next residual add reads them).
+struct LnSpec {
+  const float *w = nullptr, *b = nullptr, *w2 = nullptr, *b2 = nullptr;
+  float* out = nullptr;
+};
+
+// y[M,N] = epi( (LN(x) (+x2)) . w^T ).  With an LnSpec the norm runs as the GEMM's prologue when the launch
+// configuration keeps whole rows in LDS (K == 256, 8-wavefront K-split: the one-pair regime); otherwise as
+// separate layernorm launches into ln.out followed by the plain GEMM (batched regime).
 int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_period, int a2_width,
            const float* w, const float* bias, const float* residual, int relu, float colscale, int colscale_n,
-           float* y, int M, int N, int K, hipStream_t s) {
+           float* y, int M, int N, int K, hipStream_t s, const LnSpec* ln = nullptr) {
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K;
   p.A = x; p.lda = K;
@@ -166,6 +176,19 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
   p.W = w; p.C = y; p.ldc = N;
   p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
   p.colscale = colscale; p.colscale_n = colscale_n;
+  if (ln != nullptr && ln->w != nullptr) {
+    int cfg = gemm_pick_config(GEMM_DENSE, p);
+    if (K == D && !gemm_cfg_supports_ln(cfg) && M <= 4096) cfg = 3;  // the 8-wavefront K-split, 32x32 tile
+    if (K == D && gemm_cfg_supports_ln(cfg)) {
+      p.ln_w = ln->w; p.ln_b = ln->b; p.ln2_w = ln->w2; p.ln2_b = ln->b2; p.ln_out = ln->out;
+      KCHK(h, launch_gemm_cfg(GEMM_DENSE, cfg, p, s), "linear+layernorm");
+      return COTR_OK;
+    }
+    if (ln->out == nullptr) { h->err = "linear: LayerNorm fallback needs an output buffer"; return COTR_ERR_ARG; }
+    KCHK(h, launch_layernorm(x, ln->w, ln->b, ln->out, M, s), "layernorm");
+    if (ln->w2) KCHK(h, launch_layernorm(ln->out, ln->w2, ln->b2, ln->out, M, s), "layernorm");
+    p.A = ln->out;
+  }
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
   return COTR_OK;
 }
@@ -456,7 +479,7 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   // scratch carve (floats per pair)
   const size_t n_stem = (size_t)128 * 256 * 64, n_pool = (size_t)64 * 128 * 64, n_act = (size_t)64 * 128 * 256;
   const size_t n_tok = (size_t)TOK * D;
-  const size_t per_pair = n_stem + n_pool + 5 * n_act + 4 * n_tok + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
+  const size_t per_pair = n_stem + n_pool + 5 * n_act + 6 * n_tok + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
   {
     int r = ensure(h, h->enc_scr, per_pair * Bc_max);
     if (r) return r;
@@ -472,6 +495,8 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   float* t_src = p; p += n_tok * Bc_max;
   float* t_alt = p; p += n_tok * Bc_max;
   float* t_tmp = p; p += n_tok * Bc_max;
+  float* t_x1 = p; p += n_tok * Bc_max;
+  float* t_pre2 = p; p += n_tok * Bc_max;
   float* t_ao = p; p += n_tok * Bc_max;
   float* t_qkv = p; p += (size_t)TOK * 3 * D * Bc_max;
   float* t_hid = p; p += (size_t)TOK * FFN * Bc_max;
@@ -523,26 +548,40 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
     if ((r = linear(h, x, nullptr, 0, 1, 0, h->ip_w, h->ip_b, nullptr, 0, 1.f, 0, t_src, M, D, CFEAT, s))) return r;
     if ((r = tap_save(h, "src", t_src, (size_t)M * D, s))) return r;
     prof_mark(h, "input_proj", s);
-    // ---- encoder --------------------------------------------------------------------------
-    float* cur = t_src;
+    // ---- encoder (transformer.py:143-159, post-norm) ----------------------------------------
+    // Every LayerNorm runs as the prologue of the GEMM that consumes it: norm2 of layer i-1 in the QKV
+    // projection of layer i (which also materialises the layer input `xin` for the residual), norm1 in
+    // linear1 (materialising x1), norm2 of the last layer in the decoder K/V projection (-> memory).
     float* mem_c = memory + (size_t)b0 * TOK * D;
+    const float* xin = t_src;      // normalised input of the current layer
+    const float* pre2 = nullptr;   // un-normalised output of the previous layer
     for (size_t li = 0; li < h->enc.size(); ++li) {
       const EncW& e = h->enc[li];
       // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
-      if ((r = linear(h, cur, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
+      if (li == 0) {
+        if ((r = linear(h, t_src, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
+      } else {
+        const EncW& pe = h->enc[li - 1];
+        LnSpec ln; ln.w = pe.n2w; ln.b = pe.n2b; ln.out = t_alt;
+        if ((r = linear(h, pre2, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s, &ln))) return r;
+        xin = t_alt;
+      }
       KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
-      if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, cur, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
-      KCHK(h, launch_layernorm(t_tmp, e.n1w, e.n1b, t_tmp, M, s), "layernorm");
-      if ((r = linear(h, t_tmp, nullptr, 0, 1, 0, e.l1w, e.l1b, nullptr, 1, 1.f, 0, t_hid, M, FFN, D, s))) return r;
-      float* nxt = (li + 1 == h->enc.size()) ? mem_c : (cur == t_src ? t_alt : t_src);
-      if ((r = linear(h, t_hid, nullptr, 0, 1, 0, e.l2w, e.l2b, t_tmp, 0, 1.f, 0, nxt, M, D, FFN, s))) return r;
-      KCHK(h, launch_layernorm(nxt, e.n2w, e.n2b, nxt, M, s), "layernorm");
-      cur = nxt;
+      if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
+      LnSpec ln1; ln1.w = e.n1w; ln1.b = e.n1b; ln1.out = t_x1;
+      if ((r = linear(h, t_tmp, nullptr, 0, 1, 0, e.l1w, e.l1b, nullptr, 1, 1.f, 0, t_hid, M, FFN, D, s, &ln1))) return r;
+      if ((r = linear(h, t_hid, nullptr, 0, 1, 0, e.l2w, e.l2b, t_x1, 0, 1.f, 0, t_pre2, M, D, FFN, s))) return r;
+      pre2 = t_pre2;
     }
     prof_mark(h, "encoder", s);
-    // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195)
+    // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195);
+    //      memory = norm2 of the last encoder layer, applied here
     float* kv_c = kv + (size_t)b0 * TOK * KVLD;
-    if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
+    {
+      const EncW& pe = h->enc.back();
+      LnSpec ln; ln.w = pe.n2w; ln.b = pe.n2b; ln.out = mem_c;
+      if ((r = linear(h, pre2, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s, &ln))) return r;
+    }
     prof_mark(h, "dec_kv", s);
   }
   h->taps["memory"] = {memory, (size_t)B * TOK * D};
@@ -573,7 +612,7 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
   const int nb_max = B < pairs_per ? B : pairs_per;
   const size_t Rmax = (size_t)nb_max * q_chunk;
   {
-    int r = ensure(h, h->dec_scr, Rmax * (5 * D + FFN));
+    int r = ensure(h, h->dec_scr, Rmax * (7 * D + FFN));
     if (r) return r;
   }
   float* p = h->dec_scr.ptr;
@@ -581,7 +620,9 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
   float* d_tgt = p; p += Rmax * D;
   float* d_q = p; p += Rmax * D;
   float* d_ao = p; p += Rmax * D;
-  float* d_tmp = p; p += Rmax * D;
+  float* d_pre2 = p; p += Rmax * D;
+  float* d_t2 = p; p += Rmax * D;
+  float* d_pre3 = p; p += Rmax * D;
   float* d_hid = p; p += Rmax * FFN;
 
   prof_mark(h, "dec_begin", s);
@@ -595,29 +636,35 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
       const float* kv_c = kv + (size_t)b0 * TOK * KVLD;
       KCHK(h, launch_posenc(qsrc, d_qpos, nb, nq, Q, s), "posenc");
       int r;
+      // transformer.py:185-201 per layer; norm3 of layer l-1 is the prologue of layer l's q projection
+      // (which materialises tgt for the residual), norm2 the prologue of linear1 (materialising t2).
       for (int li = 0; li < L; ++li) {
         const DecW& w = h->dec[li];
         // q = Wq(tgt + query_pos) * 32^-0.5 ; tgt == 0 at layer 0 (transformer.py:54)
         if (li == 0) {
           if ((r = linear(h, d_qpos, nullptr, 0, 1, 0, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d_q, R, D, D, s))) return r;
         } else {
-          if ((r = linear(h, d_tgt, d_qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d_q, R, D, D, s))) return r;
+          const DecW& pw = h->dec[li - 1];
+          LnSpec ln; ln.w = pw.n3w; ln.b = pw.n3b; ln.out = d_tgt;
+          if ((r = linear(h, d_pre3, d_qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d_q, R, D, D, s, &ln))) return r;
         }
         KCHK(h, launch_attention(d_q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d_ao, D, nb, nq, s),
              "attention");
-        if ((r = linear(h, d_ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d_tgt, 0, 1.f, 0, d_tmp, R, D, D, s))) return r;
-        KCHK(h, launch_layernorm(d_tmp, w.n2w, w.n2b, d_tmp, R, s), "layernorm");
-        if ((r = linear(h, d_tmp, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d_hid, R, FFN, D, s))) return r;
-        if ((r = linear(h, d_hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d_tmp, 0, 1.f, 0, d_tgt, R, D, FFN, s))) return r;
-        KCHK(h, launch_layernorm(d_tgt, w.n3w, w.n3b, d_tgt, R, s), "layernorm");
+        if ((r = linear(h, d_ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d_tgt, 0, 1.f, 0, d_pre2, R, D, D, s))) return r;
+        LnSpec ln2; ln2.w = w.n2w; ln2.b = w.n2b; ln2.out = d_t2;
+        if ((r = linear(h, d_pre2, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d_hid, R, FFN, D, s, &ln2))) return r;
+        if ((r = linear(h, d_hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d_t2, 0, 1.f, 0, d_pre3, R, D, FFN, s))) return r;
       }
-      // decoder.norm + corr_embed on the last layer only
-      KCHK(h, launch_layernorm(d_tgt, h->dn_w, h->dn_b, d_tmp, R, s), "layernorm");
-      if ((r = linear(h, d_tmp, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d_ao, R, D, D, s))) return r;
+      // norm3 of the last layer, then decoder.norm, then corr_embed - on the last layer only
+      {
+        const DecW& lw = h->dec[L - 1];
+        LnSpec ln; ln.w = lw.n3w; ln.b = lw.n3b; ln.w2 = h->dn_w; ln.b2 = h->dn_b; ln.out = d_tgt;
+        if ((r = linear(h, d_pre3, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d_ao, R, D, D, s, &ln))) return r;
+      }
       if ((r = linear(h, d_ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d_q, R, D, D, s))) return r;
       KCHK(h, launch_head2(d_q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
       if ((r = tap_save(h, "query_pos", d_qpos, (size_t)R * D, s))) return r;
-      if ((r = tap_save(h, "hs", d_tmp, (size_t)R * D, s))) return r;
+      if ((r = tap_save(h, "hs", d_tgt, (size_t)R * D, s))) return r;
     }
   }
   prof_mark(h, "decoder", s);
@@ -636,12 +683,12 @@ int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   const size_t L = h->dec.empty() ? 6 : h->dec.size();
   const size_t Bc = B < ENC_CHUNK ? B : ENC_CHUNK;
   const size_t per_pair = (size_t)128 * 256 * 64 + (size_t)64 * 128 * 64 + 5 * (size_t)64 * 128 * 256 +
-                          4 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
+                          6 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
   const size_t q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
   const size_t pairs_per = (Q > 0 && Q < DEC_ROWS) ? (DEC_ROWS / Q) : 1;
   const size_t nb = (size_t)B < pairs_per ? B : pairs_per;
   size_t fl = h->wfloats + (size_t)TOK * D + (size_t)B * TOK * (D + L * 2 * D) + per_pair * Bc +
-              nb * q_chunk * (5 * D + FFN);
+              nb * q_chunk * (7 * D + FFN);
   *bytes = fl * sizeof(float);
   return COTR_OK;
 }

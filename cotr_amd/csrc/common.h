@@ -44,12 +44,24 @@ struct GemmParams {
   int relu;
   float colscale;
   int colscale_n;
+  // LayerNorm prologue (k-split kernel, DENSE, K == 256 == NWK*32: the A tile holds whole rows):
+  //   A'' = LN2(LN1(A)) (+ A2 as above, added AFTER the norm); ln2 optional (decoder.norm after norm3).
+  // ln_out (optional, [M][256]): the normalised rows (before the A2 add) are written by the workgroups
+  // of the first 256 output columns, so the residual path of the next GEMM can read them.
+  const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
+  const float* ln_w;
+  const float* ln_b;
+  const float* ln2_w;
+  const float* ln2_b;
+  float* ln_out;
 };
 
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s);            // tuned / modelled config
 int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s);  // explicit config (tuning, tests)
 int gemm_pick_config(int mode, const GemmParams& p);
 int gemm_num_configs();
+bool gemm_cfg_supports_ln(int cfg);
+const float* gemm_zero_buffer();  // per-process device buffer of zeros (LDS-DMA padding source)  // can this configuration run the LayerNorm prologue (K == 256)?
 
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]
 int launch_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,

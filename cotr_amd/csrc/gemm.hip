@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 // accumulators are summed through LDS in a fixed order (deterministic, no atomics, no second
 // launch) and the same fused epilogue is applied.
 // ---------------------------------------------------------------------------------------------
-template <int NWK, int TM, int TN, int MODE, int DB>
+template <int NWK, int TM, int TN, int MODE, int DB, int LN>
 __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
   constexpr int NT = NWK * 64;
   constexpr int BM = TM * 32, BN = TN * 32;
@@ -289,6 +289,8 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 
   f32x4 ra[PA], rw[PW];
   const int tiles_per_tap = (MODE == GEMM_CONV) ? p.Cin / BK : 1;
+  constexpr bool ln_pro = LN != 0;  // host: DENSE, K == 256 == KS (one step), ln_w != nullptr
+  static_assert(!LN || (MODE == GEMM_DENSE && KS == 256), "LayerNorm prologue needs whole rows per step");
 
   auto load_tile = [&](int st) {
 #if defined(COTR_ABL) && COTR_ABL == 1  // ablation: only the first global load
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
         f32x4 v = z;
         if (a_ok[i] && k_ok) {
           v = *reinterpret_cast<const f32x4*>(a_ptr[i] + st * KS);
-          if (use_a2) v += *reinterpret_cast<const f32x4*>(a2_ptr[i] + st * KS);
+          if (use_a2 && !ln_pro) v += *reinterpret_cast<const f32x4*>(a2_ptr[i] + st * KS);
         }
         ra[i] = v;
       }
@@ -368,8 +370,116 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
     }
   };
 
-  load_tile(0);
-  if constexpr (DB) {
+  // LayerNorm prologue, in registers: with 8 wavefronts a thread's float4 i is row (wave + 8*i),
+  // columns lane*4..+3 of the 256-wide row, so a row is exactly one wavefront-wide register and the
+  // statistics are wave reductions; the PA rows are reduced in lock-step to overlap shuffle latency.
+  auto ln_regs = [&]() {
+    if constexpr (LN != 0) {
+      f32x4 a2v[PA];
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        a2v[i] = (use_a2 && a_ok[i]) ? *reinterpret_cast<const f32x4*>(a2_ptr[i]) : z;
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && p.ln2_w == nullptr) break;
+        const f32x4 ww = *reinterpret_cast<const f32x4*>((pass == 0 ? p.ln_w : p.ln2_w) + lc4 * 4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>((pass == 0 ? p.ln_b : p.ln2_b) + lc4 * 4);
+        float sum[PA], sq[PA];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) sum[i] = ra[i][0] + ra[i][1] + ra[i][2] + ra[i][3];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+          for (int i = 0; i < PA; ++i) sum[i] += __shfl_xor(sum[i], off);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const float mean = sum[i] * (1.f / 256.f);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ra[i][c] -= mean;
+          sq[i] = ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+          for (int i = 0; i < PA; ++i) sq[i] += __shfl_xor(sq[i], off);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const float rstd = 1.f / sqrtf(sq[i] * (1.f / 256.f) + 1e-5f);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ra[i][c] = ra[i][c] * rstd * ww[c] + bb[c];
+        }
+      }
+      const bool writer = p.ln_out != nullptr && n0 < 256 && lc4 * 4 >= n0 && lc4 * 4 < n0 + BN;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int m = m0 + lr + 8 * i;
+        if (writer && a_ok[i]) *reinterpret_cast<f32x4*>(p.ln_out + (size_t)m * 256 + lc4 * 4) = ra[i];
+        if (a_ok[i]) ra[i] += a2v[i];
+        else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  // DB == 2: global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write pass).  With
+  // 8 wavefronts one wave instruction moves exactly one padded row (64 lanes x 16 B = 1024 B of data),
+  // so the LDS destination is wave-uniform as the instruction requires; out-of-range rows / padded taps
+  // read a zero buffer instead.  The transfer of step st+1 runs under the MFMAs of step st.
+  auto dma_tile = [&](int st, int buf) {
+    static_assert(DB != 2 || C4 == 64, "one wave instruction per LDS row needs 8 wavefronts");
+    float* As = smem + buf * TILE;
+    float* Ws = As + BM * LD;
+    const int kt = st * NWK + ktl;
+    const bool k_ok = kt < KT;
+    const float* zsrc = p.zeros;
+    if constexpr (MODE == GEMM_DENSE) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const float* src = (a_ok[i] && k_ok) ? a_ptr[i] + st * KS : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(As + (lr + 8 * i) * LD), 16, 0, 0);
+      }
+    } else {
+      const int tap = kt / tiles_per_tap;
+      const int c0 = (kt - tap * tiles_per_tap) * BK;
+      const int ky = tap / p.ksize;
+      const int kx = tap - ky * p.ksize;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int hi = c_hi0[i] + ky, wi = c_wi0[i] + kx;
+        const bool ok = a_ok[i] && k_ok && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
+        const float* src = ok ? a_ptr[i] + ((size_t)hi * (2 * p.Win) + wi) * p.Cin + c0 : zsrc;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(As + (lr + 8 * i) * LD), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const float* src = k_ok ? w_ptr[i] + st * KS : zsrc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Ws + (lr + 8 * i) * LD), 16, 0, 0);
+    }
+  };
+
+  if constexpr (DB == 2) {
+    dma_tile(0, 0);
+    __syncthreads();
+    for (int st = 0; st < steps; ++st) {
+      if (st + 1 < steps) dma_tile(st + 1, (st + 1) & 1);
+      compute(st & 1);
+      __syncthreads();
+    }
+  } else if constexpr (LN) {
+    load_tile(0);
+    // K == 256 is a single step: normalise in registers, stage once, compute (one LDS stage is enough)
+    ln_regs();
+    store_tile(0);
+    __syncthreads();
+    compute(0);
+    __syncthreads();
+  } else if constexpr (DB) {
+    load_tile(0);
     // two LDS stages, ONE barrier per K step: a wavefront that has finished its MFMAs of step st
     // writes the tile of step st+1 into the other stage while slower wavefronts still compute,
     // and the global loads of step st+2 are in flight across the whole step.
@@ -385,6 +495,7 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
       __syncthreads();
     }
   } else {
+    load_tile(0);
     for (int st = 0; st < steps; ++st) {
       __syncthreads();
       store_tile(0);
@@ -436,7 +547,7 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 // (tools/tune_gemm.py -> gemm_tuned.inc) with a heuristic for shapes not in the table.
 // ---------------------------------------------------------------------------------------------
 struct GemmCfg {
-  int kind;  // 0 = spatial (WM=WN=2), 1 = k-split, 2 = k-split with two LDS stages
+  int kind;  // 0 = spatial (WM=WN=2), 1 = k-split, 2 = k-split with two LDS stages, 3 = k-split LDS-DMA (two stages)
   int a, tm, tn;  // spatial: a unused; k-split: a = NWK
 };
 static const GemmCfg kCfgs[] = {
@@ -459,6 +570,9 @@ static const GemmCfg kCfgs[] = {
     {2, 8, 1, 2},   // 16 k-split 8 waves, 32x64, double-buffered
     {2, 4, 2, 1},   // 17 k-split 4 waves, 64x32, double-buffered
     {2, 2, 2, 2},   // 18 k-split 2 waves, 64x64, double-buffered
+    {3, 8, 1, 1},   // 19 k-split 8 waves, 32x32, LDS-DMA (global_load_lds) double-buffered
+    {3, 8, 1, 2},   // 20 k-split 8 waves, 32x64, LDS-DMA
+    {3, 8, 2, 1},   // 21 k-split 8 waves, 64x32, LDS-DMA
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -479,21 +593,38 @@ static constexpr size_t ks_smem() {
   return tile > red ? tile : red;
 }
 
-template <int NWK, int TM, int TN, int MODE, int DB = 0>
-static int launch_ks(const GemmParams& p, hipStream_t s) {
+template <int NWK, int TM, int TN, int MODE, int DB, int LN>
+static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
   constexpr int BM = TM * 32, BN = TN * 32;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  constexpr size_t smem = ks_smem<NWK, TM, TN, DB>();
+  constexpr size_t smem = ks_smem<NWK, TM, TN, (DB && !LN)>();  // the LN variant is single-step: one stage
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_kernel<NWK, TM, TN, MODE, DB>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_kernel<NWK, TM, TN, MODE, DB, LN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles), dim3(NWK * 64), smem, s, p);
+  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB, LN>), dim3(tiles), dim3(NWK * 64), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+template <int NWK, int TM, int TN, int MODE, int DB = 0>
+static int launch_ks(const GemmParams& p, hipStream_t s) {
+  if constexpr (MODE == GEMM_DENSE && NWK == 8) {  // the LayerNorm-prologue instantiation (separate: +40 VGPRs)
+    if (p.ln_w != nullptr) return p.K == 256 ? launch_ks_impl<NWK, TM, TN, MODE, DB, 1>(p, s) : -1;
+  }
+  if (p.ln_w != nullptr) return -1;
+  if constexpr (DB == 2) {
+    if (p.A2 != nullptr) return -1;  // the x+pos prologue needs the register path
+    GemmParams q = p;
+    if (q.zeros == nullptr) q.zeros = gemm_zero_buffer();
+    if (q.zeros == nullptr) return -2;
+    return launch_ks_impl<NWK, TM, TN, MODE, DB, 0>(q, s);
+  } else {
+    return launch_ks_impl<NWK, TM, TN, MODE, DB, 0>(p, s);
+  }
 }
 
 template <int MODE>
@@ -518,24 +649,30 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 16: return launch_ks<8, 1, 2, MODE, 1>(p, s);
     case 17: return launch_ks<4, 2, 1, MODE, 1>(p, s);
     case 18: return launch_ks<2, 2, 2, MODE, 1>(p, s);
+    case 19: return launch_ks<8, 1, 1, MODE, 2>(p, s);
+    case 20: return launch_ks<8, 1, 2, MODE, 2>(p, s);
+    case 21: return launch_ks<8, 2, 1, MODE, 2>(p, s);
     default: return -1;
   }
 }
 
 struct TunedEntry {
-  int mode, M, N, K, cfg;
+  int mode, M, N, K;
+  int cfg;      // fastest configuration
+  int cfg_reg;  // fastest among the register-staged ones (needed when the x+pos prologue is in use)
 };
 static const TunedEntry kTuned[] = {
 #include "gemm_tuned.inc"
-    {-1, 0, 0, 0, 0}};
+    {-1, 0, 0, 0, 0, 0}};
 
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
   const int bn = (c.kind == 0 ? 2 : 1) * c.tn * 32;
   if (c.kind != 0) {  // dynamic LDS of the k-split kernels must fit the CU's 160 KB
-    const size_t tile = (size_t)c.kind * (c.tm + c.tn) * 32 * (c.a * BK + 4) * sizeof(float);
+    const size_t tile = (size_t)(c.kind >= 2 ? 2 : 1) * (c.tm + c.tn) * 32 * (c.a * BK + 4) * sizeof(float);
     const size_t red = (size_t)c.a * c.tm * c.tn * 16 * 64 * sizeof(float);
     if ((tile > red ? tile : red) > 163840) return false;
+    if (c.kind == 3 && (p.A2 != nullptr || p.ln_w != nullptr)) return false;  // LDS-DMA has no register prologue
   }
   return p.N % bn == 0;
 }
@@ -547,7 +684,7 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
   const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
   const int kt = p.K / BK;
   const int steps = c.kind == 0 ? kt : (kt + c.a - 1) / c.a;
-  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)c.kind * (c.tm + c.tn) * 32 * (c.a * 32 + 4) * 4.0;
+  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)(c.kind >= 2 ? 2 : 1) * (c.tm + c.tn) * 32 * (c.a * 32 + 4) * 4.0;
   double per_cu = floor(163840.0 / lds);
   if (per_cu > 32.0 / waves) per_cu = 32.0 / waves;
   if (per_cu > 4) per_cu = 4;
@@ -555,14 +692,17 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
   const double rounds = ceil(wgs / (256.0 * per_cu));
   const double resident = wgs < 256.0 * per_cu ? ceil(wgs / 256.0) : per_cu;
   const double share = (waves * resident) / 4.0 > 1.0 ? (waves * resident) / 4.0 : 1.0;
-  const double step = c.tm * c.tn * 16 * 64.0 * share + (c.kind == 2 ? 300.0 : 700.0);
+  const double step = c.tm * c.tn * 16 * 64.0 * share + (c.kind >= 2 ? 300.0 : 700.0);
   return rounds * (steps * step + 2500.0 + (c.kind != 0 ? 600.0 : 0.0));
 }
 
 int gemm_pick_config(int mode, const GemmParams& p) {
   if (mode == GEMM_STEM) return 1;
   for (const TunedEntry* e = kTuned; e->mode >= 0; ++e)
-    if (e->mode == mode && e->M == p.M && e->N == p.N && e->K == p.K && cfg_fits(e->cfg, p)) return e->cfg;
+    if (e->mode == mode && e->M == p.M && e->N == p.N && e->K == p.K) {
+      if (cfg_fits(e->cfg, p)) return e->cfg;
+      if (cfg_fits(e->cfg_reg, p)) return e->cfg_reg;
+    }
   int best = -1;
   double best_cost = 0;
   for (int i = 0; i < kNumCfgs; ++i) {
@@ -593,8 +733,23 @@ int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s) {
   }
 }
 
+const float* gemm_zero_buffer() {
+  static float* z = nullptr;  // one device per process (one process per GPU)
+  if (z == nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&z), 4096) != hipSuccess) return nullptr;
+    if (hipMemset(z, 0, 4096) != hipSuccess) return nullptr;
+  }
+  return z;
+}
+
+// The LayerNorm prologue needs a configuration whose K step is the whole row: k-split with 8 wavefronts.
+bool gemm_cfg_supports_ln(int cfg) {
+  return cfg >= 0 && cfg < kNumCfgs && (kCfgs[cfg].kind == 1 || kCfgs[cfg].kind == 2) && kCfgs[cfg].a == 8;
+}
+
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s) {
   const int cfg = gemm_pick_config(mode, p);
   if (cfg < 0) return -1;
+  if (p.ln_w != nullptr && !(mode == GEMM_DENSE && p.K == 256 && gemm_cfg_supports_ln(cfg))) return -1;
   return launch_gemm_cfg(mode, cfg, p, s);
 }
