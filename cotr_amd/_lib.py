@@ -45,6 +45,9 @@ _PROTOS = {
     'cotr_op_layernorm': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_posenc': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_gemm_num_configs': (ctypes.c_int, []),
+    'cotr_set_stream_overlap': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_ln_fusion_min_rows': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_splits': (ctypes.c_int, [ctypes.c_int]),
     'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),

@@ -56,6 +56,23 @@ struct Arena {
 };
 
 thread_local std::string g_create_error;
+// LayerNorm as the prologue of the consuming GEMM (instead of its own 2 us launch) is implemented and tested but
+// OFF by default: every column tile of a row block redoes the row statistics (48 cross-lane shuffles), which
+// measured slower than the separate launch at every batch size tried (B=1: 1.162 vs 1.142 ms, B=8: 4.40 vs 4.11 ms;
+// tools/time_forward.py).  cotr_set_ln_fusion_min_rows(n) turns it on for GEMMs with >= n rows.
+int g_ln_fuse_min_rows = 0x7fffffff;
+// XCD mapping of GEMM workgroups: -1 automatic (by operand sizes), 0 column-split, 1 row-split (tuning hook)
+int g_xcd_msplit = 0;
+
+int pick_msplit(const GemmParams& p, int mode) {
+  if (g_xcd_msplit >= 0) return g_xcd_msplit;
+  // bytes each XCD must pull privately: column-split replicates the activations, row-split the weights
+  double a_bytes = (double)p.M * p.K * 4.0;
+  if (mode == GEMM_CONV) a_bytes /= (double)(p.ksize * p.ksize);  // im2col taps re-read the same pixels
+  if (mode == GEMM_STEM) return 0;
+  const double w_bytes = (double)p.N * p.K * 4.0;
+  return a_bytes > w_bytes ? 1 : 0;
+}
 
 }  // namespace
 
@@ -85,8 +102,15 @@ struct cotr_ctx {
   std::map<std::string, std::pair<const float*, size_t>> taps;
   bool keep_taps = false;
   std::map<std::string, Arena> tap_store;
+  // side stream for work that does not depend on the main chain (downsample convs, K/V of decoder layers >= 1,
+  // the query-side prologue of layer 0); joined back with events.  At one pair every kernel leaves most CUs
+  // idle and is latency-bound, so concurrent independent kernels are nearly free.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_kv = nullptr, ev_q = nullptr;
+  bool kv_pending = false;  // ev_kv recorded and not yet waited for by a decode
+  bool overlap = false;  // measured slower in eager mode: cross-stream event waits cost more than they hide
   // profiling
-  bool prof = false;
+  int prof = 0;  // 0 off, 1 per stage, 2 per kernel launch
   std::vector<std::string> prof_names;
   std::vector<hipEvent_t> prof_ev;
 };
@@ -121,8 +145,8 @@ int ensure(cotr_ctx* h, Arena& a, size_t floats) {
   return COTR_OK;
 }
 
-void prof_mark(cotr_ctx* h, const char* name, hipStream_t s) {
-  if (!h->prof) return;
+void prof_mark(cotr_ctx* h, const char* name, hipStream_t s, int level = 1) {
+  if (h->prof < level || (h->prof >= 2 && level == 1 && strcmp(name, "begin") != 0 && strcmp(name, "dec_begin") != 0)) return;
   hipEvent_t ev;
   if (hipEventCreate(&ev) != hipSuccess) return;
   (void)hipEventRecord(ev, s);
@@ -147,6 +171,22 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
   return COTR_OK;
 }
 
+bool use_side(const cotr_ctx* h) { return h->overlap && h->side != nullptr && h->prof < 2; }
+
+// side stream continues from the current point of `main`
+int fork_side(cotr_ctx* h, hipStream_t main) {
+  HIPCHK(h, hipEventRecord(h->ev_fork, main));
+  HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  return COTR_OK;
+}
+
+// `main` continues only after everything enqueued on the side stream so far
+int join_side(cotr_ctx* h, hipStream_t main) {
+  HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+  HIPCHK(h, hipStreamWaitEvent(main, h->ev_join, 0));
+  return COTR_OK;
+}
+
 GemmParams base_params() {
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -168,28 +208,34 @@ struct LnSpec {
 // separate layernorm launches into ln.out followed by the plain GEMM (batched regime).
 int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_period, int a2_width,
            const float* w, const float* bias, const float* residual, int relu, float colscale, int colscale_n,
-           float* y, int M, int N, int K, hipStream_t s, const LnSpec* ln = nullptr) {
+           float* y, int M, int N, int K, hipStream_t s, const LnSpec* ln = nullptr, int ldc = 0) {
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K;
   p.A = x; p.lda = K;
   p.A2 = x2; p.lda2 = K; p.a2_row_mod = x2_row_mod; p.a2_period = a2_period; p.a2_width = a2_width;
-  p.W = w; p.C = y; p.ldc = N;
+  p.W = w; p.C = y; p.ldc = ldc ? ldc : N;
   p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
   p.colscale = colscale; p.colscale_n = colscale_n;
   if (ln != nullptr && ln->w != nullptr) {
     int cfg = gemm_pick_config(GEMM_DENSE, p);
-    if (K == D && !gemm_cfg_supports_ln(cfg) && M <= 4096) cfg = 3;  // the 8-wavefront K-split, 32x32 tile
-    if (K == D && gemm_cfg_supports_ln(cfg)) {
+    p.xcd_msplit = pick_msplit(p, GEMM_DENSE);
+  const bool want_fused = K == D && M >= g_ln_fuse_min_rows;
+    if (want_fused && !gemm_cfg_supports_ln(cfg) && M <= 4096) cfg = 3;  // the 8-wavefront K-split, 32x32 tile
+    if (want_fused && gemm_cfg_supports_ln(cfg)) {
       p.ln_w = ln->w; p.ln_b = ln->b; p.ln2_w = ln->w2; p.ln2_b = ln->b2; p.ln_out = ln->out;
       KCHK(h, launch_gemm_cfg(GEMM_DENSE, cfg, p, s), "linear+layernorm");
+      if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "ln+linear %dx%dx%d cfg%d", M, N, K, cfg); prof_mark(h, nm, s, 2); }
       return COTR_OK;
     }
     if (ln->out == nullptr) { h->err = "linear: LayerNorm fallback needs an output buffer"; return COTR_ERR_ARG; }
     KCHK(h, launch_layernorm(x, ln->w, ln->b, ln->out, M, s), "layernorm");
     if (ln->w2) KCHK(h, launch_layernorm(ln->out, ln->w2, ln->b2, ln->out, M, s), "layernorm");
+    if (h->prof >= 2) prof_mark(h, "layernorm", s, 2);
     p.A = ln->out;
   }
+  p.xcd_msplit = pick_msplit(p, GEMM_DENSE);
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
+  if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, gemm_pick_config(GEMM_DENSE, p)); prof_mark(h, nm, s, 2); }
   return COTR_OK;
 }
 
@@ -205,7 +251,9 @@ int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int
   p.A = x; p.lda = c.cin;
   p.W = c.w; p.C = y; p.ldc = c.cout;
   p.scale = c.scale; p.bias = c.bias; p.residual = residual; p.ldr = c.cout; p.relu = relu;
+  p.xcd_msplit = pick_msplit(p, GEMM_CONV);
   KCHK(h, launch_gemm(GEMM_CONV, p, s), "conv");
+  if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "conv%dx%d/%d %dx%dx%d cfg%d", c.k, c.k, c.stride, p.M, p.N, p.K, gemm_pick_config(GEMM_CONV, p)); prof_mark(h, nm, s, 2); }
   return COTR_OK;
 }
 
@@ -215,6 +263,7 @@ int stem(cotr_ctx* h, const ConvW& c, const float* img, float* y, int B, hipStre
   p.A = img; p.W = c.w; p.C = y; p.ldc = 64;
   p.scale = c.scale; p.bias = c.bias; p.relu = 1;
   KCHK(h, launch_gemm(GEMM_STEM, p, s), "stem");
+  if (h->prof >= 2) prof_mark(h, "stem conv7x7", s, 2);
   return COTR_OK;
 }
 
@@ -257,6 +306,15 @@ int cotr_create(cotr_handle* out, int device) {
     delete h;
     return COTR_ERR_HIP;
   }
+  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_kv, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming) != hipSuccess) {
+    g_create_error = "creating the side stream / events failed";
+    delete h;
+    return COTR_ERR_HIP;
+  }
   *out = h;
   return COTR_OK;
 }
@@ -266,6 +324,9 @@ void cotr_destroy(cotr_handle h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   prof_reset(h);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_kv, h->ev_q})
+    if (e) (void)hipEventDestroy(e);
   if (h->wbuf) (void)hipFree(h->wbuf);
   if (h->pos) (void)hipFree(h->pos);
   if (h->memkv.ptr) (void)hipFree(h->memkv.ptr);
@@ -502,6 +563,10 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   float* t_hid = p; p += (size_t)TOK * FFN * Bc_max;
 
   if (h->prof) prof_reset(h);
+  if (h->kv_pending) {  // an earlier encode's side-stream K/V may still be reading/writing the cache
+    HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));
+    h->kv_pending = false;
+  }
   prof_mark(h, "begin", s);
   for (int b0 = 0; b0 < B; b0 += ENC_CHUNK) {
     const int Bc = (B - b0) < ENC_CHUNK ? (B - b0) : ENC_CHUNK;
@@ -510,6 +575,7 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
     int ci = 0;
     { int r = stem(h, h->convs[ci++], img_c, b_stem, Bc, s); if (r) return r; }
     KCHK(h, launch_maxpool(b_stem, b_pool, Bc, 128, 128, 64, s), "maxpool");
+    prof_mark(h, "maxpool", s, 2);
     prof_mark(h, "stem+pool", s);
     if (int r = tap_save(h, "stem", b_stem, n_stem * Bc, s)) return r;
     if (int r = tap_save(h, "pool", b_pool, n_pool * Bc, s)) return r;
@@ -526,14 +592,22 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
         float* y = outbuf[flip];
         flip ^= 1;
         int r;
-        if ((r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
-        if ((r = conv(h, c2, b_t1, nullptr, 1, b_t2, Bc, H, W, s))) return r;
         const float* idt = x;
-        if (b == 0) {
-          const ConvW& cd = h->convs[ci++];
-          if ((r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
+        const bool side_ds = (b == 0) && use_side(h);
+        if (b == 0) {  // downsample branch (1x1, strided) only needs x: runs beside conv1 -> conv2
+          const ConvW& cd = h->convs[ci + 0];
+          if (side_ds) {
+            if ((r = fork_side(h, s))) return r;
+            if ((r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, h->side))) return r;
+          } else {
+            if ((r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
+          }
+          ++ci;
           idt = b_d;
         }
+        if ((r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
+        if ((r = conv(h, c2, b_t1, nullptr, 1, b_t2, Bc, H, W, s))) return r;
+        if (side_ds && (r = join_side(h, s))) return r;
         if ((r = conv(h, c3, b_t2, idt, 1, y, Bc, Ho, Wo, s))) return r;
         x = y;
         H = Ho; W = Wo;
@@ -567,6 +641,7 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
         xin = t_alt;
       }
       KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
+      prof_mark(h, "attention enc", s, 2);
       if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
       LnSpec ln1; ln1.w = e.n1w; ln1.b = e.n1b; ln1.out = t_x1;
       if ((r = linear(h, t_tmp, nullptr, 0, 1, 0, e.l1w, e.l1b, nullptr, 1, 1.f, 0, t_hid, M, FFN, D, s, &ln1))) return r;
@@ -575,14 +650,31 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
     }
     prof_mark(h, "encoder", s);
     // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195);
-    //      memory = norm2 of the last encoder layer, applied here
+    //      memory = norm2 of the last encoder layer.  Layer 0's K/V stay on the main stream (the decode needs
+    //      them first); layers >= 1 go to the side stream and overlap decoder layer 0 (joined by ev_kv).
     float* kv_c = kv + (size_t)b0 * TOK * KVLD;
     {
       const EncW& pe = h->enc.back();
-      LnSpec ln; ln.w = pe.n2w; ln.b = pe.n2b; ln.out = mem_c;
-      if ((r = linear(h, pre2, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s, &ln))) return r;
+      KCHK(h, launch_layernorm(pre2, pe.n2w, pe.n2b, mem_c, M, s), "layernorm");
+      prof_mark(h, "layernorm", s, 2);
+      const int L = (int)h->dec.size();
+      if (use_side(h) && L > 1) {
+        if ((r = fork_side(h, s))) return r;
+        if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w + (size_t)2 * D * D, h->kv_b + 2 * D, nullptr, 0, 1.f, 0,
+                        kv_c + 2 * D, M, (L - 1) * 2 * D, D, h->side, nullptr, (int)KVLD))) return r;
+        HIPCHK(h, hipEventRecord(h->ev_kv, h->side));
+        h->kv_pending = true;
+        if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, 2 * D, D, s, nullptr,
+                        (int)KVLD))) return r;
+      } else {
+        if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
+      }
     }
     prof_mark(h, "dec_kv", s);
+    if (h->kv_pending && b0 + ENC_CHUNK < B) {  // more chunks follow: finish this chunk's side K/V first
+      HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));
+      h->kv_pending = false;
+    }
   }
   h->taps["memory"] = {memory, (size_t)B * TOK * D};
   h->taps["kv"] = {kv, (size_t)B * TOK * KVLD};
@@ -591,91 +683,150 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   return COTR_OK;
 }
 
-int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, cotr_stream stream) {
-  if (!h) return COTR_ERR_ARG;
-  if (!h->loaded) { h->err = "cotr_decode before cotr_load_weights"; return COTR_ERR_STATE; }
-  if (B <= 0 || Q < 0) { h->err = "cotr_decode: B <= 0 or Q < 0"; return COTR_ERR_ARG; }
-  if (h->enc_B != B) {
-    h->err = "cotr_decode: no cached encode for this batch size (call cotr_encode first)";
-    return COTR_ERR_STATE;
-  }
-  if (Q == 0) return COTR_OK;
-  if (!queries || !out) { h->err = "cotr_decode: null queries/out"; return COTR_ERR_ARG; }
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  HIPCHK(h, hipSetDevice(h->device));
+}  // extern "C"
+
+namespace {
+
+struct DecPlan {
+  int q_chunk = 0, nb_max = 0;
+  size_t Rmax = 0;
+  float *qpos = nullptr, *tgt = nullptr, *q = nullptr, *ao = nullptr, *pre2 = nullptr, *t2 = nullptr, *pre3 = nullptr,
+        *hid = nullptr;
+  bool single_chunk = false;
+};
+
+int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
+  d.q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
+  const int pairs_per = Q < DEC_ROWS ? (DEC_ROWS / Q) : 1;
+  d.nb_max = B < pairs_per ? B : pairs_per;
+  d.Rmax = (size_t)d.nb_max * d.q_chunk;
+  d.single_chunk = d.nb_max >= B && d.q_chunk >= Q;
+  int r = ensure(h, h->dec_scr, d.Rmax * (7 * D + FFN));
+  if (r) return r;
+  float* p = h->dec_scr.ptr;
+  d.qpos = p; p += d.Rmax * D;
+  d.tgt = p; p += d.Rmax * D;
+  d.q = p; p += d.Rmax * D;
+  d.ao = p; p += d.Rmax * D;
+  d.pre2 = p; p += d.Rmax * D;
+  d.t2 = p; p += d.Rmax * D;
+  d.pre3 = p; p += d.Rmax * D;
+  d.hid = p; p += d.Rmax * FFN;
+  return COTR_OK;
+}
+
+// query-side prologue of one chunk: lin_sine encoding of the queries (cotr_model.py:34-36) and layer 0's
+// q = Wq(0 + query_pos) * 32^-0.5 (tgt == 0 at layer 0, transformer.py:54).  Depends on the queries only.
+int dec_prologue(cotr_ctx* h, const DecPlan& d, const float* qsrc, int nb, int nq, int Q, hipStream_t s) {
+  KCHK(h, launch_posenc(qsrc, d.qpos, nb, nq, Q, s), "posenc");
+  prof_mark(h, "posenc", s, 2);
+  const DecW& w = h->dec[0];
+  return linear(h, d.qpos, nullptr, 0, 1, 0, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, nb * nq, D, D, s);
+}
+
+int decode_impl(cotr_ctx* h, const float* queries, int B, int Q, float* out, hipStream_t s, const DecPlan& d,
+                bool first_prologue_done) {
   const int L = (int)h->dec.size();
   const int KVLD = L * 2 * D;
   const float* kv = h->memkv.ptr + (size_t)B * TOK * D;
-
-  const int q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
-  const int pairs_per = Q < DEC_ROWS ? (DEC_ROWS / Q) : 1;
-  const int nb_max = B < pairs_per ? B : pairs_per;
-  const size_t Rmax = (size_t)nb_max * q_chunk;
-  {
-    int r = ensure(h, h->dec_scr, Rmax * (7 * D + FFN));
-    if (r) return r;
-  }
-  float* p = h->dec_scr.ptr;
-  float* d_qpos = p; p += Rmax * D;
-  float* d_tgt = p; p += Rmax * D;
-  float* d_q = p; p += Rmax * D;
-  float* d_ao = p; p += Rmax * D;
-  float* d_pre2 = p; p += Rmax * D;
-  float* d_t2 = p; p += Rmax * D;
-  float* d_pre3 = p; p += Rmax * D;
-  float* d_hid = p; p += Rmax * FFN;
-
   prof_mark(h, "dec_begin", s);
-  for (int b0 = 0; b0 < B; b0 += nb_max) {
-    const int nb = (B - b0) < nb_max ? (B - b0) : nb_max;
-    for (int q0 = 0; q0 < Q; q0 += q_chunk) {
-      const int nq = (Q - q0) < q_chunk ? (Q - q0) : q_chunk;
+  for (int b0 = 0; b0 < B; b0 += d.nb_max) {
+    const int nb = (B - b0) < d.nb_max ? (B - b0) : d.nb_max;
+    for (int q0 = 0; q0 < Q; q0 += d.q_chunk) {
+      const int nq = (Q - q0) < d.q_chunk ? (Q - q0) : d.q_chunk;
       const int R = nb * nq;
       const float* qsrc = queries + ((size_t)b0 * Q + q0) * 2;
       float* odst = out + ((size_t)b0 * Q + q0) * 2;
       const float* kv_c = kv + (size_t)b0 * TOK * KVLD;
-      KCHK(h, launch_posenc(qsrc, d_qpos, nb, nq, Q, s), "posenc");
       int r;
-      // transformer.py:185-201 per layer; norm3 of layer l-1 is the prologue of layer l's q projection
-      // (which materialises tgt for the residual), norm2 the prologue of linear1 (materialising t2).
+      if (first_prologue_done && b0 == 0 && q0 == 0) {
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev_q, 0));  // prologue ran on the side stream beside the encode
+      } else if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s))) {
+        return r;
+      }
+      // transformer.py:185-201 per layer; norm3 of layer l-1 feeds layer l's q projection (tgt is kept for the
+      // residual), norm2 feeds linear1 (t2 kept for the residual).
       for (int li = 0; li < L; ++li) {
         const DecW& w = h->dec[li];
-        // q = Wq(tgt + query_pos) * 32^-0.5 ; tgt == 0 at layer 0 (transformer.py:54)
-        if (li == 0) {
-          if ((r = linear(h, d_qpos, nullptr, 0, 1, 0, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d_q, R, D, D, s))) return r;
-        } else {
+        if (li > 0) {
           const DecW& pw = h->dec[li - 1];
-          LnSpec ln; ln.w = pw.n3w; ln.b = pw.n3b; ln.out = d_tgt;
-          if ((r = linear(h, d_pre3, d_qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d_q, R, D, D, s, &ln))) return r;
+          LnSpec ln; ln.w = pw.n3w; ln.b = pw.n3b; ln.out = d.tgt;
+          if ((r = linear(h, d.pre3, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s, &ln))) return r;
+          if (li == 1 && h->kv_pending) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));  // K/V of layers >= 1 (side stream)
         }
-        KCHK(h, launch_attention(d_q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d_ao, D, nb, nq, s),
+        KCHK(h, launch_attention(d.q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d.ao, D, nb, nq, s),
              "attention");
-        if ((r = linear(h, d_ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d_tgt, 0, 1.f, 0, d_pre2, R, D, D, s))) return r;
-        LnSpec ln2; ln2.w = w.n2w; ln2.b = w.n2b; ln2.out = d_t2;
-        if ((r = linear(h, d_pre2, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d_hid, R, FFN, D, s, &ln2))) return r;
-        if ((r = linear(h, d_hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d_t2, 0, 1.f, 0, d_pre3, R, D, FFN, s))) return r;
+        prof_mark(h, "attention dec", s, 2);
+        if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
+        LnSpec ln2; ln2.w = w.n2w; ln2.b = w.n2b; ln2.out = d.t2;
+        if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d.hid, R, FFN, D, s, &ln2))) return r;
+        if ((r = linear(h, d.hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d.t2, 0, 1.f, 0, d.pre3, R, D, FFN, s))) return r;
       }
+      if (L == 1 && h->kv_pending) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));
       // norm3 of the last layer, then decoder.norm, then corr_embed - on the last layer only
       {
         const DecW& lw = h->dec[L - 1];
-        LnSpec ln; ln.w = lw.n3w; ln.b = lw.n3b; ln.w2 = h->dn_w; ln.b2 = h->dn_b; ln.out = d_tgt;
-        if ((r = linear(h, d_pre3, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d_ao, R, D, D, s, &ln))) return r;
+        LnSpec ln; ln.w = lw.n3w; ln.b = lw.n3b; ln.w2 = h->dn_w; ln.b2 = h->dn_b; ln.out = d.tgt;
+        if ((r = linear(h, d.pre3, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s, &ln))) return r;
       }
-      if ((r = linear(h, d_ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d_q, R, D, D, s))) return r;
-      KCHK(h, launch_head2(d_q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
-      if ((r = tap_save(h, "query_pos", d_qpos, (size_t)R * D, s))) return r;
-      if ((r = tap_save(h, "hs", d_tgt, (size_t)R * D, s))) return r;
+      if ((r = linear(h, d.ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d.q, R, D, D, s))) return r;
+      KCHK(h, launch_head2(d.q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
+      prof_mark(h, "head2", s, 2);
+      if ((r = tap_save(h, "query_pos", d.qpos, (size_t)R * D, s))) return r;
+      if ((r = tap_save(h, "hs", d.tgt, (size_t)R * D, s))) return r;
     }
   }
   prof_mark(h, "decoder", s);
   return COTR_OK;
 }
 
+int decode_check(cotr_ctx* h, const float* queries, int B, int Q, float* out) {
+  if (!h->loaded) { h->err = "cotr_decode before cotr_load_weights"; return COTR_ERR_STATE; }
+  if (B <= 0 || Q < 0) { h->err = "cotr_decode: B <= 0 or Q < 0"; return COTR_ERR_ARG; }
+  if (Q > 0 && (!queries || !out)) { h->err = "cotr_decode: null queries/out"; return COTR_ERR_ARG; }
+  return COTR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, cotr_stream stream) {
+  if (!h) return COTR_ERR_ARG;
+  if (int r = decode_check(h, queries, B, Q, out)) return r;
+  if (h->enc_B != B) {
+    h->err = "cotr_decode: no cached encode for this batch size (call cotr_encode first)";
+    return COTR_ERR_STATE;
+  }
+  if (Q == 0) return COTR_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  DecPlan d;
+  if (int r = dec_plan(h, B, Q, d)) return r;
+  return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d, false);
+}
+
 int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, int Q, float* out,
                  cotr_stream stream) {
+  if (!h) return COTR_ERR_ARG;
+  if (int r = decode_check(h, queries, B, Q, out)) return r;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DecPlan d;
+  bool prologue_on_side = false;
+  if (Q > 0) {
+    HIPCHK(h, hipSetDevice(h->device));
+    if (int r = dec_plan(h, B, Q, d)) return r;
+    // the query-side prologue of the first chunk only needs the queries: run it beside the encode
+    if (use_side(h)) {
+      if (int r = fork_side(h, s)) return r;
+      if (int r = dec_prologue(h, d, queries, d.nb_max < B ? d.nb_max : B, d.q_chunk, Q, h->side)) return r;
+      HIPCHK(h, hipEventRecord(h->ev_q, h->side));
+      prologue_on_side = true;
+    }
+  }
   int r = cotr_encode(h, img, B, stream);
   if (r) return r;
-  return cotr_decode(h, queries, B, Q, out, stream);
+  if (Q == 0) return COTR_OK;
+  return decode_impl(h, queries, B, Q, out, s, d, prologue_on_side);
 }
 
 int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
@@ -702,6 +853,7 @@ int cotr_debug_tap(cotr_handle h, const char* name, float* dst, size_t max_elems
   if (!dst) return COTR_OK;
   if (max_elems < it->second.second) { h->err = "tap buffer too small"; return COTR_ERR_ARG; }
   HIPCHK(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
   HIPCHK(h, hipMemcpy(dst, it->second.first, it->second.second * sizeof(float), hipMemcpyDefault));
   return COTR_OK;
 }
@@ -714,7 +866,7 @@ int cotr_set_debug_taps(cotr_handle h, int enable) {
 
 int cotr_set_profiling(cotr_handle h, int enable) {
   if (!h) return COTR_ERR_ARG;
-  h->prof = enable != 0;
+  h->prof = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
   if (!h->prof) prof_reset(h);
   return COTR_OK;
 }
@@ -729,7 +881,7 @@ int cotr_get_profile(cotr_handle h, const char** names, float* ms, int max_entri
     if (h->prof_names[i] == "dec_begin") continue;  // interval between encode and decode calls
     float t = 0.f;
     HIPCHK(h, hipEventElapsedTime(&t, h->prof_ev[i - 1], h->prof_ev[i]));
-    if (names) names[n] = h->prof_names[i].c_str();
+    if (names) names[n] = h->prof_names[i].c_str();  // valid until the next profiled call
     if (ms) ms[n] = t;
     ++n;
   }
@@ -836,6 +988,23 @@ static int bench_launches(int mode, int cfg, const GemmParams& p, int iters, flo
 
 int cotr_gemm_num_configs(void) { return gemm_num_configs(); }
 
+int cotr_set_stream_overlap(cotr_handle h, int enable) {
+  if (!h) return COTR_ERR_ARG;
+  h->overlap = enable != 0;
+  return COTR_OK;
+}
+
+int cotr_set_xcd_mapping(int mode) {
+  if (mode < -1 || mode > 1) return COTR_ERR_ARG;
+  g_xcd_msplit = mode;
+  return COTR_OK;
+}
+
+int cotr_set_ln_fusion_min_rows(int rows) {
+  g_ln_fuse_min_rows = rows < 0 ? 0 : rows;
+  return COTR_OK;
+}
+
 int cotr_set_attention_splits(int ns) {
   if (ns != 0 && ns != 4 && ns != 8 && ns != 16) return COTR_ERR_ARG;
   set_attention_splits(ns);
@@ -847,6 +1016,7 @@ int cotr_bench_linear(const float* x, const float* w, const float* bias, float* 
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K; p.W = w; p.C = y; p.ldc = N; p.bias = bias;
   if (cfg < 0) cfg = gemm_pick_config(GEMM_DENSE, p);
+  p.xcd_msplit = pick_msplit(p, GEMM_DENSE);
   return bench_launches(GEMM_DENSE, cfg, p, iters, us);
 }
 
@@ -861,6 +1031,7 @@ int cotr_bench_conv(const float* x, const float* w, const float* scale, const fl
   p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
   p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout; p.scale = scale; p.bias = bias; p.relu = 1;
   if (cfg < 0) cfg = gemm_pick_config(GEMM_CONV, p);
+  p.xcd_msplit = pick_msplit(p, GEMM_CONV);
   return bench_launches(GEMM_CONV, cfg, p, iters, us);
 }
 

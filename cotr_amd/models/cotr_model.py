@@ -208,12 +208,13 @@ class COTR(nn.Module):
         return lib
 
     def _release(self):
-        if self.__dict__.get('_handle') is not None:
+        handle = self.__dict__.get('_handle')
+        if handle is not None:
+            self.__dict__['_handle'] = None  # (nn.Module.__setattr__ may already be torn down at interpreter exit)
             try:
-                _lib.load_library().cotr_destroy(self._handle)
+                _lib.load_library().cotr_destroy(handle)
             except Exception:
                 pass
-            self._handle = None
 
     def __del__(self):
         self._release()
@@ -302,16 +303,17 @@ class COTR(nn.Module):
         self._ensure_ready(next(self.parameters()).device)
         _lib.check(_lib.load_library().cotr_set_debug_taps(self._handle, int(enable)), self._handle, 'debug taps')
 
-    def set_profiling(self, enable=True):
+    def set_profiling(self, level=1):
+        """0 off, 1 HIP-event timing per stage, 2 per kernel launch (see get_profile)."""
         self._ensure_ready(next(self.parameters()).device)
-        _lib.check(_lib.load_library().cotr_set_profiling(self._handle, int(enable)), self._handle, 'profiling')
+        _lib.check(_lib.load_library().cotr_set_profiling(self._handle, int(level)), self._handle, 'profiling')
 
     def get_profile(self):
         lib = _lib.load_library()
-        names = (ctypes.c_char_p * 64)()
-        ms = (ctypes.c_float * 64)()
+        names = (ctypes.c_char_p * 512)()
+        ms = (ctypes.c_float * 512)()
         n = ctypes.c_int()
-        _lib.check(lib.cotr_get_profile(self._handle, names, ms, 64, ctypes.byref(n)), self._handle, 'profile')
+        _lib.check(lib.cotr_get_profile(self._handle, names, ms, 512, ctypes.byref(n)), self._handle, 'profile')
         return [(names[i].decode(), ms[i]) for i in range(n.value)]
 
 

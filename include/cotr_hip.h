@@ -97,7 +97,8 @@ int cotr_set_debug_taps(cotr_handle h, int enable);
 int cotr_debug_tap(cotr_handle h, const char* name, float* dst, size_t max_elems, size_t* n_elems,
                    cotr_stream stream);
 
-/* Per-stage HIP-event timings (ms) of the last cotr_forward when enabled; see bench.py. */
+/* HIP-event timings (ms) of the last cotr_encode + cotr_decode: enable = 1 per stage, 2 per kernel launch
+ * (names carry the GEMM shape and launch configuration), 0 off. */
 int cotr_set_profiling(cotr_handle h, int enable);
 int cotr_get_profile(cotr_handle h, const char** names, float* ms, int max_entries, int* n_entries);
 
@@ -126,6 +127,15 @@ int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
 
 /* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
 int cotr_gemm_num_configs(void);
+/* run branch-independent kernels (downsample convs, K/V of decoder layers >= 1, query prologue) on the handle's
+ * side stream beside the main chain.  Default OFF: at one pair it measured 1.31 vs 1.16 ms per forward (each
+ * cross-stream event wait costs more than the ~10 us kernel it hides) */
+int cotr_set_stream_overlap(cotr_handle h, int enable);
+/* workgroup -> XCD mapping of the GEMMs: 0 column-split (default), 1 row-split, -1 by operand sizes (measured neutral) */
+int cotr_set_xcd_mapping(int mode);
+/* LayerNorm can run as the prologue of the consuming GEMM when the GEMM has at least this many rows; default:
+ * never (the separate launch measured faster), 0 = always where the launch configuration allows it */
+int cotr_set_ln_fusion_min_rows(int rows);
 /* key splits (wavefronts per workgroup) of the attention kernel: 4, 8, 16, or 0 = automatic */
 int cotr_set_attention_splits(int ns);
 /* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured

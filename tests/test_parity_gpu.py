@@ -156,3 +156,35 @@ def test_state_dict_round_trip_and_reload():
     b = m2(img.cuda(), qs.cuda())['pred_corrs']
     assert cotr_oracle.px_err(b.cpu(), cotr_oracle.cotr_forward(sd2, img, qs)) < PX_BAR
     assert not torch.equal(a, b)
+
+
+def test_layernorm_prologue_fusion_path():
+    """The LayerNorm-as-GEMM-prologue variant (off by default) computes the same function."""
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(2, 300, seed=15)
+    m = hip_model()
+    base = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    lib = _lib.load_library()
+    try:
+        assert lib.cotr_set_ln_fusion_min_rows(0) == 0
+        fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    finally:
+        lib.cotr_set_ln_fusion_min_rows(0x7fffffff)
+    assert cotr_oracle.px_err(fused, base) < SHAPE_NOISE_PX
+    assert cotr_oracle.px_err(fused, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
+
+
+def test_dense_pass_shape_q131072():
+    """cotr_patch_flow_exhaustive feeds q[1,131072,2] (inference_helper.py:116-127): 4 decoder chunks; a strided
+    sample of it is checked against the oracle."""
+    sd = synth_state_dict(0)
+    img, _ = synth_inputs(1, 1, seed=16)
+    ys, xs = torch.meshgrid(torch.arange(256) / 256.0, torch.arange(512) / 512.0, indexing='ij')
+    qs = torch.stack([xs, ys], -1).reshape(1, -1, 2).float()
+    m = hip_model()
+    out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    assert out.shape == (1, 131072, 2) and not torch.isnan(out).any()
+    idx = torch.arange(0, 131072, 997)
+    ref = cotr_oracle.cotr_forward(sd, img, qs[:, idx])
+    assert cotr_oracle.px_err(out[:, idx], ref) < PX_BAR

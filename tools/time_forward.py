@@ -11,9 +11,10 @@ def main():
     m = build_model(cotr_amd.default_args()).cuda().eval()
     m.load_state_dict(synth_state_dict(0))
     lib = _lib.load_library()
-    shapes = [(1, 1000), (32, 1), (8, 1000)]
-    for ns in [0, 4, 8, 16]:
-        lib.cotr_set_attention_splits(ns)
+    shapes = [(1, 1000), (2, 257), (4, 1000), (8, 1000), (32, 1), (32, 1000)]
+    m(*[t.cuda() for t in synth_inputs(1, 4, seed=1)])  # creates the handle
+    for ns in [0, 1]:
+        lib.cotr_set_stream_overlap(m._handle, ns)
         for (b, q) in shapes:
             img, qs = synth_inputs(b, q, seed=1)
             img, qs = img.cuda(), qs.cuda()
@@ -23,6 +24,5 @@ def main():
             t = time.perf_counter()
             for _ in range(n): m(img, qs)
             torch.cuda.synchronize()
-            print(f'ns={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
-    lib.cotr_set_attention_splits(0)
+            print(f'overlap={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
 main()
