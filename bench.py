@@ -59,6 +59,48 @@ def usable_cores():
     return n
 
 
+def kernel_breakdown(model, img, qs, step_ms, reps=5):
+    """Per-kernel-family time of one forward from HIP events recorded after every launch on the launch stream
+    (cotr_set_profiling level 2).  An event costs ~3 us of stream time per launch, so the raw per-launch times are
+    rescaled to sum to the un-instrumented step time measured above."""
+    import collections
+    model.set_profiling(2)
+    fam = collections.OrderedDict()
+    n_launch = 0
+    for _ in range(reps):
+        model(img, qs)
+        torch.cuda.synchronize()
+        prof = model.get_profile()
+        n_launch = len(prof)
+        for name, ms in prof:
+            key = name.split(' ')[0]
+            e = fam.setdefault(key, [0, 0.0])
+            e[0] += 1
+            e[1] += ms
+    model.set_profiling(0)
+    raw_total = sum(v[1] for v in fam.values()) / reps
+    overhead = max(0.0, (raw_total - step_ms) / max(1, n_launch))      # ms per launch added by the event
+    out = {}
+    for k, (cnt, ms) in fam.items():
+        launches = cnt // reps
+        out[k] = {'launches': launches, 'us': round(max(0.0, ms / reps - overhead * launches) * 1e3, 1)}
+    return {'launches_per_forward': n_launch, 'event_overhead_us_per_launch': round(overhead * 1e3, 2), 'families': out}
+
+
+def hbm_traffic_bytes():
+    """HBM<->L2 bytes per forward from the committed rocprofv3 PMC passes (profiles/r1_pmc_hbm_traffic.txt:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes), or None."""
+    path = os.path.join(ROOT, 'profiles', 'r1_pmc_hbm_traffic.txt')
+    try:
+        tot = 0.0
+        for line in open(path):
+            if line.startswith(('FETCH_SIZE', 'WRITE_SIZE')):
+                tot += float(line.split('->')[1].split('MB')[0]) * 1e6
+        return tot or None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def cpu_baseline(budget_s=12.0):
     from cotr_amd.utils.synth import synth_state_dict, synth_inputs
     from oracle import cotr_oracle
@@ -176,6 +218,11 @@ def main():
                          'min_hbm_gbs': min_hbm_bytes(PAIRS_PER_GPU, QUERIES) / (kernel_ms * 1e-3) / 1e9,
                          'hbm_peak_gbs': HBM_PEAK_GBS},
         }
+        line['roofline']['traffic'] = hbm_traffic_bytes()
+        line['roofline']['traffic_note'] = ('bytes per forward crossing L2<->fabric (MALL/HBM), rocprofv3 PMC FETCH_SIZE x2 + '
+                                            'WRITE_SIZE from profiles/r1_pmc_hbm_traffic.txt; minimum is 75.4 MB')
+        if world == 1:
+            line['roofline']['kernels'] = kernel_breakdown(model, img, qs, kernel_ms)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
