@@ -13,7 +13,9 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcotr_hip.so')
-SOURCES = ['gemm.hip', 'attention.hip', 'pointwise.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'pointwise.hip', 'crop_resize.hip', 'api.hip']
+# Pillow-exact integer resample: double-precision coefficient code must not be contracted into FMAs
+EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off']}
 HEADERS = ['common.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
 # code-object v5: loadable by the ROCm 7.0 runtime torch bundles as well as by ROCm 7.2's
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-mcode-object-version=5',
@@ -44,7 +46,7 @@ def build_library(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

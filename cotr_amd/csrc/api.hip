@@ -1059,4 +1059,12 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
   return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
 }
 
+// ---- engine-side input construction --------------------------------------------------
+int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* img_b, int hb, int wb,
+                           const int32_t* boxes, int n, float* out, int max_size, cotr_stream stream) {
+  if (n < 0 || (n > 0 && (!img_a || !img_b || !boxes || !out))) return COTR_ERR_ARG;
+  if (ha <= 0 || wa <= 0 || hb <= 0 || wb <= 0) return COTR_ERR_ARG;
+  return op_ret(launch_crop_resize(img_a, ha, wa, img_b, hb, wb, boxes, n, out, max_size, static_cast<hipStream_t>(stream)));
+}
+
 }  // extern "C"

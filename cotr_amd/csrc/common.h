@@ -76,3 +76,7 @@ int launch_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, hip
 // y[(bi*q_total + qi)*2 + j] = x[bi*nq+qi, :] . w[j, :] + b[j]   (last corr_embed layer, 256 -> 2)
 int launch_head2(const float* x, const float* w, const float* b, float* y, int nb, int nq, int q_total,
                  hipStream_t s);
+
+// batched crop + Pillow-bilinear resize to 256x256 + side-by-side + ImageNet normalise (crop_resize.hip)
+int launch_crop_resize(const uint8_t* img_a, int ha, int wa, const uint8_t* img_b, int hb, int wb,
+                       const int32_t* boxes, int n, float* out, int max_size, hipStream_t s);

@@ -125,6 +125,17 @@ int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, 
 int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
 
 
+/* ---- engine-side input construction (one launch per zoom level) -------------
+ * For each of n tasks: crop the square box (xa, ya, size_a) of image A and (xb, yb, size_b) of image B
+ * (uint8 HWC RGB, DEVICE pointers; boxes int32 [n][6] on the device, inside the images), resize both to
+ * 256x256 with Pillow's 8-bit BILINEAR resample (bit-exact), place them side by side, convert to float/255
+ * and ImageNet-normalise: out float32 [n,3,256,512], directly consumable by cotr_encode.
+ * Replaces per task: PIL resize x2 + two_images_side_by_side + to_tensor + normalize
+ * (COTR/inference/refinement_task.py:105-120) and the H2D copy of sparse_engine.py:50.
+ * max_size: largest crop edge among the boxes (sizes LDS; <= 16384). */
+int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* img_b, int hb, int wb,
+                           const int32_t* boxes, int n, float* out, int max_size, cotr_stream stream);
+
 /* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
 int cotr_gemm_num_configs(void);
 /* run branch-independent kernels (downsample convs, K/V of decoder layers >= 1, query prologue) on the handle's
