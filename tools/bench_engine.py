@@ -1,0 +1,41 @@
+"""End-to-end zoom-in refinement throughput on the MI355X: ZoomEngine (one crop launch + batched model calls per
+level) vs the reference's loop shape (32 tasks per call, PIL crops on the host, H2D per batch) with the same HIP model.
+    python tools/bench_engine.py [n_queries]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import cotr_amd
+from cotr_amd.inference import ZoomEngine
+from cotr_amd.models import build_model
+from cotr_amd.utils.synth import synth_state_dict
+from tests.engine_fixtures import synthetic_pair, pil_cropper_factory
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+img_a, img_b = synthetic_pair(3, (783, 1064), (1053, 689))     # the cathedral demo pair's sizes
+rng = np.random.default_rng(0)
+loc_from = np.stack([rng.uniform(5, img_a.shape[1] - 5, n), rng.uniform(5, img_a.shape[0] - 5, n)], 1)
+loc_to = np.stack([rng.uniform(5, img_b.shape[1] - 5, n), rng.uniform(5, img_b.shape[0] - 5, n)], 1)
+zooms = np.linspace(0.5, 0.0625, 4)
+m = build_model(cotr_amd.default_args()).cuda().eval()
+m.load_state_dict(synth_state_dict(0))
+for max_pairs, tag in ((256, 'ZoomEngine, device crops, 256 crops per model call'),
+                       (1024, 'ZoomEngine, device crops, 1024 crops per model call')):
+    eng = ZoomEngine(m, max_pairs=max_pairs)
+    eng.refine(img_a, img_b, loc_from[:64], loc_to[:64], 1.0, 1.0, zooms, 1, force=True)   # warm-up
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    res = eng.refine(img_a, img_b, loc_from, loc_to, 1.0, 1.0, zooms, 1, force=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    print(f'{tag}: {n} queries x {len(zooms)} levels in {dt:.3f} s = {n / dt:.0f} correspondences/s '
+          f'({res.crops} crops, {res.model_calls} levels)', flush=True)
+# reference loop shape: 32 tasks per call, host PIL crops + H2D (SparseEngine.form_batch / infer_batch)
+n_ref = min(n, 128)
+eng = ZoomEngine(m, max_pairs=32, make_cropper=lambda a, b, d: (lambda boxes, out, f=pil_cropper_factory(a, b, d): f(boxes, out)))
+t = time.perf_counter()
+eng.refine(img_a, img_b, loc_from[:n_ref], loc_to[:n_ref], 1.0, 1.0, zooms, 1, force=True)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t
+print(f'reference loop shape (32 per call, PIL crops on the host, same HIP model): {n_ref} queries in {dt:.3f} s = '
+      f'{n_ref / dt:.0f} correspondences/s', flush=True)
