@@ -177,15 +177,78 @@ class ZoomEngine:
         return RefineResult(loc_from, cur.copy(), good, hist, calls0, self.total_tasks - crops0)
 
     # ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _square_patches(img):
+        """``to_square_patches`` (inference_helper.py:41-58) as boxes: [(x, y, size)], one or two per image."""
+        h, w = img.shape[:2]
+        size = min(h, w)
+        if max(h, w) == size:
+            return [(0, 0, size)]
+        if max(h, w) <= size * 2:
+            return [(0, 0, size), (w - size, h - size, size)]
+        raise NotImplementedError('aspect ratio above 2 (the reference raises here as well)')
+
+    def corr_base(self, img_a, img_b, queries_a):
+        """``cotr_corr_base`` (inference_helper.py:185-232): for every pair of square patches of the two images one
+        forward for the queries and one for the answers (cycle check), the patch pair with the smallest cycle error
+        wins per query.  -> [N,4] (x_a, y_a, x_b, y_b).  The two forwards share ONE encode (``model.encode`` +
+        two ``model.decode``) when the model offers the split, and all patch pairs are cropped in one launch."""
+        img_a = np.ascontiguousarray(img_a)
+        img_b = np.ascontiguousarray(img_b)
+        queries_a = np.asarray(queries_a, dtype=np.float64)
+        pa, pb = self._square_patches(img_a), self._square_patches(img_b)
+        pairs = [(i, j) for i in pa for j in pb]
+        boxes = np.array([[i[0], i[1], i[2], j[0], j[1], j[2]] for i, j in pairs], dtype=np.int32)
+        device = next(self.model.parameters()).device
+        cropper = self.make_cropper(img_a, img_b, device)
+        buf = torch.empty((len(pairs), 3, 256, 512), dtype=torch.float32, device=device)
+        img = cropper(boxes, buf)
+        qn = np.empty((len(pairs),) + queries_a.shape, dtype=np.float32)
+        masks = []
+        for k, (i, _) in enumerate(pairs):
+            q = queries_a.copy()
+            masks.append((q[:, 0] >= i[0]) & (q[:, 1] >= i[1]) & (q[:, 0] <= i[0] + i[2]) & (q[:, 1] <= i[1] + i[2]))
+            q[:, 0] = (q[:, 0] - i[0]) / (2 * i[2])
+            q[:, 1] = (q[:, 1] - i[1]) / i[2]
+            qn[k] = q.astype(np.float32)
+        qt = torch.from_numpy(qn).to(device)
+        if hasattr(self.model, 'encode') and hasattr(self.model, 'decode'):
+            self.model.encode(img)                      # backbone + encoder + K/V once, reused by both passes
+            out = self.model.decode(qt)
+            cyc = self.model.decode(out)
+        else:
+            out = self.model(img, qt)['pred_corrs']
+            cyc = self.model(img, out)['pred_corrs']
+        self.total_tasks += len(pairs)
+        out, cyc = out.detach().cpu().numpy(), cyc.detach().cpu().numpy()
+        preds = []
+        for k, (_, j) in enumerate(pairs):
+            conf = np.linalg.norm(qn[k] - cyc[k], axis=1, keepdims=True)
+            pred = np.concatenate([out[k], conf], axis=1)          # float32, like the reference's one_pass
+            pred[~masks[k], 2] = np.inf
+            pred[:, 0] -= 0.5
+            pred[:, 0] *= 2 * j[2]
+            pred[:, 0] += j[0]
+            pred[:, 1] *= j[2]
+            pred[:, 1] += j[1]
+            preds.append(pred)
+        preds = np.stack(preds).transpose(1, 0, 2)                  # [N, pairs, 3]
+        best = np.array([item[np.argmin(item[..., 2], axis=0)] for item in preds])[..., :2]
+        return np.concatenate([queries_a, best], axis=1)
+
+    # ------------------------------------------------------------------------------------------------
     def cotr_corr_multiscale(self, img_a, img_b, zoom_ins=(1.0,), converge_iters=1, max_corrs=1000, queries_a=None,
                              return_idx=False, force=False, areas=None, init_b=None):
         """``SparseEngine.cotr_corr_multiscale`` for tasks with known scale: ``queries_a`` [N,2] pixel positions in
         img_a, ``areas`` = (area_a, area_b) as the reference requires for this path (:108-114), initial estimates
-        ``init_b`` [N,2] in img_b (the reference takes them from ``cotr_corr_base``).  Returns [M,4]
+        ``init_b`` [N,2] in img_b (default: ``corr_base``, as the reference does).  Returns [M,4]
         (x_a, y_a, x_b, y_b), at most max_corrs rows, in task order."""
-        if queries_a is None or areas is None or init_b is None:
-            raise NotImplementedError('ZoomEngine batches the refinement of tasks with known scale and initial '
-                                      'estimates; the dense initial pass (cotr_flow) is not part of it yet')
+        if queries_a is None or areas is None:
+            raise NotImplementedError('ZoomEngine batches the refinement of tasks with known scale (queries_a + areas, '
+                                      'sparse_engine.py:100-114); the dense initial pass (cotr_flow) is not part of it yet')
+        if init_b is None:                                         # gen_tasks_w_known_scale :100-106
+            base = self.corr_base(img_a, img_b, queries_a)
+            queries_a, init_b = base[:, :2], base[:, 2:]
         res = self.refine(img_a, img_b, queries_a, init_b, areas[0], areas[1], zoom_ins, converge_iters, force)
         corrs = np.concatenate([res.loc_from, res.loc_to], axis=1)
         idx = np.arange(corrs.shape[0])

@@ -52,3 +52,14 @@ def test_patch_boxes_is_get_patch_centered_at():
             if lx + s > w:
                 lx -= (lx + s) - w
             assert (x[i], y[i], size) == (lx, ly, s)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_corr_base_matches_reference(name, golden_dir):
+    """cotr_corr_base (inference_helper.py:185-232) incl. the two-patch tiling of non-square images and the cycle
+    selection; golden 'init' is the reference's own output with the same fake model."""
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    img_a, img_b = synthetic_pair(int(g['meta'][0]))
+    eng = ZoomEngine(FakeModel(), make_cropper=pil_cropper_factory)
+    assert np.array_equal(eng.corr_base(img_a, img_b, g['queries']), g['init'])

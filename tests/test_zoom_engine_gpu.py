@@ -56,3 +56,25 @@ def test_one_zoom_level_with_the_real_model_matches_oracle():
     # 1e-3 px in the 256x512 network frame = 1e-3 * size/256 px in the image
     assert np.abs(got.loc_to - ref.loc_to).max() < 1e-3 * size_b / 256 * 2
     assert got.crops == n and got.model_calls == 1          # one launch for the whole level
+
+
+def test_corr_base_reuses_one_encode_for_the_cycle_pass():
+    """model.encode + 2x model.decode (K/V cached in the handle) == two full forwards (inference_helper.py:197-198)."""
+    sd = synth_state_dict(0)
+    img_a, img_b = synthetic_pair(6)                    # non-square: 2 x 2 patch pairs
+    rng = np.random.default_rng(2)
+    q = np.stack([rng.uniform(5, img_a.shape[1] - 5, 30), rng.uniform(5, img_a.shape[0] - 5, 30)], 1)
+    hip = build_model(cotr_amd.default_args()).cuda().eval()
+    hip.load_state_dict(sd)
+
+    class NoSplit(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, img, qs):
+            return self.m(img, qs)
+
+    split = ZoomEngine(hip).corr_base(img_a, img_b, q)
+    full = ZoomEngine(NoSplit(hip)).corr_base(img_a, img_b, q)
+    assert split.shape == (30, 4) and np.array_equal(split, full)
