@@ -46,6 +46,7 @@ _PROTOS = {
     'cotr_op_posenc': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_crop_resize_pairs': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
                                               c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_set_encode_chunk': (ctypes.c_int, [ctypes.c_int]),
     'cotr_gemm_num_configs': (ctypes.c_int, []),
     'cotr_set_stream_overlap': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),

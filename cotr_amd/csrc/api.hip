@@ -31,7 +31,8 @@ void set_attention_splits(int ns);
 namespace {
 
 constexpr int D = 256, FFN = 1024, TOK = 512, CFEAT = 1024;
-constexpr int ENC_CHUNK = 32;     // pairs per backbone/encoder pass (scratch ~50 MB per pair)
+constexpr int ENC_CHUNK_MAX = 32;  // scratch is sized for this many pairs per backbone/encoder pass (~50 MB per pair)
+int g_enc_chunk = 32;             // pairs per pass actually used (tuning knob, <= ENC_CHUNK_MAX)
 constexpr int DEC_ROWS = 32768;   // query rows per decoder pass (scratch ~9 KB per row)
 constexpr float QSCALE = 0.17677669529663687f;  // 32^-0.5, float(head_dim) ** -0.5 in torch
 
@@ -536,6 +537,7 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   float* memory = h->memkv.ptr;
   float* kv = h->memkv.ptr + (size_t)B * TOK * D;
 
+  const int ENC_CHUNK = g_enc_chunk;
   const int Bc_max = B < ENC_CHUNK ? B : ENC_CHUNK;
   // scratch carve (floats per pair)
   const size_t n_stem = (size_t)128 * 256 * 64, n_pool = (size_t)64 * 128 * 64, n_act = (size_t)64 * 128 * 256;
@@ -832,7 +834,7 @@ int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, i
 int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   if (!h || !bytes || B <= 0 || Q < 0) return COTR_ERR_ARG;
   const size_t L = h->dec.empty() ? 6 : h->dec.size();
-  const size_t Bc = B < ENC_CHUNK ? B : ENC_CHUNK;
+  const size_t Bc = B < g_enc_chunk ? B : g_enc_chunk;
   const size_t per_pair = (size_t)128 * 256 * 64 + (size_t)64 * 128 * 64 + 5 * (size_t)64 * 128 * 256 +
                           6 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
   const size_t q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
@@ -991,6 +993,12 @@ int cotr_gemm_num_configs(void) { return gemm_num_configs(); }
 int cotr_set_stream_overlap(cotr_handle h, int enable) {
   if (!h) return COTR_ERR_ARG;
   h->overlap = enable != 0;
+  return COTR_OK;
+}
+
+int cotr_set_encode_chunk(int pairs) {
+  if (pairs < 1 || pairs > ENC_CHUNK_MAX) return COTR_ERR_ARG;
+  g_enc_chunk = pairs;
   return COTR_OK;
 }
 

@@ -722,11 +722,24 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
 
 int gemm_pick_config(int mode, const GemmParams& p) {
   if (mode == GEMM_STEM) return 1;
-  for (const TunedEntry* e = kTuned; e->mode >= 0; ++e)
-    if (e->mode == mode && e->M == p.M && e->N == p.N && e->K == p.K) {
+  // 1. measured table, exact shape; 2. same (N, K) at the nearest measured row count (log distance): the best
+  // configuration changes slowly with M; 3. cost model
+  const TunedEntry* near = nullptr;
+  double near_d = 0;
+  for (const TunedEntry* e = kTuned; e->mode >= 0; ++e) {
+    if (e->mode != mode || e->N != p.N || e->K != p.K) continue;
+    if (e->M == p.M) {
       if (cfg_fits(e->cfg, p)) return e->cfg;
       if (cfg_fits(e->cfg_reg, p)) return e->cfg_reg;
     }
+    if (!cfg_fits(e->cfg, p) && !cfg_fits(e->cfg_reg, p)) continue;
+    const double d = fabs(log((double)e->M / (double)p.M));
+    if (near == nullptr || d < near_d) {
+      near = e;
+      near_d = d;
+    }
+  }
+  if (near != nullptr && near_d < 1.0) return cfg_fits(near->cfg, p) ? near->cfg : near->cfg_reg;
   int best = -1;
   double best_cost = 0;
   for (int i = 0; i < kNumCfgs; ++i) {

@@ -138,6 +138,9 @@ int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* 
 
 /* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
 int cotr_gemm_num_configs(void);
+/* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB
+ * Infinity Cache, larger ones fill the CUs better */
+int cotr_set_encode_chunk(int pairs);
 /* run branch-independent kernels (downsample convs, K/V of decoder layers >= 1, query prologue) on the handle's
  * side stream beside the main chain.  Default OFF: at one pair it measured 1.31 vs 1.16 ms per forward (each
  * cross-stream event wait costs more than the ~10 us kernel it hides) */

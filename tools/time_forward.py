@@ -12,9 +12,9 @@ def main():
     m.load_state_dict(synth_state_dict(0))
     lib = _lib.load_library()
     shapes = [(1, 1000), (2, 257), (4, 1000), (8, 1000), (32, 1), (32, 1000)]
-    m(*[t.cuda() for t in synth_inputs(1, 4, seed=1)])  # creates the handle
-    for ns in [0, 1]:
-        lib.cotr_set_stream_overlap(m._handle, ns)
+    shapes = [(1, 1000), (2, 257), (3, 500), (4, 1000), (5, 100), (8, 1000), (13, 1), (16, 1), (32, 1), (32, 1000)]
+    for ns in [32]:
+        lib.cotr_set_encode_chunk(ns)
         for (b, q) in shapes:
             img, qs = synth_inputs(b, q, seed=1)
             img, qs = img.cuda(), qs.cuda()
@@ -24,5 +24,5 @@ def main():
             t = time.perf_counter()
             for _ in range(n): m(img, qs)
             torch.cuda.synchronize()
-            print(f'overlap={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
+            print(f'enc_chunk={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
 main()
