@@ -32,7 +32,8 @@ namespace {
 
 constexpr int D = 256, FFN = 1024, TOK = 512, CFEAT = 1024;
 constexpr int ENC_CHUNK_MAX = 32;  // scratch is sized for this many pairs per backbone/encoder pass (~50 MB per pair)
-int g_enc_chunk = 32;             // pairs per pass actually used (tuning knob, <= ENC_CHUNK_MAX)
+int g_enc_chunk = 32;
+int g_dec_split = 0;             // split a decoder chunk with >= this many rows into two concurrent chains (0 = off)             // pairs per pass actually used (tuning knob, <= ENC_CHUNK_MAX)
 constexpr int DEC_ROWS = 32768;   // query rows per decoder pass (scratch ~9 KB per row)
 constexpr float QSCALE = 0.17677669529663687f;  // 32^-0.5, float(head_dim) ** -0.5 in torch
 
@@ -726,6 +727,48 @@ int dec_prologue(cotr_ctx* h, const DecPlan& d, const float* qsrc, int nb, int n
   return linear(h, d.qpos, nullptr, 0, 1, 0, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, nb * nq, D, D, s);
 }
 
+// one chunk of query rows through the decoder: rows [row0, row0 + nb*nq) of the scratch buffers
+int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc, float* odst, const float* kv_c, int nb, int nq,
+                 int Q, hipStream_t s, bool prologue_done) {
+  DecPlan d = d0;
+  d.qpos += row0 * D; d.tgt += row0 * D; d.q += row0 * D; d.ao += row0 * D; d.pre2 += row0 * D; d.t2 += row0 * D;
+  d.pre3 += row0 * D; d.hid += row0 * FFN;
+  const int L = (int)h->dec.size();
+  const int KVLD = L * 2 * D;
+  const int R = nb * nq;
+  int r;
+  if (!prologue_done && (r = dec_prologue(h, d, qsrc, nb, nq, Q, s))) return r;
+  // transformer.py:185-201 per layer; norm3 of layer l-1 feeds layer l's q projection (tgt is kept for the
+  // residual), norm2 feeds linear1 (t2 kept for the residual).
+  for (int li = 0; li < L; ++li) {
+    const DecW& w = h->dec[li];
+    if (li > 0) {
+      const DecW& pw = h->dec[li - 1];
+      LnSpec ln; ln.w = pw.n3w; ln.b = pw.n3b; ln.out = d.tgt;
+      if ((r = linear(h, d.pre3, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s, &ln))) return r;
+      if (li == 1 && h->kv_pending) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));  // K/V of layers >= 1 (side stream)
+    }
+    KCHK(h, launch_attention(d.q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d.ao, D, nb, nq, s),
+         "attention");
+    prof_mark(h, "attention dec", s, 2);
+    if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
+    LnSpec ln2; ln2.w = w.n2w; ln2.b = w.n2b; ln2.out = d.t2;
+    if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d.hid, R, FFN, D, s, &ln2))) return r;
+    if ((r = linear(h, d.hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d.t2, 0, 1.f, 0, d.pre3, R, D, FFN, s))) return r;
+  }
+  if (L == 1 && h->kv_pending) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));
+  // norm3 of the last layer, then decoder.norm, then corr_embed - on the last layer only
+  {
+    const DecW& lw = h->dec[L - 1];
+    LnSpec ln; ln.w = lw.n3w; ln.b = lw.n3b; ln.w2 = h->dn_w; ln.b2 = h->dn_b; ln.out = d.tgt;
+    if ((r = linear(h, d.pre3, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s, &ln))) return r;
+  }
+  if ((r = linear(h, d.ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d.q, R, D, D, s))) return r;
+  KCHK(h, launch_head2(d.q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
+  prof_mark(h, "head2", s, 2);
+  return COTR_OK;
+}
+
 int decode_impl(cotr_ctx* h, const float* queries, int B, int Q, float* out, hipStream_t s, const DecPlan& d,
                 bool first_prologue_done) {
   const int L = (int)h->dec.size();
@@ -741,39 +784,29 @@ int decode_impl(cotr_ctx* h, const float* queries, int B, int Q, float* out, hip
       float* odst = out + ((size_t)b0 * Q + q0) * 2;
       const float* kv_c = kv + (size_t)b0 * TOK * KVLD;
       int r;
-      if (first_prologue_done && b0 == 0 && q0 == 0) {
-        HIPCHK(h, hipStreamWaitEvent(s, h->ev_q, 0));  // prologue ran on the side stream beside the encode
-      } else if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s))) {
-        return r;
-      }
-      // transformer.py:185-201 per layer; norm3 of layer l-1 feeds layer l's q projection (tgt is kept for the
-      // residual), norm2 feeds linear1 (t2 kept for the residual).
-      for (int li = 0; li < L; ++li) {
-        const DecW& w = h->dec[li];
-        if (li > 0) {
-          const DecW& pw = h->dec[li - 1];
-          LnSpec ln; ln.w = pw.n3w; ln.b = pw.n3b; ln.out = d.tgt;
-          if ((r = linear(h, d.pre3, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s, &ln))) return r;
-          if (li == 1 && h->kv_pending) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));  // K/V of layers >= 1 (side stream)
+      const bool pro_done = first_prologue_done && b0 == 0 && q0 == 0;
+      if (pro_done) HIPCHK(h, hipStreamWaitEvent(s, h->ev_q, 0));  // prologue ran on the side stream beside the encode
+      // two independent chains (queries never interact): the second half of the rows runs on the side stream.
+      // At ~1000 rows every decoder kernel is latency-bound with the chip half idle, so the chains overlap.
+      const bool split = g_dec_split && h->side != nullptr && h->prof < 2 && !h->keep_taps && R >= g_dec_split &&
+                         (nb == 1 || nb % 2 == 0);
+      if (split) {
+        const int nb1 = nb == 1 ? 1 : nb / 2, nq1 = nb == 1 ? (nq / 2 + 31) / 32 * 32 : nq;
+        const int nb2 = nb == 1 ? 1 : nb - nb1, nq2 = nb == 1 ? nq - nq1 : nq;
+        const size_t rows1 = (size_t)nb1 * nq1;
+        const float* qsrc2 = nb == 1 ? qsrc + (size_t)nq1 * 2 : qsrc + (size_t)nb1 * Q * 2;
+        float* odst2 = nb == 1 ? odst + (size_t)nq1 * 2 : odst + (size_t)nb1 * Q * 2;
+        const float* kv_c2 = nb == 1 ? kv_c : kv_c + (size_t)nb1 * TOK * KVLD;
+        if (pro_done && nb == 1) {
+          // the prologue covered all rows of the chunk in one launch: nothing to redo per half
         }
-        KCHK(h, launch_attention(d.q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d.ao, D, nb, nq, s),
-             "attention");
-        prof_mark(h, "attention dec", s, 2);
-        if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
-        LnSpec ln2; ln2.w = w.n2w; ln2.b = w.n2b; ln2.out = d.t2;
-        if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d.hid, R, FFN, D, s, &ln2))) return r;
-        if ((r = linear(h, d.hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d.t2, 0, 1.f, 0, d.pre3, R, D, FFN, s))) return r;
+        if ((r = fork_side(h, s))) return r;
+        if ((r = decode_chunk(h, d, rows1, qsrc2, odst2, kv_c2, nb2, nq2, Q, h->side, pro_done))) return r;
+        if ((r = decode_chunk(h, d, 0, qsrc, odst, kv_c, nb1, nq1, Q, s, pro_done))) return r;
+        if ((r = join_side(h, s))) return r;
+      } else {
+        if ((r = decode_chunk(h, d, 0, qsrc, odst, kv_c, nb, nq, Q, s, pro_done))) return r;
       }
-      if (L == 1 && h->kv_pending) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));
-      // norm3 of the last layer, then decoder.norm, then corr_embed - on the last layer only
-      {
-        const DecW& lw = h->dec[L - 1];
-        LnSpec ln; ln.w = lw.n3w; ln.b = lw.n3b; ln.w2 = h->dn_w; ln.b2 = h->dn_b; ln.out = d.tgt;
-        if ((r = linear(h, d.pre3, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s, &ln))) return r;
-      }
-      if ((r = linear(h, d.ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d.q, R, D, D, s))) return r;
-      KCHK(h, launch_head2(d.q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
-      prof_mark(h, "head2", s, 2);
       if ((r = tap_save(h, "query_pos", d.qpos, (size_t)R * D, s))) return r;
       if ((r = tap_save(h, "hs", d.tgt, (size_t)R * D, s))) return r;
     }
@@ -993,6 +1026,11 @@ int cotr_gemm_num_configs(void) { return gemm_num_configs(); }
 int cotr_set_stream_overlap(cotr_handle h, int enable) {
   if (!h) return COTR_ERR_ARG;
   h->overlap = enable != 0;
+  return COTR_OK;
+}
+
+int cotr_set_decoder_split_rows(int rows) {
+  g_dec_split = rows < 0 ? 0 : rows;
   return COTR_OK;
 }
 

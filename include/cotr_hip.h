@@ -138,6 +138,9 @@ int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* 
 
 /* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
 int cotr_gemm_num_configs(void);
+/* run the two halves of a decoder chunk with >= rows query rows as two concurrent chains (main + side stream);
+ * 0 = off */
+int cotr_set_decoder_split_rows(int rows);
 /* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB
  * Infinity Cache, larger ones fill the CUs better */
 int cotr_set_encode_chunk(int pairs);
