@@ -47,10 +47,7 @@ _PROTOS = {
     'cotr_crop_resize_pairs': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
                                               c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_set_encode_chunk': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_decoder_split_rows': (ctypes.c_int, [ctypes.c_int]),
     'cotr_gemm_num_configs': (ctypes.c_int, []),
-    'cotr_set_stream_overlap': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
-    'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_ln_fusion_min_rows': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_splits': (ctypes.c_int, [ctypes.c_int]),
     'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,

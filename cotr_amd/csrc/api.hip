@@ -32,8 +32,7 @@ namespace {
 
 constexpr int D = 256, FFN = 1024, TOK = 512, CFEAT = 1024;
 constexpr int ENC_CHUNK_MAX = 32;  // scratch is sized for this many pairs per backbone/encoder pass (~50 MB per pair)
-int g_enc_chunk = 32;
-int g_dec_split = 0;             // split a decoder chunk with >= this many rows into two concurrent chains (0 = off)             // pairs per pass actually used (tuning knob, <= ENC_CHUNK_MAX)
+int g_enc_chunk = 32;             // pairs per pass actually used (tuning knob, <= ENC_CHUNK_MAX)
 constexpr int DEC_ROWS = 32768;   // query rows per decoder pass (scratch ~9 KB per row)
 constexpr float QSCALE = 0.17677669529663687f;  // 32^-0.5, float(head_dim) ** -0.5 in torch
 
@@ -63,19 +62,6 @@ thread_local std::string g_create_error;
 // measured slower than the separate launch at every batch size tried (B=1: 1.162 vs 1.142 ms, B=8: 4.40 vs 4.11 ms;
 // tools/time_forward.py).  cotr_set_ln_fusion_min_rows(n) turns it on for GEMMs with >= n rows.
 int g_ln_fuse_min_rows = 0x7fffffff;
-// XCD mapping of GEMM workgroups: -1 automatic (by operand sizes), 0 column-split, 1 row-split (tuning hook)
-int g_xcd_msplit = 0;
-
-int pick_msplit(const GemmParams& p, int mode) {
-  if (g_xcd_msplit >= 0) return g_xcd_msplit;
-  // bytes each XCD must pull privately: column-split replicates the activations, row-split the weights
-  double a_bytes = (double)p.M * p.K * 4.0;
-  if (mode == GEMM_CONV) a_bytes /= (double)(p.ksize * p.ksize);  // im2col taps re-read the same pixels
-  if (mode == GEMM_STEM) return 0;
-  const double w_bytes = (double)p.N * p.K * 4.0;
-  return a_bytes > w_bytes ? 1 : 0;
-}
-
 }  // namespace
 
 struct cotr_ctx {
@@ -104,13 +90,6 @@ struct cotr_ctx {
   std::map<std::string, std::pair<const float*, size_t>> taps;
   bool keep_taps = false;
   std::map<std::string, Arena> tap_store;
-  // side stream for work that does not depend on the main chain (downsample convs, K/V of decoder layers >= 1,
-  // the query-side prologue of layer 0); joined back with events.  At one pair every kernel leaves most CUs
-  // idle and is latency-bound, so concurrent independent kernels are nearly free.
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_kv = nullptr, ev_q = nullptr;
-  bool kv_pending = false;  // ev_kv recorded and not yet waited for by a decode
-  bool overlap = false;  // measured slower in eager mode: cross-stream event waits cost more than they hide
   // profiling
   int prof = 0;  // 0 off, 1 per stage, 2 per kernel launch
   std::vector<std::string> prof_names;
@@ -173,22 +152,6 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
   return COTR_OK;
 }
 
-bool use_side(const cotr_ctx* h) { return h->overlap && h->side != nullptr && h->prof < 2; }
-
-// side stream continues from the current point of `main`
-int fork_side(cotr_ctx* h, hipStream_t main) {
-  HIPCHK(h, hipEventRecord(h->ev_fork, main));
-  HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  return COTR_OK;
-}
-
-// `main` continues only after everything enqueued on the side stream so far
-int join_side(cotr_ctx* h, hipStream_t main) {
-  HIPCHK(h, hipEventRecord(h->ev_join, h->side));
-  HIPCHK(h, hipStreamWaitEvent(main, h->ev_join, 0));
-  return COTR_OK;
-}
-
 GemmParams base_params() {
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -220,8 +183,7 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
   p.colscale = colscale; p.colscale_n = colscale_n;
   if (ln != nullptr && ln->w != nullptr) {
     int cfg = gemm_pick_config(GEMM_DENSE, p);
-    p.xcd_msplit = pick_msplit(p, GEMM_DENSE);
-  const bool want_fused = K == D && M >= g_ln_fuse_min_rows;
+    const bool want_fused = K == D && M >= g_ln_fuse_min_rows;
     if (want_fused && !gemm_cfg_supports_ln(cfg) && M <= 4096) cfg = 3;  // the 8-wavefront K-split, 32x32 tile
     if (want_fused && gemm_cfg_supports_ln(cfg)) {
       p.ln_w = ln->w; p.ln_b = ln->b; p.ln2_w = ln->w2; p.ln2_b = ln->b2; p.ln_out = ln->out;
@@ -235,7 +197,6 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
     if (h->prof >= 2) prof_mark(h, "layernorm", s, 2);
     p.A = ln->out;
   }
-  p.xcd_msplit = pick_msplit(p, GEMM_DENSE);
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, gemm_pick_config(GEMM_DENSE, p)); prof_mark(h, nm, s, 2); }
   return COTR_OK;
@@ -253,7 +214,6 @@ int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int
   p.A = x; p.lda = c.cin;
   p.W = c.w; p.C = y; p.ldc = c.cout;
   p.scale = c.scale; p.bias = c.bias; p.residual = residual; p.ldr = c.cout; p.relu = relu;
-  p.xcd_msplit = pick_msplit(p, GEMM_CONV);
   KCHK(h, launch_gemm(GEMM_CONV, p, s), "conv");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "conv%dx%d/%d %dx%dx%d cfg%d", c.k, c.k, c.stride, p.M, p.N, p.K, gemm_pick_config(GEMM_CONV, p)); prof_mark(h, nm, s, 2); }
   return COTR_OK;
@@ -308,15 +268,6 @@ int cotr_create(cotr_handle* out, int device) {
     delete h;
     return COTR_ERR_HIP;
   }
-  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_kv, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_q, hipEventDisableTiming) != hipSuccess) {
-    g_create_error = "creating the side stream / events failed";
-    delete h;
-    return COTR_ERR_HIP;
-  }
   *out = h;
   return COTR_OK;
 }
@@ -326,9 +277,6 @@ void cotr_destroy(cotr_handle h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   prof_reset(h);
-  if (h->side) (void)hipStreamDestroy(h->side);
-  for (hipEvent_t e : {h->ev_fork, h->ev_join, h->ev_kv, h->ev_q})
-    if (e) (void)hipEventDestroy(e);
   if (h->wbuf) (void)hipFree(h->wbuf);
   if (h->pos) (void)hipFree(h->pos);
   if (h->memkv.ptr) (void)hipFree(h->memkv.ptr);
@@ -566,10 +514,6 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   float* t_hid = p; p += (size_t)TOK * FFN * Bc_max;
 
   if (h->prof) prof_reset(h);
-  if (h->kv_pending) {  // an earlier encode's side-stream K/V may still be reading/writing the cache
-    HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));
-    h->kv_pending = false;
-  }
   prof_mark(h, "begin", s);
   for (int b0 = 0; b0 < B; b0 += ENC_CHUNK) {
     const int Bc = (B - b0) < ENC_CHUNK ? (B - b0) : ENC_CHUNK;
@@ -596,21 +540,13 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
         flip ^= 1;
         int r;
         const float* idt = x;
-        const bool side_ds = (b == 0) && use_side(h);
-        if (b == 0) {  // downsample branch (1x1, strided) only needs x: runs beside conv1 -> conv2
-          const ConvW& cd = h->convs[ci + 0];
-          if (side_ds) {
-            if ((r = fork_side(h, s))) return r;
-            if ((r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, h->side))) return r;
-          } else {
-            if ((r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
-          }
-          ++ci;
+        if (b == 0) {  // downsample branch (1x1, strided)
+          const ConvW& cd = h->convs[ci++];
+          if ((r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
           idt = b_d;
         }
         if ((r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
         if ((r = conv(h, c2, b_t1, nullptr, 1, b_t2, Bc, H, W, s))) return r;
-        if (side_ds && (r = join_side(h, s))) return r;
         if ((r = conv(h, c3, b_t2, idt, 1, y, Bc, Ho, Wo, s))) return r;
         x = y;
         H = Ho; W = Wo;
@@ -653,31 +589,14 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
     }
     prof_mark(h, "encoder", s);
     // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195);
-    //      memory = norm2 of the last encoder layer.  Layer 0's K/V stay on the main stream (the decode needs
-    //      them first); layers >= 1 go to the side stream and overlap decoder layer 0 (joined by ev_kv).
+    //      memory = norm2 of the last encoder layer
     float* kv_c = kv + (size_t)b0 * TOK * KVLD;
     {
       const EncW& pe = h->enc.back();
-      KCHK(h, launch_layernorm(pre2, pe.n2w, pe.n2b, mem_c, M, s), "layernorm");
-      prof_mark(h, "layernorm", s, 2);
-      const int L = (int)h->dec.size();
-      if (use_side(h) && L > 1) {
-        if ((r = fork_side(h, s))) return r;
-        if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w + (size_t)2 * D * D, h->kv_b + 2 * D, nullptr, 0, 1.f, 0,
-                        kv_c + 2 * D, M, (L - 1) * 2 * D, D, h->side, nullptr, (int)KVLD))) return r;
-        HIPCHK(h, hipEventRecord(h->ev_kv, h->side));
-        h->kv_pending = true;
-        if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, 2 * D, D, s, nullptr,
-                        (int)KVLD))) return r;
-      } else {
-        if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
-      }
+      LnSpec ln; ln.w = pe.n2w; ln.b = pe.n2b; ln.out = mem_c;
+      if ((r = linear(h, pre2, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s, &ln))) return r;
     }
     prof_mark(h, "dec_kv", s);
-    if (h->kv_pending && b0 + ENC_CHUNK < B) {  // more chunks follow: finish this chunk's side K/V first
-      HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));
-      h->kv_pending = false;
-    }
   }
   h->taps["memory"] = {memory, (size_t)B * TOK * D};
   h->taps["kv"] = {kv, (size_t)B * TOK * KVLD};
@@ -729,7 +648,7 @@ int dec_prologue(cotr_ctx* h, const DecPlan& d, const float* qsrc, int nb, int n
 
 // one chunk of query rows through the decoder: rows [row0, row0 + nb*nq) of the scratch buffers
 int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc, float* odst, const float* kv_c, int nb, int nq,
-                 int Q, hipStream_t s, bool prologue_done) {
+                 int Q, hipStream_t s) {
   DecPlan d = d0;
   d.qpos += row0 * D; d.tgt += row0 * D; d.q += row0 * D; d.ao += row0 * D; d.pre2 += row0 * D; d.t2 += row0 * D;
   d.pre3 += row0 * D; d.hid += row0 * FFN;
@@ -737,7 +656,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   const int KVLD = L * 2 * D;
   const int R = nb * nq;
   int r;
-  if (!prologue_done && (r = dec_prologue(h, d, qsrc, nb, nq, Q, s))) return r;
+  if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s))) return r;
   // transformer.py:185-201 per layer; norm3 of layer l-1 feeds layer l's q projection (tgt is kept for the
   // residual), norm2 feeds linear1 (t2 kept for the residual).
   for (int li = 0; li < L; ++li) {
@@ -746,7 +665,6 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       const DecW& pw = h->dec[li - 1];
       LnSpec ln; ln.w = pw.n3w; ln.b = pw.n3b; ln.out = d.tgt;
       if ((r = linear(h, d.pre3, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s, &ln))) return r;
-      if (li == 1 && h->kv_pending) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));  // K/V of layers >= 1 (side stream)
     }
     KCHK(h, launch_attention(d.q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d.ao, D, nb, nq, s),
          "attention");
@@ -756,7 +674,6 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
     if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d.hid, R, FFN, D, s, &ln2))) return r;
     if ((r = linear(h, d.hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d.t2, 0, 1.f, 0, d.pre3, R, D, FFN, s))) return r;
   }
-  if (L == 1 && h->kv_pending) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));
   // norm3 of the last layer, then decoder.norm, then corr_embed - on the last layer only
   {
     const DecW& lw = h->dec[L - 1];
@@ -769,8 +686,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   return COTR_OK;
 }
 
-int decode_impl(cotr_ctx* h, const float* queries, int B, int Q, float* out, hipStream_t s, const DecPlan& d,
-                bool first_prologue_done) {
+int decode_impl(cotr_ctx* h, const float* queries, int B, int Q, float* out, hipStream_t s, const DecPlan& d) {
   const int L = (int)h->dec.size();
   const int KVLD = L * 2 * D;
   const float* kv = h->memkv.ptr + (size_t)B * TOK * D;
@@ -784,29 +700,7 @@ int decode_impl(cotr_ctx* h, const float* queries, int B, int Q, float* out, hip
       float* odst = out + ((size_t)b0 * Q + q0) * 2;
       const float* kv_c = kv + (size_t)b0 * TOK * KVLD;
       int r;
-      const bool pro_done = first_prologue_done && b0 == 0 && q0 == 0;
-      if (pro_done) HIPCHK(h, hipStreamWaitEvent(s, h->ev_q, 0));  // prologue ran on the side stream beside the encode
-      // two independent chains (queries never interact): the second half of the rows runs on the side stream.
-      // At ~1000 rows every decoder kernel is latency-bound with the chip half idle, so the chains overlap.
-      const bool split = g_dec_split && h->side != nullptr && h->prof < 2 && !h->keep_taps && R >= g_dec_split &&
-                         (nb == 1 || nb % 2 == 0);
-      if (split) {
-        const int nb1 = nb == 1 ? 1 : nb / 2, nq1 = nb == 1 ? (nq / 2 + 31) / 32 * 32 : nq;
-        const int nb2 = nb == 1 ? 1 : nb - nb1, nq2 = nb == 1 ? nq - nq1 : nq;
-        const size_t rows1 = (size_t)nb1 * nq1;
-        const float* qsrc2 = nb == 1 ? qsrc + (size_t)nq1 * 2 : qsrc + (size_t)nb1 * Q * 2;
-        float* odst2 = nb == 1 ? odst + (size_t)nq1 * 2 : odst + (size_t)nb1 * Q * 2;
-        const float* kv_c2 = nb == 1 ? kv_c : kv_c + (size_t)nb1 * TOK * KVLD;
-        if (pro_done && nb == 1) {
-          // the prologue covered all rows of the chunk in one launch: nothing to redo per half
-        }
-        if ((r = fork_side(h, s))) return r;
-        if ((r = decode_chunk(h, d, rows1, qsrc2, odst2, kv_c2, nb2, nq2, Q, h->side, pro_done))) return r;
-        if ((r = decode_chunk(h, d, 0, qsrc, odst, kv_c, nb1, nq1, Q, s, pro_done))) return r;
-        if ((r = join_side(h, s))) return r;
-      } else {
-        if ((r = decode_chunk(h, d, 0, qsrc, odst, kv_c, nb, nq, Q, s, pro_done))) return r;
-      }
+      if ((r = decode_chunk(h, d, 0, qsrc, odst, kv_c, nb, nq, Q, s))) return r;
       if ((r = tap_save(h, "query_pos", d.qpos, (size_t)R * D, s))) return r;
       if ((r = tap_save(h, "hs", d.tgt, (size_t)R * D, s))) return r;
     }
@@ -837,31 +731,20 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
   HIPCHK(h, hipSetDevice(h->device));
   DecPlan d;
   if (int r = dec_plan(h, B, Q, d)) return r;
-  return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d, false);
+  return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
 }
 
 int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, int Q, float* out,
                  cotr_stream stream) {
   if (!h) return COTR_ERR_ARG;
   if (int r = decode_check(h, queries, B, Q, out)) return r;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  DecPlan d;
-  bool prologue_on_side = false;
-  if (Q > 0) {
-    HIPCHK(h, hipSetDevice(h->device));
-    if (int r = dec_plan(h, B, Q, d)) return r;
-    // the query-side prologue of the first chunk only needs the queries: run it beside the encode
-    if (use_side(h)) {
-      if (int r = fork_side(h, s)) return r;
-      if (int r = dec_prologue(h, d, queries, d.nb_max < B ? d.nb_max : B, d.q_chunk, Q, h->side)) return r;
-      HIPCHK(h, hipEventRecord(h->ev_q, h->side));
-      prologue_on_side = true;
-    }
-  }
   int r = cotr_encode(h, img, B, stream);
   if (r) return r;
   if (Q == 0) return COTR_OK;
-  return decode_impl(h, queries, B, Q, out, s, d, prologue_on_side);
+  HIPCHK(h, hipSetDevice(h->device));
+  DecPlan d;
+  if ((r = dec_plan(h, B, Q, d))) return r;
+  return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
 }
 
 int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
@@ -888,7 +771,6 @@ int cotr_debug_tap(cotr_handle h, const char* name, float* dst, size_t max_elems
   if (!dst) return COTR_OK;
   if (max_elems < it->second.second) { h->err = "tap buffer too small"; return COTR_ERR_ARG; }
   HIPCHK(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-  if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
   HIPCHK(h, hipMemcpy(dst, it->second.first, it->second.second * sizeof(float), hipMemcpyDefault));
   return COTR_OK;
 }
@@ -1023,26 +905,9 @@ static int bench_launches(int mode, int cfg, const GemmParams& p, int iters, flo
 
 int cotr_gemm_num_configs(void) { return gemm_num_configs(); }
 
-int cotr_set_stream_overlap(cotr_handle h, int enable) {
-  if (!h) return COTR_ERR_ARG;
-  h->overlap = enable != 0;
-  return COTR_OK;
-}
-
-int cotr_set_decoder_split_rows(int rows) {
-  g_dec_split = rows < 0 ? 0 : rows;
-  return COTR_OK;
-}
-
 int cotr_set_encode_chunk(int pairs) {
   if (pairs < 1 || pairs > ENC_CHUNK_MAX) return COTR_ERR_ARG;
   g_enc_chunk = pairs;
-  return COTR_OK;
-}
-
-int cotr_set_xcd_mapping(int mode) {
-  if (mode < -1 || mode > 1) return COTR_ERR_ARG;
-  g_xcd_msplit = mode;
   return COTR_OK;
 }
 
@@ -1062,7 +927,6 @@ int cotr_bench_linear(const float* x, const float* w, const float* bias, float* 
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K; p.W = w; p.C = y; p.ldc = N; p.bias = bias;
   if (cfg < 0) cfg = gemm_pick_config(GEMM_DENSE, p);
-  p.xcd_msplit = pick_msplit(p, GEMM_DENSE);
   return bench_launches(GEMM_DENSE, cfg, p, iters, us);
 }
 
@@ -1077,7 +941,6 @@ int cotr_bench_conv(const float* x, const float* w, const float* scale, const fl
   p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
   p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout; p.scale = scale; p.bias = bias; p.relu = 1;
   if (cfg < 0) cfg = gemm_pick_config(GEMM_CONV, p);
-  p.xcd_msplit = pick_msplit(p, GEMM_CONV);
   return bench_launches(GEMM_CONV, cfg, p, iters, us);
 }
 

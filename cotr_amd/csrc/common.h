@@ -48,7 +48,6 @@ struct GemmParams {
   //   A'' = LN2(LN1(A)) (+ A2 as above, added AFTER the norm); ln2 optional (decoder.norm after norm3).
   // ln_out (optional, [M][256]): the normalised rows (before the A2 add) are written by the workgroups
   // of the first 256 output columns, so the residual path of the next GEMM can read them.
-  int xcd_msplit;      // 1: workgroups of one XCD (blockIdx % 8) share row tiles' complement: see tile_coords()
   const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
   const float* ln_w;
   const float* ln_b;

@@ -23,29 +23,6 @@
 #define LDSLD 36
 
 
-// blockIdx -> (row tile, column tile).  Consecutive workgroups land on consecutive XCDs (8 of them, each with
-// its own 4 MB L2), so the mapping decides which operand every XCD's L2 has to hold a private copy of:
-//   default   column tile = bid % tiles_n: with tiles_n a multiple of 8 an XCD owns 1/8 of the column tiles
-//             and walks ALL row tiles -> W is fetched once chip-wide, the activations once per XCD
-//             (right for the convolutions at one pair: weights >> activations)
-//   M-split   an XCD owns every 8th ROW tile and walks all column tiles -> activations fetched once chip-wide,
-//             W once per XCD (right when the activation operand is the larger one: FFN2, batched shapes)
-__device__ __forceinline__ bool tile_coords(const GemmParams& p, int bm, int bn, int& m0, int& n0) {
-  const int tiles_n = p.N / bn;
-  if (p.xcd_msplit) {
-    const int tiles_m = (p.M + bm - 1) / bm;
-    const int bid = blockIdx.x;
-    const int mt = (bid / (8 * tiles_n)) * 8 + (bid & 7);
-    if (mt >= tiles_m) return false;
-    m0 = mt * bm;
-    n0 = ((bid >> 3) % tiles_n) * bn;
-  } else {
-    m0 = (blockIdx.x / tiles_n) * bm;
-    n0 = (blockIdx.x % tiles_n) * bn;
-  }
-  return true;
-}
-
 template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -55,8 +32,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   float* Ws = smem + BM * LDSLD;
 
   const int t = threadIdx.x;
-  int m0, n0;
-  if (!tile_coords(p, BM, BN, m0, n0)) return;
+  // column tile fastest: consecutive workgroups (= consecutive XCDs) share a row tile; with tiles_n a multiple of
+  // 8 an XCD owns 1/8 of the column tiles, so W is fetched once chip-wide (a row-split alternative measured neutral)
+  const int tiles_n = p.N / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM;
+  const int n0 = (blockIdx.x % tiles_n) * BN;
   const int lr = t >> 3, lc = (t & 7) * 4;
   const int KT = p.K / BK;
 
@@ -121,6 +101,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   float rs[16];
 
   auto load_tile = [&](int kt) {
+#if defined(COTR_ABL) && COTR_ABL == 1  // ablation: only the first global load
+    if (kt > 0) return;
+#endif
     if constexpr (MODE == GEMM_DENSE) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
@@ -195,6 +178,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     store_tile();
     __syncthreads();
     if (kt + 1 < KT) load_tile(kt + 1);
+#if defined(COTR_ABL) && COTR_ABL == 2  // ablation: no LDS reads / MFMAs
+    if (p.M > 0) continue;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f32x4 af[TM], bf[TN];
@@ -264,8 +250,9 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int t = threadIdx.x;
-  int m0, n0;
-  if (!tile_coords(p, BM, BN, m0, n0)) return;
+  const int tiles_n = p.N / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM;
+  const int n0 = (blockIdx.x % tiles_n) * BN;
   const int lr = t / C4, lc4 = t % C4;
   const int ktl = lc4 >> 3;            // which 32-wide k-tile of the step this thread loads
   const int lcc = (lc4 & 7) * 4;       // column inside that k-tile
@@ -604,7 +591,7 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tiles = (p.xcd_msplit ? (tiles_m + 7) / 8 * 8 : tiles_m) * (p.N / BN);
+  const int tiles = tiles_m * (p.N / BN);
   hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, MODE>), dim3(tiles), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -629,7 +616,7 @@ static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
     attr_set = true;
   }
   const int tiles_m = (p.M + BM - 1) / BM;
-  const int tiles = (p.xcd_msplit ? (tiles_m + 7) / 8 * 8 : tiles_m) * (p.N / BN);
+  const int tiles = tiles_m * (p.N / BN);
   hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB, LN>), dim3(tiles), dim3(NWK * 64), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

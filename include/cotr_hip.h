@@ -138,18 +138,9 @@ int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* 
 
 /* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
 int cotr_gemm_num_configs(void);
-/* run the two halves of a decoder chunk with >= rows query rows as two concurrent chains (main + side stream);
- * 0 = off */
-int cotr_set_decoder_split_rows(int rows);
 /* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB
  * Infinity Cache, larger ones fill the CUs better */
 int cotr_set_encode_chunk(int pairs);
-/* run branch-independent kernels (downsample convs, K/V of decoder layers >= 1, query prologue) on the handle's
- * side stream beside the main chain.  Default OFF: at one pair it measured 1.31 vs 1.16 ms per forward (each
- * cross-stream event wait costs more than the ~10 us kernel it hides) */
-int cotr_set_stream_overlap(cotr_handle h, int enable);
-/* workgroup -> XCD mapping of the GEMMs: 0 column-split (default), 1 row-split, -1 by operand sizes (measured neutral) */
-int cotr_set_xcd_mapping(int mode);
 /* LayerNorm can run as the prologue of the consuming GEMM when the GEMM has at least this many rows; default:
  * never (the separate launch measured faster), 0 = always where the launch configuration allows it */
 int cotr_set_ln_fusion_min_rows(int rows);

@@ -3,6 +3,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
+#include <stdlib.h>
 template <typename F> float run(F launch, int n) {
   hipStream_t s; (void)hipStreamCreate(&s);
   hipGraph_t g; hipGraphExec_t e;
@@ -22,6 +24,19 @@ int main() {
   float *x, *w, *y; (void)hipMalloc(&x, (size_t)Mmax * Kmax * 4); (void)hipMalloc(&w, (size_t)N * Kmax * 4); (void)hipMalloc(&y, (size_t)Mmax * N * 4);
   std::vector<float> h((size_t)Mmax * Kmax); for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
   (void)hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(w, h.data(), (size_t)N * Kmax * 4, hipMemcpyHostToDevice);
+  const char* big = getenv("ABL_BIG");
+  if (big) {
+    const int M = 16384;
+    float *xb, *yb; (void)hipMalloc(&xb, (size_t)M * Kmax * 4); (void)hipMalloc(&yb, (size_t)M * N * 4);
+    for (size_t off = 0; off < (size_t)M * Kmax; off += h.size()) (void)hipMemcpy(xb + off, h.data(), (std::min(h.size(), (size_t)M * Kmax - off)) * 4, hipMemcpyHostToDevice);
+    for (int K : {256, 1024, 2304}) for (int cfg : {0, 1, 2}) {
+      GemmParams p; memset(&p, 0, sizeof(p)); p.colscale = 1.f; p.a2_period = 1;
+      p.M = M; p.N = N; p.K = K; p.A = xb; p.lda = K; p.W = w; p.C = yb; p.ldc = N;
+      float us = run([&](hipStream_t s, int) { launch_gemm_cfg(GEMM_DENSE, cfg, p, s); }, 20);
+      printf("ABL=%d M=%5d K=%4d cfg=%2d: %.2f us  (%.1f TFLOP/s)\n", COTR_ABL, M, K, cfg, us, 2.0 * M * N * K / us * 1e-6);
+    }
+    return 0;
+  }
   for (int M : {32, 512}) for (int K : {256, 1024, 2304}) for (int cfg : {3, 13, 4, 14, 8}) {
     GemmParams p; memset(&p, 0, sizeof(p)); p.colscale = 1.f; p.a2_period = 1;
     p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K; p.W = w; p.C = y; p.ldc = N;

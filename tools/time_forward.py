@@ -14,8 +14,8 @@ def main():
     shapes = [(1, 1000), (2, 257), (4, 1000), (8, 1000), (32, 1), (32, 1000)]
     shapes = [(1, 1000), (2, 257), (3, 500), (4, 1000), (5, 100), (8, 1000), (13, 1), (16, 1), (32, 1), (32, 1000)]
     shapes = [(1, 1000), (1, 4000), (2, 257), (4, 1000), (32, 1000)]
-    for ns in [0, 256]:
-        lib.cotr_set_decoder_split_rows(ns)
+    for ns in [32]:
+        lib.cotr_set_encode_chunk(ns)
         for (b, q) in shapes:
             img, qs = synth_inputs(b, q, seed=1)
             img, qs = img.cuda(), qs.cuda()
@@ -25,5 +25,5 @@ def main():
             t = time.perf_counter()
             for _ in range(n): m(img, qs)
             torch.cuda.synchronize()
-            print(f'dec_split={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
+            print(f'enc_chunk={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
 main()
