@@ -239,12 +239,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 template <int NWK, int TM, int TN, int MODE, int DB, int LN>
 __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
   constexpr int NT = NWK * 64;
-  constexpr int BM = TM * 32, BN = TN * 32;
+  // TN == 0 selects the 32 x 16 tile built from v_mfma_f32_16x16x4_f32 (two 16-row blocks x one 16-column block):
+  // twice the workgroups of the 32 x 32 tile for the M <= 512, N = 256 shapes that otherwise fill half the CUs
+  constexpr bool N16 = (TN == 0);
+  static_assert(!N16 || TM == 1, "the 16-column tile is 32 rows tall");
+  constexpr int BM = TM * 32, BN = N16 ? 16 : TN * 32;
   constexpr int KS = NWK * BK;        // K elements per step
   constexpr int LD = KS + 4;          // padded LDS row
   constexpr int C4 = NWK * 8;         // float4 per row per step
   constexpr int PA = BM / 8, PW = BN / 8;  // passes: 8 rows per pass (NT / C4 == 8)
-  constexpr int NB = TM * TN;
+  constexpr int NB = N16 ? 1 : TM * TN;
   static_assert(NT / C4 == 8, "8 rows per pass");
   constexpr int TILE = (BM + BN) * LD;  // floats per LDS stage (A rows then W rows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -346,11 +350,13 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 
   const int lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  f32x16 acc[TM][TN];
+  const int l15 = lane & 15, q4 = lane >> 4;
+  f32x16 acc[TM][N16 ? 1 : TN];
+  f32x4 acc16[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int b = 0; b < (N16 ? 1 : TN); ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -360,9 +366,26 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 #if defined(COTR_ABL) && COTR_ABL == 2  // ablation: no LDS reads / MFMAs
     if (p.M > 0) return;
 #endif
+    if constexpr (N16) {
+      // 16x16x4: lane (row l&15, k group l>>4) reads 4 consecutive k; element e of the float4 feeds the e-th MFMA
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int ko = wave * BK + jj * 16 + q4 * 4;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[l15 * LD + ko]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[(16 + l15) * LD + ko]);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(&Ws[l15 * LD + ko]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], bb[e], acc16[0], 0, 0, 0);
+          acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], bb[e], acc16[1], 0, 0, 0);
+        }
+      }
+      return;
+    }
+    constexpr int TNN = N16 ? 1 : TN;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      f32x4 af[TM], bf[TN];
+      f32x4 af[TM], bf[TNN];
 #pragma unroll
       for (int a = 0; a < TM; ++a)
         af[a] = *reinterpret_cast<const f32x4*>(&As[(a * 32 + l31) * LD + wave * BK + j * 8 + hh * 4]);
@@ -517,6 +540,32 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 
   // ---- cross-wave reduction through LDS: red[wave][block][r][lane] ----------------------------
   float* red = smem;
+  if constexpr (N16) {
+    // D of 16x16x4: column = lane&15, row = (lane>>4)*4 + reg; 2 blocks x 4 regs = 8 slots per lane
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave * 8) + blk * 4 + r) * 64 + lane] = acc16[blk][r];
+    __syncthreads();
+    const int n = n0 + l15;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+    const float cs = (n < p.colscale_n) ? p.colscale : 1.f;
+    for (int slot = wave; slot < 8; slot += NWK) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWK; ++w) v += red[(w * 8 + slot) * 64 + lane];
+      const int m = m0 + (slot >> 2) * 16 + q4 * 4 + (slot & 3);
+      if (m < p.M) {
+        v = p.scale ? fmaf(v, sc, bi) : v + bi;
+        v *= cs;
+        if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
+        if (p.relu) v = (v < 0.f) ? 0.f : v;
+        p.C[(size_t)m * p.ldc + n] = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -582,6 +631,10 @@ static const GemmCfg kCfgs[] = {
     {3, 8, 1, 1},   // 19 k-split 8 waves, 32x32, LDS-DMA (global_load_lds) double-buffered
     {3, 8, 1, 2},   // 20 k-split 8 waves, 32x64, LDS-DMA
     {3, 8, 2, 1},   // 21 k-split 8 waves, 64x32, LDS-DMA
+    {1, 8, 1, 0},   // 22 k-split 8 waves, 32x16 (16x16x4 MFMA)
+    {2, 8, 1, 0},   // 23 k-split 8 waves, 32x16, double-buffered
+    {3, 8, 1, 0},   // 24 k-split 8 waves, 32x16, LDS-DMA double-buffered
+    {1, 4, 1, 0},   // 25 k-split 4 waves, 32x16
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -598,14 +651,15 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
 
 template <int NWK, int TM, int TN, int DB>
 static constexpr size_t ks_smem() {
-  size_t tile = (size_t)(DB ? 2 : 1) * (TM + TN) * 32 * (NWK * BK + 4) * sizeof(float);
-  size_t red = (size_t)NWK * TM * TN * 16 * 64 * sizeof(float);
+  size_t rows = (size_t)TM * 32 + (TN == 0 ? 16 : TN * 32);
+  size_t tile = (size_t)(DB ? 2 : 1) * rows * (NWK * BK + 4) * sizeof(float);
+  size_t red = (size_t)NWK * (TN == 0 ? 8 : TM * TN * 16) * 64 * sizeof(float);
   return tile > red ? tile : red;
 }
 
 template <int NWK, int TM, int TN, int MODE, int DB, int LN>
 static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
-  constexpr int BM = TM * 32, BN = TN * 32;
+  constexpr int BM = TM * 32, BN = TN == 0 ? 16 : TN * 32;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
   constexpr size_t smem = ks_smem<NWK, TM, TN, (DB && !LN)>();  // the LN variant is single-step: one stage
@@ -623,7 +677,7 @@ static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
 
 template <int NWK, int TM, int TN, int MODE, int DB = 0>
 static int launch_ks(const GemmParams& p, hipStream_t s) {
-  if constexpr (MODE == GEMM_DENSE && NWK == 8) {  // the LayerNorm-prologue instantiation (separate: +40 VGPRs)
+  if constexpr (MODE == GEMM_DENSE && NWK == 8 && TN >= 1) {  // the LayerNorm-prologue instantiation (separate: +40 VGPRs)
     if (p.ln_w != nullptr) return p.K == 256 ? launch_ks_impl<NWK, TM, TN, MODE, DB, 1>(p, s) : -1;
   }
   if (p.ln_w != nullptr) return -1;
@@ -663,6 +717,10 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 19: return launch_ks<8, 1, 1, MODE, 2>(p, s);
     case 20: return launch_ks<8, 1, 2, MODE, 2>(p, s);
     case 21: return launch_ks<8, 2, 1, MODE, 2>(p, s);
+    case 22: return launch_ks<8, 1, 0, MODE, 0>(p, s);
+    case 23: return launch_ks<8, 1, 0, MODE, 1>(p, s);
+    case 24: return launch_ks<8, 1, 0, MODE, 2>(p, s);
+    case 25: return launch_ks<4, 1, 0, MODE, 0>(p, s);
     default: return -1;
   }
 }
@@ -678,10 +736,11 @@ static const TunedEntry kTuned[] = {
 
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  const int bn = (c.kind == 0 ? 2 : 1) * c.tn * 32;
+  const int bn = c.tn == 0 ? 16 : (c.kind == 0 ? 2 : 1) * c.tn * 32;
   if (c.kind != 0) {  // dynamic LDS of the k-split kernels must fit the CU's 160 KB
-    const size_t tile = (size_t)(c.kind >= 2 ? 2 : 1) * (c.tm + c.tn) * 32 * (c.a * BK + 4) * sizeof(float);
-    const size_t red = (size_t)c.a * c.tm * c.tn * 16 * 64 * sizeof(float);
+    const size_t rows = (size_t)c.tm * 32 + (c.tn == 0 ? 16 : c.tn * 32);
+    const size_t tile = (size_t)(c.kind >= 2 ? 2 : 1) * rows * (c.a * BK + 4) * sizeof(float);
+    const size_t red = (size_t)c.a * (c.tn == 0 ? 8 : c.tm * c.tn * 16) * 64 * sizeof(float);
     if ((tile > red ? tile : red) > 163840) return false;
     if (c.kind == 3 && (p.A2 != nullptr || p.ln_w != nullptr)) return false;  // LDS-DMA has no register prologue
   }
@@ -691,11 +750,11 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
 // rough cost model (cycles) for shapes outside the tuned table
 static double model_cost(const GemmCfg& c, const GemmParams& p) {
   const int waves = c.kind == 0 ? 4 : c.a;
-  const int bm = (c.kind == 0 ? 2 : 1) * c.tm * 32, bn = (c.kind == 0 ? 2 : 1) * c.tn * 32;
+  const int bm = (c.kind == 0 ? 2 : 1) * c.tm * 32, bn = c.tn == 0 ? 16 : (c.kind == 0 ? 2 : 1) * c.tn * 32;
   const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
   const int kt = p.K / BK;
   const int steps = c.kind == 0 ? kt : (kt + c.a - 1) / c.a;
-  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)(c.kind >= 2 ? 2 : 1) * (c.tm + c.tn) * 32 * (c.a * 32 + 4) * 4.0;
+  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)(c.kind >= 2 ? 2 : 1) * (bm + bn) * (c.a * 32 + 4) * 4.0;
   double per_cu = floor(163840.0 / lds);
   if (per_cu > 32.0 / waves) per_cu = 32.0 / waves;
   if (per_cu > 4) per_cu = 4;
@@ -703,7 +762,7 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
   const double rounds = ceil(wgs / (256.0 * per_cu));
   const double resident = wgs < 256.0 * per_cu ? ceil(wgs / 256.0) : per_cu;
   const double share = (waves * resident) / 4.0 > 1.0 ? (waves * resident) / 4.0 : 1.0;
-  const double step = c.tm * c.tn * 16 * 64.0 * share + (c.kind >= 2 ? 300.0 : 700.0);
+  const double step = c.tm * (c.tn == 0 ? 0.5 : (double)c.tn) * 16 * 64.0 * share + (c.kind >= 2 ? 300.0 : 700.0);
   return rounds * (steps * step + 2500.0 + (c.kind != 0 ? 600.0 : 0.0));
 }
 
@@ -741,7 +800,7 @@ int gemm_pick_config(int mode, const GemmParams& p) {
 }
 
 int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s) {
-  if (p.N % 32 != 0 || cfg < 0 || cfg >= kNumCfgs || !cfg_fits(cfg, p)) return -1;
+  if (p.N % 16 != 0 || cfg < 0 || cfg >= kNumCfgs || !cfg_fits(cfg, p)) return -1;
   switch (mode) {
     case GEMM_DENSE:
       if (p.lda % 4 != 0 || (p.A2 && p.lda2 % 4 != 0)) return -1;
@@ -768,7 +827,7 @@ const float* gemm_zero_buffer() {
 
 // The LayerNorm prologue needs a configuration whose K step is the whole row: k-split with 8 wavefronts.
 bool gemm_cfg_supports_ln(int cfg) {
-  return cfg >= 0 && cfg < kNumCfgs && (kCfgs[cfg].kind == 1 || kCfgs[cfg].kind == 2) && kCfgs[cfg].a == 8;
+  return cfg >= 0 && cfg < kNumCfgs && (kCfgs[cfg].kind == 1 || kCfgs[cfg].kind == 2) && kCfgs[cfg].a == 8 && kCfgs[cfg].tn >= 1;
 }
 
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s) {

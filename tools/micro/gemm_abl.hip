@@ -37,6 +37,18 @@ int main() {
     }
     return 0;
   }
+  const char* occ = getenv("ABL_OCC");
+  if (occ) {  // does a second co-resident workgroup per CU overlap ingest with MFMA?  (256 vs 512 vs 1024 workgroups)
+    float *xb, *yb; (void)hipMalloc(&xb, (size_t)4096 * Kmax * 4); (void)hipMalloc(&yb, (size_t)4096 * N * 4);
+    for (size_t off = 0; off < (size_t)4096 * Kmax; off += h.size()) (void)hipMemcpy(xb + off, h.data(), (std::min(h.size(), (size_t)4096 * Kmax - off)) * 4, hipMemcpyHostToDevice);
+    for (int K : {1024, 2304}) for (int cfg : {3, 4}) for (int M : {512, 1024, 2048, 4096}) {
+      GemmParams p; memset(&p, 0, sizeof(p)); p.colscale = 1.f; p.a2_period = 1;
+      p.M = M; p.N = N; p.K = K; p.A = xb; p.lda = K; p.W = w; p.C = yb; p.ldc = N;
+      float us = run([&](hipStream_t s, int) { launch_gemm_cfg(GEMM_DENSE, cfg, p, s); }, 30);
+      printf("OCC cfg=%d K=%4d M=%4d (%4d WGs): %.2f us\n", cfg, K, M, (M / 32) * (N / 32), us);
+    }
+    return 0;
+  }
   for (int M : {32, 512}) for (int K : {256, 1024, 2304}) for (int cfg : {3, 13, 4, 14, 8}) {
     GemmParams p; memset(&p, 0, sizeof(p)); p.colscale = 1.f; p.a2_period = 1;
     p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K; p.W = w; p.C = y; p.ldc = N;
