@@ -13,7 +13,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcotr_hip.so')
-SOURCES = ['gemm.hip', 'attention.hip', 'pointwise.hip', 'crop_resize.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'attention.hip', 'pointwise.hip', 'crop_resize.hip', 'ffn.hip', 'api.hip']
 # Pillow-exact integer resample: double-precision coefficient code must not be contracted into FMAs
 EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off']}
 HEADERS = ['common.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]

@@ -57,11 +57,7 @@ struct Arena {
 };
 
 thread_local std::string g_create_error;
-// LayerNorm as the prologue of the consuming GEMM (instead of its own 2 us launch) is implemented and tested but
-// OFF by default: every column tile of a row block redoes the row statistics (48 cross-lane shuffles), which
-// measured slower than the separate launch at every batch size tried (B=1: 1.162 vs 1.142 ms, B=8: 4.40 vs 4.11 ms;
-// tools/time_forward.py).  cotr_set_ln_fusion_min_rows(n) turns it on for GEMMs with >= n rows.
-int g_ln_fuse_min_rows = 0x7fffffff;
+int g_ffn_fuse_max_rows = 1024;  // fused FFN block up to this many rows (forward at B=1,Q=1000: 1.064 vs 1.083 ms; slower from ~1300 rows on)
 }  // namespace
 
 struct cotr_ctx {
@@ -160,20 +156,10 @@ GemmParams base_params() {
   return p;
 }
 
-// LayerNorm(s) applied to the rows of x before the contraction (nn.LayerNorm(256), eps 1e-5):
-// w/b = first norm, w2/b2 = optional second norm (decoder.norm after norm3), out = where the normalised
-// rows are materialised (the next residual add reads them).
-struct LnSpec {
-  const float *w = nullptr, *b = nullptr, *w2 = nullptr, *b2 = nullptr;
-  float* out = nullptr;
-};
-
-// y[M,N] = epi( (LN(x) (+x2)) . w^T ).  With an LnSpec the norm runs as the GEMM's prologue when the launch
-// configuration keeps whole rows in LDS (K == 256, 8-wavefront K-split: the one-pair regime); otherwise as
-// separate layernorm launches into ln.out followed by the plain GEMM (batched regime).
+// y[M,N] = epi( (x (+x2)) . w^T )
 int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_period, int a2_width,
            const float* w, const float* bias, const float* residual, int relu, float colscale, int colscale_n,
-           float* y, int M, int N, int K, hipStream_t s, const LnSpec* ln = nullptr, int ldc = 0) {
+           float* y, int M, int N, int K, hipStream_t s, int ldc = 0) {
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K;
   p.A = x; p.lda = K;
@@ -181,25 +167,35 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
   p.W = w; p.C = y; p.ldc = ldc ? ldc : N;
   p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
   p.colscale = colscale; p.colscale_n = colscale_n;
-  if (ln != nullptr && ln->w != nullptr) {
-    int cfg = gemm_pick_config(GEMM_DENSE, p);
-    const bool want_fused = K == D && M >= g_ln_fuse_min_rows;
-    if (want_fused && !gemm_cfg_supports_ln(cfg) && M <= 4096) cfg = 3;  // the 8-wavefront K-split, 32x32 tile
-    if (want_fused && gemm_cfg_supports_ln(cfg)) {
-      p.ln_w = ln->w; p.ln_b = ln->b; p.ln2_w = ln->w2; p.ln2_b = ln->b2; p.ln_out = ln->out;
-      KCHK(h, launch_gemm_cfg(GEMM_DENSE, cfg, p, s), "linear+layernorm");
-      if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "ln+linear %dx%dx%d cfg%d", M, N, K, cfg); prof_mark(h, nm, s, 2); }
-      return COTR_OK;
-    }
-    if (ln->out == nullptr) { h->err = "linear: LayerNorm fallback needs an output buffer"; return COTR_ERR_ARG; }
-    KCHK(h, launch_layernorm(x, ln->w, ln->b, ln->out, M, s), "layernorm");
-    if (ln->w2) KCHK(h, launch_layernorm(ln->out, ln->w2, ln->b2, ln->out, M, s), "layernorm");
-    if (h->prof >= 2) prof_mark(h, "layernorm", s, 2);
-    p.A = ln->out;
-  }
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, gemm_pick_config(GEMM_DENSE, p)); prof_mark(h, nm, s, 2); }
   return COTR_OK;
+}
+
+int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float* y, int M, hipStream_t s) {
+  KCHK(h, launch_layernorm(x, w, b, y, M, s), "layernorm");
+  prof_mark(h, "layernorm", s, 2);
+  return COTR_OK;
+}
+
+// y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
+// Up to g_ffn_fuse_max_rows rows: ONE fused launch that keeps the hidden activations on the CU and writes per-chunk
+// partial outputs + ln_reduce (sum, bias, residual, norm); above: linear1, linear2 (+residual), layernorm.
+// `hid` holds max(M*1024, chunks*M*256) floats, `tmp` M*256.
+int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, const float* l2w, const float* l2b,
+              const float* nw, const float* nb, float* hid, float* tmp, float* y, int M, hipStream_t s) {
+  if (M <= g_ffn_fuse_max_rows) {
+    const int nch = ffn_fused_chunks(M);
+    KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
+    if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
+    KCHK(h, launch_ln_reduce(hid, nch, l2b, x, nw, nb, y, M, s), "ln_reduce");
+    prof_mark(h, "ln_reduce", s, 2);
+    return COTR_OK;
+  }
+  int r;
+  if ((r = linear(h, x, nullptr, 0, 1, 0, l1w, l1b, nullptr, 1, 1.f, 0, hid, M, FFN, D, s))) return r;
+  if ((r = linear(h, hid, nullptr, 0, 1, 0, l2w, l2b, x, 0, 1.f, 0, tmp, M, D, FFN, s))) return r;
+  return layernorm(h, tmp, nw, nb, y, M, s);
 }
 
 int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int relu, float* y, int B,
@@ -491,7 +487,7 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   // scratch carve (floats per pair)
   const size_t n_stem = (size_t)128 * 256 * 64, n_pool = (size_t)64 * 128 * 64, n_act = (size_t)64 * 128 * 256;
   const size_t n_tok = (size_t)TOK * D;
-  const size_t per_pair = n_stem + n_pool + 5 * n_act + 6 * n_tok + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
+  const size_t per_pair = n_stem + n_pool + 5 * n_act + 6 * n_tok + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
   {
     int r = ensure(h, h->enc_scr, per_pair * Bc_max);
     if (r) return r;
@@ -511,7 +507,7 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   float* t_pre2 = p; p += n_tok * Bc_max;
   float* t_ao = p; p += n_tok * Bc_max;
   float* t_qkv = p; p += (size_t)TOK * 3 * D * Bc_max;
-  float* t_hid = p; p += (size_t)TOK * FFN * Bc_max;
+  float* t_hid = p; p += (size_t)TOK * 4 * FFN * Bc_max;  // hidden activations, or up to 16 partial outputs of the fused FFN
 
   if (h->prof) prof_reset(h);
   prof_mark(h, "begin", s);
@@ -562,40 +558,24 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
     if ((r = tap_save(h, "src", t_src, (size_t)M * D, s))) return r;
     prof_mark(h, "input_proj", s);
     // ---- encoder (transformer.py:143-159, post-norm) ----------------------------------------
-    // Every LayerNorm runs as the prologue of the GEMM that consumes it: norm2 of layer i-1 in the QKV
-    // projection of layer i (which also materialises the layer input `xin` for the residual), norm1 in
-    // linear1 (materialising x1), norm2 of the last layer in the decoder K/V projection (-> memory).
     float* mem_c = memory + (size_t)b0 * TOK * D;
-    const float* xin = t_src;      // normalised input of the current layer
-    const float* pre2 = nullptr;   // un-normalised output of the previous layer
+    const float* xin = t_src;
     for (size_t li = 0; li < h->enc.size(); ++li) {
       const EncW& e = h->enc[li];
       // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
-      if (li == 0) {
-        if ((r = linear(h, t_src, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
-      } else {
-        const EncW& pe = h->enc[li - 1];
-        LnSpec ln; ln.w = pe.n2w; ln.b = pe.n2b; ln.out = t_alt;
-        if ((r = linear(h, pre2, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s, &ln))) return r;
-        xin = t_alt;
-      }
+      if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
       KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
       prof_mark(h, "attention enc", s, 2);
       if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
-      LnSpec ln1; ln1.w = e.n1w; ln1.b = e.n1b; ln1.out = t_x1;
-      if ((r = linear(h, t_tmp, nullptr, 0, 1, 0, e.l1w, e.l1b, nullptr, 1, 1.f, 0, t_hid, M, FFN, D, s, &ln1))) return r;
-      if ((r = linear(h, t_hid, nullptr, 0, 1, 0, e.l2w, e.l2b, t_x1, 0, 1.f, 0, t_pre2, M, D, FFN, s))) return r;
-      pre2 = t_pre2;
+      if ((r = layernorm(h, t_tmp, e.n1w, e.n1b, t_x1, M, s))) return r;
+      float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
+      if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_tmp, y, M, s))) return r;
+      xin = y;
     }
     prof_mark(h, "encoder", s);
-    // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195);
-    //      memory = norm2 of the last encoder layer
+    // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195)
     float* kv_c = kv + (size_t)b0 * TOK * KVLD;
-    {
-      const EncW& pe = h->enc.back();
-      LnSpec ln; ln.w = pe.n2w; ln.b = pe.n2b; ln.out = mem_c;
-      if ((r = linear(h, pre2, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s, &ln))) return r;
-    }
+    if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
     prof_mark(h, "dec_kv", s);
   }
   h->taps["memory"] = {memory, (size_t)B * TOK * D};
@@ -623,7 +603,8 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
   d.nb_max = B < pairs_per ? B : pairs_per;
   d.Rmax = (size_t)d.nb_max * d.q_chunk;
   d.single_chunk = d.nb_max >= B && d.q_chunk >= Q;
-  int r = ensure(h, h->dec_scr, d.Rmax * (7 * D + FFN));
+  const size_t hid_per_row = d.Rmax <= (size_t)g_ffn_fuse_max_rows ? 4 * FFN : FFN;  // fused FFN: up to 16 partial outputs
+  int r = ensure(h, h->dec_scr, d.Rmax * (7 * D + hid_per_row));
   if (r) return r;
   float* p = h->dec_scr.ptr;
   d.qpos = p; p += d.Rmax * D;
@@ -633,7 +614,7 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
   d.pre2 = p; p += d.Rmax * D;
   d.t2 = p; p += d.Rmax * D;
   d.pre3 = p; p += d.Rmax * D;
-  d.hid = p; p += d.Rmax * FFN;
+  d.hid = p; p += d.Rmax * hid_per_row;
   return COTR_OK;
 }
 
@@ -657,29 +638,21 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   const int R = nb * nq;
   int r;
   if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s))) return r;
-  // transformer.py:185-201 per layer; norm3 of layer l-1 feeds layer l's q projection (tgt is kept for the
-  // residual), norm2 feeds linear1 (t2 kept for the residual).
+  // transformer.py:185-201 per layer (cross-attention only, post-norm)
   for (int li = 0; li < L; ++li) {
     const DecW& w = h->dec[li];
-    if (li > 0) {
-      const DecW& pw = h->dec[li - 1];
-      LnSpec ln; ln.w = pw.n3w; ln.b = pw.n3b; ln.out = d.tgt;
-      if ((r = linear(h, d.pre3, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s, &ln))) return r;
-    }
+    // q = Wq(tgt + query_pos) * 32^-0.5 ; tgt == 0 at layer 0 (transformer.py:54): computed by dec_prologue
+    if (li > 0 && (r = linear(h, d.tgt, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s))) return r;
     KCHK(h, launch_attention(d.q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d.ao, D, nb, nq, s),
          "attention");
     prof_mark(h, "attention dec", s, 2);
     if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
-    LnSpec ln2; ln2.w = w.n2w; ln2.b = w.n2b; ln2.out = d.t2;
-    if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, w.l1w, w.l1b, nullptr, 1, 1.f, 0, d.hid, R, FFN, D, s, &ln2))) return r;
-    if ((r = linear(h, d.hid, nullptr, 0, 1, 0, w.l2w, w.l2b, d.t2, 0, 1.f, 0, d.pre3, R, D, FFN, s))) return r;
+    if ((r = layernorm(h, d.pre2, w.n2w, w.n2b, d.t2, R, s))) return r;
+    if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, d.tgt, R, s))) return r;
   }
-  // norm3 of the last layer, then decoder.norm, then corr_embed - on the last layer only
-  {
-    const DecW& lw = h->dec[L - 1];
-    LnSpec ln; ln.w = lw.n3w; ln.b = lw.n3b; ln.w2 = h->dn_w; ln.b2 = h->dn_b; ln.out = d.tgt;
-    if ((r = linear(h, d.pre3, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s, &ln))) return r;
-  }
+  // decoder.norm + corr_embed on the last layer only (the reference computes all 6 and keeps [-1])
+  if ((r = layernorm(h, d.tgt, h->dn_w, h->dn_b, d.pre2, R, s))) return r;
+  if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s))) return r;
   if ((r = linear(h, d.ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d.q, R, D, D, s))) return r;
   KCHK(h, launch_head2(d.q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
   prof_mark(h, "head2", s, 2);
@@ -702,7 +675,7 @@ int decode_impl(cotr_ctx* h, const float* queries, int B, int Q, float* out, hip
       int r;
       if ((r = decode_chunk(h, d, 0, qsrc, odst, kv_c, nb, nq, Q, s))) return r;
       if ((r = tap_save(h, "query_pos", d.qpos, (size_t)R * D, s))) return r;
-      if ((r = tap_save(h, "hs", d.tgt, (size_t)R * D, s))) return r;
+      if ((r = tap_save(h, "hs", d.pre2, (size_t)R * D, s))) return r;
     }
   }
   prof_mark(h, "decoder", s);
@@ -752,12 +725,12 @@ int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   const size_t L = h->dec.empty() ? 6 : h->dec.size();
   const size_t Bc = B < g_enc_chunk ? B : g_enc_chunk;
   const size_t per_pair = (size_t)128 * 256 * 64 + (size_t)64 * 128 * 64 + 5 * (size_t)64 * 128 * 256 +
-                          6 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * FFN;
+                          6 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
   const size_t q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
   const size_t pairs_per = (Q > 0 && Q < DEC_ROWS) ? (DEC_ROWS / Q) : 1;
   const size_t nb = (size_t)B < pairs_per ? B : pairs_per;
   size_t fl = h->wfloats + (size_t)TOK * D + (size_t)B * TOK * (D + L * 2 * D) + per_pair * Bc +
-              nb * q_chunk * (7 * D + FFN);
+              nb * q_chunk * (7 * D + (nb * q_chunk <= (size_t)g_ffn_fuse_max_rows ? 4 * FFN : FFN));
   *bytes = fl * sizeof(float);
   return COTR_OK;
 }
@@ -911,8 +884,8 @@ int cotr_set_encode_chunk(int pairs) {
   return COTR_OK;
 }
 
-int cotr_set_ln_fusion_min_rows(int rows) {
-  g_ln_fuse_min_rows = rows < 0 ? 0 : rows;
+int cotr_set_ffn_fusion_max_rows(int rows) {
+  g_ffn_fuse_max_rows = rows < 0 ? 0 : rows;
   return COTR_OK;
 }
 
@@ -975,5 +948,17 @@ int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* 
   if (ha <= 0 || wa <= 0 || hb <= 0 || wb <= 0) return COTR_ERR_ARG;
   return op_ret(launch_crop_resize(img_a, ha, wa, img_b, hb, wb, boxes, n, out, max_size, static_cast<hipStream_t>(stream)));
 }
+
+// fused FFN block: y = LayerNorm(x + linear2(relu(linear1(x)))) in two launches; scratch >= ffn chunks * M * 256 floats
+int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
+                      const float* ln_b, float* scratch, float* y, int M, cotr_stream stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nch = ffn_fused_chunks(M);
+  int r = launch_ffn_fused(x, w1, b1, w2, scratch, M, nch, s);
+  if (r == 0) r = launch_ln_reduce(scratch, nch, b2, x, ln_w, ln_b, y, M, s);
+  return op_ret(r);
+}
+
+int cotr_op_ffn_chunks(int M) { return ffn_fused_chunks(M); }
 
 }  // extern "C"

@@ -44,16 +44,7 @@ struct GemmParams {
   int relu;
   float colscale;
   int colscale_n;
-  // LayerNorm prologue (k-split kernel, DENSE, K == 256 == NWK*32: the A tile holds whole rows):
-  //   A'' = LN2(LN1(A)) (+ A2 as above, added AFTER the norm); ln2 optional (decoder.norm after norm3).
-  // ln_out (optional, [M][256]): the normalised rows (before the A2 add) are written by the workgroups
-  // of the first 256 output columns, so the residual path of the next GEMM can read them.
   const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
-  const float* ln_w;
-  const float* ln_b;
-  const float* ln2_w;
-  const float* ln2_b;
-  float* ln_out;
 };
 
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s);            // tuned / modelled config
@@ -61,7 +52,7 @@ int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s);  // 
 int gemm_pick_config(int mode, const GemmParams& p);
 int gemm_num_configs();
 bool gemm_cfg_supports_ln(int cfg);
-const float* gemm_zero_buffer();  // per-process device buffer of zeros (LDS-DMA padding source)  // can this configuration run the LayerNorm prologue (K == 256)?
+const float* gemm_zero_buffer();  // per-process device buffer of zeros (LDS-DMA padding source)
 
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]
 int launch_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
@@ -79,3 +70,9 @@ int launch_head2(const float* x, const float* w, const float* b, float* y, int n
 // batched crop + Pillow-bilinear resize to 256x256 + side-by-side + ImageNet normalise (crop_resize.hip)
 int launch_crop_resize(const uint8_t* img_a, int ha, int wa, const uint8_t* img_b, int hb, int wb,
                        const int32_t* boxes, int n, float* out, int max_size, hipStream_t s);
+
+// fused feed-forward block (ffn.hip) and its reduce + bias + residual + LayerNorm tail (pointwise.hip)
+int ffn_fused_chunks(int M);
+int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch, hipStream_t s);
+int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
+                     float* y, int rows, hipStream_t s);

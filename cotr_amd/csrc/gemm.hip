@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 // accumulators are summed through LDS in a fixed order (deterministic, no atomics, no second
 // launch) and the same fused epilogue is applied.
 // ---------------------------------------------------------------------------------------------
-template <int NWK, int TM, int TN, int MODE, int DB, int LN>
+template <int NWK, int TM, int TN, int MODE, int DB>
 __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
   constexpr int NT = NWK * 64;
   // TN == 0 selects the 32 x 16 tile built from v_mfma_f32_16x16x4_f32 (two 16-row blocks x one 16-column block):
@@ -302,8 +302,6 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 
   f32x4 ra[PA], rw[PW];
   const int tiles_per_tap = (MODE == GEMM_CONV) ? p.Cin / BK : 1;
-  constexpr bool ln_pro = LN != 0;  // host: DENSE, K == 256 == KS (one step), ln_w != nullptr
-  static_assert(!LN || (MODE == GEMM_DENSE && KS == 256), "LayerNorm prologue needs whole rows per step");
 
   auto load_tile = [&](int st) {
 #if defined(COTR_ABL) && COTR_ABL == 1  // ablation: only the first global load
@@ -318,7 +316,7 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
         f32x4 v = z;
         if (a_ok[i] && k_ok) {
           v = *reinterpret_cast<const f32x4*>(a_ptr[i] + st * KS);
-          if (use_a2 && !ln_pro) v += *reinterpret_cast<const f32x4*>(a2_ptr[i] + st * KS);
+          if (use_a2) v += *reinterpret_cast<const f32x4*>(a2_ptr[i] + st * KS);
         }
         ra[i] = v;
       }
@@ -402,58 +400,6 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
     }
   };
 
-  // LayerNorm prologue, in registers: with 8 wavefronts a thread's float4 i is row (wave + 8*i),
-  // columns lane*4..+3 of the 256-wide row, so a row is exactly one wavefront-wide register and the
-  // statistics are wave reductions; the PA rows are reduced in lock-step to overlap shuffle latency.
-  auto ln_regs = [&]() {
-    if constexpr (LN != 0) {
-      f32x4 a2v[PA];
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        a2v[i] = (use_a2 && a_ok[i]) ? *reinterpret_cast<const f32x4*>(a2_ptr[i]) : z;
-      }
-#pragma unroll
-      for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1 && p.ln2_w == nullptr) break;
-        const f32x4 ww = *reinterpret_cast<const f32x4*>((pass == 0 ? p.ln_w : p.ln2_w) + lc4 * 4);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>((pass == 0 ? p.ln_b : p.ln2_b) + lc4 * 4);
-        float sum[PA], sq[PA];
-#pragma unroll
-        for (int i = 0; i < PA; ++i) sum[i] = ra[i][0] + ra[i][1] + ra[i][2] + ra[i][3];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-          for (int i = 0; i < PA; ++i) sum[i] += __shfl_xor(sum[i], off);
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-          const float mean = sum[i] * (1.f / 256.f);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) ra[i][c] -= mean;
-          sq[i] = ra[i][0] * ra[i][0] + ra[i][1] * ra[i][1] + ra[i][2] * ra[i][2] + ra[i][3] * ra[i][3];
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-          for (int i = 0; i < PA; ++i) sq[i] += __shfl_xor(sq[i], off);
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-          const float rstd = 1.f / sqrtf(sq[i] * (1.f / 256.f) + 1e-5f);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) ra[i][c] = ra[i][c] * rstd * ww[c] + bb[c];
-        }
-      }
-      const bool writer = p.ln_out != nullptr && n0 < 256 && lc4 * 4 >= n0 && lc4 * 4 < n0 + BN;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int m = m0 + lr + 8 * i;
-        if (writer && a_ok[i]) *reinterpret_cast<f32x4*>(p.ln_out + (size_t)m * 256 + lc4 * 4) = ra[i];
-        if (a_ok[i]) ra[i] += a2v[i];
-        else ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-  };
-
   // DB == 2: global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write pass).  With
   // 8 wavefronts one wave instruction moves exactly one padded row (64 lanes x 16 B = 1024 B of data),
   // so the LDS destination is wave-uniform as the instruction requires; out-of-range rows / padded taps
@@ -502,14 +448,6 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
       compute(st & 1);
       __syncthreads();
     }
-  } else if constexpr (LN) {
-    load_tile(0);
-    // K == 256 is a single step: normalise in registers, stage once, compute (one LDS stage is enough)
-    ln_regs();
-    store_tile(0);
-    __syncthreads();
-    compute(0);
-    __syncthreads();
   } else if constexpr (DB) {
     load_tile(0);
     // two LDS stages, ONE barrier per K step: a wavefront that has finished its MFMAs of step st
@@ -657,38 +595,34 @@ static constexpr size_t ks_smem() {
   return tile > red ? tile : red;
 }
 
-template <int NWK, int TM, int TN, int MODE, int DB, int LN>
+template <int NWK, int TM, int TN, int MODE, int DB>
 static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
   constexpr int BM = TM * 32, BN = TN == 0 ? 16 : TN * 32;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
   static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  constexpr size_t smem = ks_smem<NWK, TM, TN, (DB && !LN)>();  // the LN variant is single-step: one stage
+  constexpr size_t smem = ks_smem<NWK, TM, TN, DB>();
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_kernel<NWK, TM, TN, MODE, DB, LN>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_kernel<NWK, TM, TN, MODE, DB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set = true;
   }
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles = tiles_m * (p.N / BN);
-  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB, LN>), dim3(tiles), dim3(NWK * 64), smem, s, p);
+  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles), dim3(NWK * 64), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 template <int NWK, int TM, int TN, int MODE, int DB = 0>
 static int launch_ks(const GemmParams& p, hipStream_t s) {
-  if constexpr (MODE == GEMM_DENSE && NWK == 8 && TN >= 1) {  // the LayerNorm-prologue instantiation (separate: +40 VGPRs)
-    if (p.ln_w != nullptr) return p.K == 256 ? launch_ks_impl<NWK, TM, TN, MODE, DB, 1>(p, s) : -1;
-  }
-  if (p.ln_w != nullptr) return -1;
   if constexpr (DB == 2) {
     if (p.A2 != nullptr) return -1;  // the x+pos prologue needs the register path
     GemmParams q = p;
     if (q.zeros == nullptr) q.zeros = gemm_zero_buffer();
     if (q.zeros == nullptr) return -2;
-    return launch_ks_impl<NWK, TM, TN, MODE, DB, 0>(q, s);
+    return launch_ks_impl<NWK, TM, TN, MODE, DB>(q, s);
   } else {
-    return launch_ks_impl<NWK, TM, TN, MODE, DB, 0>(p, s);
+    return launch_ks_impl<NWK, TM, TN, MODE, DB>(p, s);
   }
 }
 
@@ -742,7 +676,7 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
     const size_t tile = (size_t)(c.kind >= 2 ? 2 : 1) * rows * (c.a * BK + 4) * sizeof(float);
     const size_t red = (size_t)c.a * (c.tn == 0 ? 8 : c.tm * c.tn * 16) * 64 * sizeof(float);
     if ((tile > red ? tile : red) > 163840) return false;
-    if (c.kind == 3 && (p.A2 != nullptr || p.ln_w != nullptr)) return false;  // LDS-DMA has no register prologue
+    if (c.kind == 3 && p.A2 != nullptr) return false;  // LDS-DMA has no register prologue (x + pos)
   }
   return p.N % bn == 0;
 }
@@ -825,14 +759,8 @@ const float* gemm_zero_buffer() {
   return z;
 }
 
-// The LayerNorm prologue needs a configuration whose K step is the whole row: k-split with 8 wavefronts.
-bool gemm_cfg_supports_ln(int cfg) {
-  return cfg >= 0 && cfg < kNumCfgs && (kCfgs[cfg].kind == 1 || kCfgs[cfg].kind == 2) && kCfgs[cfg].a == 8 && kCfgs[cfg].tn >= 1;
-}
-
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s) {
   const int cfg = gemm_pick_config(mode, p);
   if (cfg < 0) return -1;
-  if (p.ln_w != nullptr && !(mode == GEMM_DENSE && p.K == 256 && gemm_cfg_supports_ln(cfg))) return -1;
   return launch_gemm_cfg(mode, cfg, p, s);
 }

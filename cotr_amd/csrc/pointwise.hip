@@ -32,6 +32,36 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   *reinterpret_cast<f32x4*>(y + (size_t)row * 256 + lane * 4) = out;
 }
 
+// LayerNorm of (sum of `np` partial outputs [np][rows][256] + bias + residual): the tail of the fused FFN block
+// (ffn.hip): y = LN(residual + linear2(...)) with linear2's bias (transformer.py:156-158, 199-201).
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ parts, int np, const float* __restrict__ bias,
+                                                        const float* __restrict__ residual, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(bias + lane * 4);
+  v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * 256 + lane * 4);
+  for (int c = 0; c < np; ++c) v += *reinterpret_cast<const f32x4*>(parts + ((size_t)c * rows + row) * 256 + lane * 4);
+  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+  const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+  const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+  const float rstd = 1.f / sqrtf(var + 1e-5f);
+  const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
+  const f32x4 bb = *reinterpret_cast<const f32x4*>(b + lane * 4);
+  f32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = d[i] * rstd * ww[i] + bb[i];
+  *reinterpret_cast<f32x4*>(y + (size_t)row * 256 + lane * 4) = out;
+}
+
+int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
+                     float* y, int rows, hipStream_t s) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, w, b, y, rows);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows);

@@ -121,6 +121,11 @@ int cotr_op_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, co
 int cotr_op_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
                       int nb, int nq, cotr_stream stream);
 int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, int rows, cotr_stream stream);
+/* fused FFN block y = LN(x + W2 relu(W1 x + b1) + b2) in two launches (ffn.hip + ln_reduce); scratch holds
+ * cotr_op_ffn_chunks(M) * M * 256 floats */
+int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
+                      const float* ln_b, float* scratch, float* y, int M, cotr_stream stream);
+int cotr_op_ffn_chunks(int M);
 /* lin_sine encoding of pts [n,2] -> y [n,256] (COTR/models/position_encoding.py:41-45) */
 int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
 
@@ -141,9 +146,8 @@ int cotr_gemm_num_configs(void);
 /* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB
  * Infinity Cache, larger ones fill the CUs better */
 int cotr_set_encode_chunk(int pairs);
-/* LayerNorm can run as the prologue of the consuming GEMM when the GEMM has at least this many rows; default:
- * never (the separate launch measured faster), 0 = always where the launch configuration allows it */
-int cotr_set_ln_fusion_min_rows(int rows);
+/* the fused FFN block (ffn.hip) is used for GEMMs with at most this many rows (default 1024); 0 = never */
+int cotr_set_ffn_fusion_max_rows(int rows);
 /* key splits (wavefronts per workgroup) of the attention kernel: 4, 8, 16, or 0 = automatic */
 int cotr_set_attention_splits(int ns);
 /* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured

@@ -131,3 +131,23 @@ def test_lin_sine_encoding():
     assert _lib.load_library().cotr_op_posenc(G.P(pts_d), G.P(y), 777, G.sptr()) == 0
     e = float((y.cpu() - ref).abs().max())
     assert e < 1e-6, e
+
+
+@pytest.mark.parametrize('M', [1000, 512, 33, 4000])
+def test_fused_ffn_block(M):
+    """ffn.hip + ln_reduce: y = LayerNorm(x + linear2(relu(linear1(x)))) (transformer.py:156-158)."""
+    from cotr_amd import _lib
+    g = _g(M)
+    x = torch.randn(M, 256, generator=g)
+    w1, b1 = torch.randn(1024, 256, generator=g) / 16, torch.randn(1024, generator=g) * 0.1
+    w2, b2 = torch.randn(256, 1024, generator=g) / 32, torch.randn(256, generator=g) * 0.1
+    lw, lb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    ref = F.layer_norm(x + F.linear(F.relu(F.linear(x, w1, b1)), w2, b2), (256,), lw, lb, 1e-5)
+    d = G.dev()
+    lib = _lib.load_library()
+    t = [v.to(d) for v in (x, w1, b1, w2, b2, lw, lb)]
+    scratch = torch.empty(lib.cotr_op_ffn_chunks(M) * M * 256, device=d)
+    y = torch.empty(M, 256, device=d)
+    assert lib.cotr_op_ffn_block(*[G.P(v) for v in t], G.P(scratch), G.P(y), M, G.sptr()) == 0
+    e = G.rel_err(y, ref)
+    assert e < 2e-5, e

@@ -158,21 +158,21 @@ def test_state_dict_round_trip_and_reload():
     assert not torch.equal(a, b)
 
 
-def test_layernorm_prologue_fusion_path():
-    """The LayerNorm-as-GEMM-prologue variant (off by default) computes the same function."""
+def test_fused_and_unfused_ffn_paths_agree():
+    """The fused FFN block (default up to 3072 rows) and the three-launch path compute the same function."""
     from cotr_amd import _lib
     sd = synth_state_dict(0)
     img, qs = synth_inputs(2, 300, seed=15)
     m = hip_model()
-    base = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
     lib = _lib.load_library()
     try:
-        assert lib.cotr_set_ln_fusion_min_rows(0) == 0
-        fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+        assert lib.cotr_set_ffn_fusion_max_rows(0) == 0
+        plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
     finally:
-        lib.cotr_set_ln_fusion_min_rows(0x7fffffff)
-    assert cotr_oracle.px_err(fused, base) < SHAPE_NOISE_PX
-    assert cotr_oracle.px_err(fused, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
+        lib.cotr_set_ffn_fusion_max_rows(1024)
+    assert cotr_oracle.px_err(fused, plain) < SHAPE_NOISE_PX
+    assert cotr_oracle.px_err(plain, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
 
 
 def test_dense_pass_shape_q131072():

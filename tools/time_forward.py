@@ -14,8 +14,9 @@ def main():
     shapes = [(1, 1000), (2, 257), (4, 1000), (8, 1000), (32, 1), (32, 1000)]
     shapes = [(1, 1000), (2, 257), (3, 500), (4, 1000), (5, 100), (8, 1000), (13, 1), (16, 1), (32, 1), (32, 1000)]
     shapes = [(1, 1000), (1, 4000), (2, 257), (4, 1000), (32, 1000)]
-    for ns in [32]:
-        lib.cotr_set_encode_chunk(ns)
+    shapes = [(1, 1000), (1, 2500), (2, 257), (4, 500), (6, 400), (8, 1000), (32, 1)]
+    for ns in [0, 3072]:
+        lib.cotr_set_ffn_fusion_max_rows(ns)
         for (b, q) in shapes:
             img, qs = synth_inputs(b, q, seed=1)
             img, qs = img.cuda(), qs.cuda()
@@ -25,5 +26,5 @@ def main():
             t = time.perf_counter()
             for _ in range(n): m(img, qs)
             torch.cuda.synchronize()
-            print(f'enc_chunk={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
+            print(f'ffn_fuse_max_rows={ns} B={b} Q={q}: {(time.perf_counter()-t)/n*1e3:.3f} ms', flush=True)
 main()
