@@ -27,8 +27,62 @@ import torch
 
 BASE_ZOOM = 1.0                     # COTR/inference/inference_helper.py:17
 THRESHOLD_PIXELS_RELATIVE = 0.02    # :16
+THRESHOLD_SPARSE = 0.02             # :15
+THRESHOLD_AREA = 0.02               # :18
+MAX_SIZE = 256                      # COTR/utils/constants.py:2
 
-RefineResult = namedtuple('RefineResult', ['loc_from', 'loc_to', 'good', 'loc_history', 'model_calls', 'crops'])
+
+def _affine_from_3pts(src, dst):
+    """2x3 affine map through three point pairs - what ``cv2.getAffineTransform`` returns (float64)."""
+    a = np.concatenate([np.asarray(src, dtype=np.float64), np.ones((3, 1))], axis=1)
+    return np.linalg.solve(a, np.asarray(dst, dtype=np.float64)).T
+
+
+def _float_image_resize(img, shape):
+    """``utils.float_image_resize`` (COTR/utils/utils.py:69-83): per-channel Pillow mode-'F' bilinear resize."""
+    import PIL.Image
+    layers = [np.array(PIL.Image.fromarray(l).resize(shape[::-1], resample=PIL.Image.BILINEAR)) for l in img.transpose(2, 0, 1)]
+    return np.stack(layers, axis=-1)
+
+
+def _merge_flow_patches(corrs):
+    """``merge_flow_patches`` (inference_helper.py:61-75): per pixel keep the patch with the lowest cycle error.
+    corrs: list of (patch [h,w,3], x, y, w, h, ow, oh)."""
+    oh, ow = corrs[0][6], corrs[0][5]
+    confidence = np.ones([oh, ow]) * 100
+    flow = np.zeros([oh, ow, 2])
+    cmap = np.ones([oh, ow]) * -1
+    for i, (patch, x, y, w, h, _ow, _oh) in enumerate(corrs):
+        temp = np.ones([oh, ow]) * 100
+        temp[y:y + h, x:x + w] = patch[..., 2]
+        tempf = np.zeros([oh, ow, 2])
+        tempf[y:y + h, x:x + w] = patch[..., :2]
+        min_ind = np.stack([temp, confidence], axis=-1).argmin(axis=-1) == 0
+        confidence[min_ind] = temp[min_ind]
+        flow[min_ind] = tempf[min_ind]
+        cmap[min_ind] = i
+    return flow, confidence, cmap
+
+RefineResult = namedtuple('RefineResult', ['loc_from', 'loc_to', 'good', 'loc_history', 'model_calls', 'crops', 'steps'])
+
+
+def _reference_schedule(steps, good, batch_size, max_corrs, total):
+    """Which tasks has the reference's loop finished when it exits?  (sparse_engine.py:208-218: every iteration steps
+    the first ``batch_size`` unfinished tasks of the list once; it stops when none is left or when ``max_corrs``
+    finished tasks are 'good'.)  ``steps``/``good`` cover the first len(steps) of ``total`` tasks.
+    -> finished mask over the known prefix, or None if the answer depends on tasks beyond the prefix."""
+    remaining = np.array(steps, dtype=np.int64)
+    n_good = 0
+    while True:
+        window = np.flatnonzero(remaining > 0)[:batch_size]
+        if n_good >= max_corrs:
+            return remaining == 0               # stops here whatever follows in the list
+        if window.size < batch_size and len(remaining) < total:
+            return None                         # the next batch would reach into tasks not refined yet
+        if window.size == 0:
+            return remaining == 0
+        remaining[window] -= 1
+        n_good += int(np.asarray(good)[window[remaining[window] == 0]].sum())
 
 
 def patch_boxes(img_shape, pos, scale):
@@ -87,8 +141,11 @@ class ZoomEngine:
     make_cropper  factory (img_a, img_b, device) -> callable(boxes, out); default: the HIP kernel.
     """
 
-    def __init__(self, model, max_pairs=256, make_cropper=None):
+    def __init__(self, model, max_pairs=256, make_cropper=None, batch_size=32, mode='tile'):
+        if mode != 'tile':
+            raise NotImplementedError("only SparseEngine's mode='tile' is mirrored (demo_single_pair / guided matching / wbs)")
         self.model = model
+        self.batch_size = int(batch_size)   # the reference walks tasks in groups of this size: decides where it stops
         self.max_pairs = int(max_pairs)
         self.make_cropper = make_cropper or _DeviceCropper
         self.total_tasks = 0       # same bookkeeping as SparseEngine.total_tasks: crops pushed through the model
@@ -129,6 +186,7 @@ class ZoomEngine:
         cropper = self.make_cropper(img_a, img_b, device)
         buf = torch.empty((min(n, self.max_pairs), 3, 256, 512), dtype=torch.float32, device=device) if n else None
         history = [cur.copy()]
+        steps = np.zeros(n, dtype=np.int64)
         calls0, crops0 = 0, self.total_tasks
         for zi, zoom in enumerate(zoom_ins):
             last = zi == len(zoom_ins) - 1
@@ -143,6 +201,7 @@ class ZoomEngine:
                 q = ((loc_from[active] - np.stack([ax, ay], 1)) / np.array([asz * 2, asz])).astype(np.float32)
                 raw = self._infer(cropper, boxes, q, device, buf)
                 calls0 += 1
+                steps[active] += 1
                 # scale_to_loc :145-151
                 raw = raw.copy()
                 raw[:, 0] = (raw[:, 0] - np.float32(0.5)) * np.float32(2)
@@ -174,7 +233,7 @@ class ZoomEngine:
             good = np.ones(n, dtype=bool)
         else:                                                      # conclude :184-188
             good = hist.std(axis=0).max(axis=1) < THRESHOLD_PIXELS_RELATIVE * max(*img_b.shape)
-        return RefineResult(loc_from, cur.copy(), good, hist, calls0, self.total_tasks - crops0)
+        return RefineResult(loc_from, cur.copy(), good, hist, calls0, self.total_tasks - crops0, steps)
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod
@@ -237,24 +296,178 @@ class ZoomEngine:
         return np.concatenate([queries_a, best], axis=1)
 
     # ------------------------------------------------------------------------------------------------
+    def flow(self, img_a, img_b):
+        """``cotr_flow`` (inference_helper.py:168-182): the dense initial pass.  Every pair of square patches of the two
+        images gets ONE forward with the 256x512 grid of queries (131072, both halves; :116-127), the self-composition
+        of the answer gives a per-pixel cycle error (:137-145), maps are moved to image coordinates, resized to the patch
+        and merged by lowest cycle error.  All patch pairs are cropped in one launch and go through the model as one
+        batch.  -> corr_a, con_a, resample_a, corr_b, con_b, resample_b (as the reference)."""
+        import torch.nn.functional as F
+        img_a = np.ascontiguousarray(img_a)
+        img_b = np.ascontiguousarray(img_b)
+        pa, pb = self._square_patches(img_a), self._square_patches(img_b)
+        pairs = [(i, j) for i in pa for j in pb]
+        boxes = np.array([[i[0], i[1], i[2], j[0], j[1], j[2]] for i, j in pairs], dtype=np.int32)
+        device = next(self.model.parameters()).device
+        cropper = self.make_cropper(img_a, img_b, device)
+        buf = torch.empty((len(pairs), 3, 256, 512), dtype=torch.float32, device=device)
+        img = cropper(boxes, buf)
+        jj, ii = np.meshgrid(np.arange(MAX_SIZE * 2), np.arange(MAX_SIZE))
+        q_grid = np.stack([jj / (MAX_SIZE * 2), ii / MAX_SIZE], axis=-1)               # [256,512,2] float64
+        q = torch.from_numpy(q_grid.reshape(1, -1, 2)).float().to(device).expand(len(pairs), -1, -1).contiguous()
+        out_all = self.model(img, q)['pred_corrs'].detach().cpu().numpy()
+        self.total_tasks += len(pairs)
+        (ha, wa), (hb, wb) = img_a.shape[:2], img_b.shape[:2]
+        base = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]])
+        corrs_a, corrs_b = [], []
+        for k, (pi, pj) in enumerate(pairs):
+            out_list = out_all[k].reshape(MAX_SIZE, MAX_SIZE * 2, -1)
+            in_grid = torch.from_numpy(q_grid).float()[None] * 2 - 1
+            out_grid = torch.from_numpy(out_list).float()[None] * 2 - 1
+            cycle_grid = F.grid_sample(out_grid.permute(0, 3, 1, 2), out_grid, align_corners=False).permute(0, 2, 3, 1)
+            confidence = torch.norm(cycle_grid[0, ...] - in_grid[0, ...], dim=-1)
+            corr = out_grid[0].clone()
+            corr[:, :MAX_SIZE, 0] = corr[:, :MAX_SIZE, 0] * 2 - 1
+            corr[:, MAX_SIZE:, 0] = corr[:, MAX_SIZE:, 0] * 2 + 1
+            corr = torch.cat([corr, confidence[..., None]], dim=-1).numpy()
+            c_i, c_j = corr[:, :MAX_SIZE, :], corr[:, MAX_SIZE:, :]
+
+            def corners(px, py, ps, ow, oh):
+                return (np.array([[px, py], [px + ps, py], [px + ps, py + ps], [px, py + ps]]) / np.array([ow, oh])) * 2 + \
+                    np.array([-1, -1])
+            real_j, real_i = corners(pj[0], pj[1], pj[2], wb, hb), corners(pi[0], pi[1], pi[2], wa, ha)
+            t_i = _affine_from_3pts(base[:3].astype(np.float32), real_j[:3].astype(np.float32))
+            t_j = _affine_from_3pts(base[:3].astype(np.float32), real_i[:3].astype(np.float32))
+            c_i[..., :2] = c_i[..., :2] @ t_i[:2, :2] + t_i[:, 2]
+            c_j[..., :2] = c_j[..., :2] @ t_j[:2, :2] + t_j[:, 2]
+            corrs_a.append((_float_image_resize(c_i, (pi[2], pi[2])), pi[0], pi[1], pi[2], pi[2], wa, ha))
+            corrs_b.append((_float_image_resize(c_j, (pj[2], pj[2])), pj[0], pj[1], pj[2], pj[2], wb, hb))
+        corr_a, con_a, _ = _merge_flow_patches(corrs_a)
+        corr_b, con_b, _ = _merge_flow_patches(corrs_b)
+
+        def resample(img_src, corr):
+            t = torch.from_numpy(np.transpose(img_src, (2, 0, 1)))[None].float()
+            r = F.grid_sample(t, torch.from_numpy(corr)[None].float(), align_corners=False)[0]
+            return np.transpose(r.numpy(), (1, 2, 0))
+        return corr_a, con_a, resample(img_b, corr_a), corr_b, con_b, resample(img_a, corr_b)
+
+    def gen_tasks(self, img_a, img_b, max_corrs, queries_a, force):
+        """``SparseEngine.gen_tasks`` without ``areas`` (sparse_engine.py:108-195, mode 'tile'): dense pass, confident
+        pixels, relative scale from the confident areas.  -> loc_from [N,2], loc_to [N,2], identifier [N] (-1 = None),
+        area_a, area_b.  Uses numpy's global RNG exactly where the reference does (np.random.choice, :151,154)."""
+        corr_a, con_a, _, corr_b, con_b, _ = self.flow(img_a, img_b)
+        mask_a, mask_b = con_a < THRESHOLD_SPARSE, con_b < THRESHOLD_SPARSE
+        area_a = (con_a < THRESHOLD_AREA).sum() / mask_a.size
+        area_b = (con_b < THRESHOLD_AREA).sum() / mask_b.size
+        size_a, size_b = np.array(img_a.shape[:2][::-1]), np.array(img_b.shape[:2][::-1])
+        loc_from, loc_to, ident = [], [], []
+        if queries_a is None:
+            index_a = np.array(np.where(mask_a)).T
+            index_a = index_a[np.random.choice(len(index_a), min(max_corrs, len(index_a)))]
+            index_b = np.array(np.where(mask_b)).T
+            index_b = index_b[np.random.choice(len(index_b), min(max_corrs, len(index_b)))]
+            for pos in index_a:
+                loc_from.append(pos[::-1].astype(np.float64))
+                loc_to.append((corr_a[tuple(np.floor(pos).astype('int'))].copy() * 0.5 + 0.5) * size_b)
+                ident.append(-1)
+            for pos in index_b:   # "trick": the first guess is fixed instead of the query (sparse_engine.py:160-166)
+                loc_from.append((corr_b[tuple(np.floor(pos).astype('int'))].copy() * 0.5 + 0.5) * size_a)
+                loc_to.append(pos[::-1].astype(np.float64))
+                ident.append(-1)
+        elif force:
+            for i, lf in enumerate(queries_a):
+                pos = lf[::-1]
+                pos = np.array([np.clip(pos[0], 0, corr_a.shape[0] - 1), np.clip(pos[1], 0, corr_a.shape[1] - 1)], dtype=int)
+                loc_from.append(np.asarray(lf, dtype=np.float64))
+                loc_to.append((corr_a[tuple(pos)].copy() * 0.5 + 0.5) * size_b)
+                ident.append(i)
+        else:
+            def inside(pos):
+                return not ((pos > np.array(img_a.shape[:2]) - 1).any() or (pos < 0).any())
+            for i, lf in enumerate(queries_a):
+                pos = lf[::-1]
+                if inside(pos) and mask_a[tuple(np.floor(pos).astype('int'))]:
+                    loc_from.append(np.asarray(lf, dtype=np.float64))
+                    loc_to.append((corr_a[tuple(np.floor(pos).astype('int'))].copy() * 0.5 + 0.5) * size_b)
+                    ident.append(i)
+            if len(loc_from) < max_corrs:
+                extra, counter = max_corrs - len(loc_from), 0
+                for i, lf in enumerate(queries_a):
+                    if counter >= extra:
+                        break
+                    pos = lf[::-1]
+                    if inside(pos) and not mask_a[tuple(np.floor(pos).astype('int'))]:
+                        loc_from.append(np.asarray(lf, dtype=np.float64))
+                        loc_to.append((corr_a[tuple(np.floor(pos).astype('int'))].copy() * 0.5 + 0.5) * size_b)
+                        ident.append(i)
+                        counter += 1
+        n = len(loc_from)
+        return (np.array(loc_from, dtype=np.float64).reshape(n, 2), np.array(loc_to, dtype=np.float64).reshape(n, 2),
+                np.array(ident, dtype=np.int64), area_a, area_b)
+
     def cotr_corr_multiscale(self, img_a, img_b, zoom_ins=(1.0,), converge_iters=1, max_corrs=1000, queries_a=None,
                              return_idx=False, force=False, areas=None, init_b=None):
-        """``SparseEngine.cotr_corr_multiscale`` for tasks with known scale: ``queries_a`` [N,2] pixel positions in
-        img_a, ``areas`` = (area_a, area_b) as the reference requires for this path (:108-114), initial estimates
-        ``init_b`` [N,2] in img_b (default: ``corr_base``, as the reference does).  Returns [M,4]
-        (x_a, y_a, x_b, y_b), at most max_corrs rows, in task order."""
-        if queries_a is None or areas is None:
-            raise NotImplementedError('ZoomEngine batches the refinement of tasks with known scale (queries_a + areas, '
-                                      'sparse_engine.py:100-114); the dense initial pass (cotr_flow) is not part of it yet')
-        if init_b is None:                                         # gen_tasks_w_known_scale :100-106
-            base = self.corr_base(img_a, img_b, queries_a)
-            queries_a, init_b = base[:, :2], base[:, 2:]
-        res = self.refine(img_a, img_b, queries_a, init_b, areas[0], areas[1], zoom_ins, converge_iters, force)
-        corrs = np.concatenate([res.loc_from, res.loc_to], axis=1)
-        idx = np.arange(corrs.shape[0])
-        keep = res.good.copy()
-        if not force:                                              # conclude_tasks border mask :75-80
+        """``SparseEngine.cotr_corr_multiscale`` (sparse_engine.py:197-233), same arguments and result ([M,4] rows
+        (x_a, y_a, x_b, y_b), at most max_corrs, in task order; with return_idx also the task identifiers).
+        ``init_b`` (extra): initial estimates for the known-scale path instead of running ``corr_base``."""
+        img_a, img_b = np.ascontiguousarray(img_a), np.ascontiguousarray(img_b)
+        if areas is not None:                                      # gen_tasks_w_known_scale :100-114
+            assert queries_a is not None and max_corrs >= len(queries_a)   # the reference also insists on force=True
+            if init_b is None:
+                base = self.corr_base(img_a, img_b, queries_a)
+                loc_from, loc_to = base[:, :2], base[:, 2:]
+            else:
+                loc_from, loc_to = np.asarray(queries_a, dtype=np.float64), np.asarray(init_b, dtype=np.float64)
+            ident = np.full(len(loc_from), -1, dtype=np.int64)     # the reference leaves identifier = None here
+            area_a, area_b = areas
+        else:
+            loc_from, loc_to, ident, area_a, area_b = self.gen_tasks(img_a, img_b, max_corrs, queries_a, force)
+        n = len(loc_from)
+        # The reference refines tasks in groups of batch_size in list order and stops as soon as max_corrs of them are
+        # "good" (:208-218).  Same outcome here, but a chunk of max_pairs tasks at a time and one launch per level.
+        chunk = max(self.batch_size, (self.max_pairs // self.batch_size) * self.batch_size)
+        final = np.zeros((n, 2))
+        good = np.zeros(n, dtype=bool)
+        steps = np.zeros(n, dtype=np.int64)
+        done = 0
+        finished = np.zeros(0, dtype=bool)
+        while True:
+            sched = _reference_schedule(steps[:done], good[:done], self.batch_size, max_corrs, n)
+            if sched is not None:
+                finished = sched
+                break
+            hi = min(n, done + chunk)
+            res = self.refine(img_a, img_b, loc_from[done:hi], loc_to[done:hi], area_a, area_b, zoom_ins, converge_iters, False)
+            final[done:hi], good[done:hi], steps[done:hi] = res.loc_to, res.good, res.steps
+            done = hi
+        keep = np.zeros(n, dtype=bool)
+        keep[:done] = finished if force else (finished & good[:done])  # status == 'finished' and conclude(force) :67-72
+        corrs = np.concatenate([loc_from, final], axis=1)
+        if not force:                                                  # conclude_tasks border mask :75-80
             lim = np.concatenate([np.array(img_a.shape[:2])[::-1], np.array(img_b.shape[:2])[::-1]])
             keep &= (corrs < lim).all(axis=1) & (corrs > 0).all(axis=1)
-        corrs, idx = corrs[keep][:max_corrs], idx[keep][:max_corrs]
+        corrs, idx = corrs[keep][:max_corrs], ident[keep][:max_corrs]
         return (corrs, idx) if return_idx else corrs
+
+    def cotr_corr_multiscale_with_cycle_consistency(self, img_a, img_b, zoom_ins=(1.0,), converge_iters=1, max_corrs=1000,
+                                                    queries_a=None, return_idx=False, return_cycle_error=False):
+        """``SparseEngine.cotr_corr_multiscale_with_cycle_consistency`` (sparse_engine.py:235-264): a -> b with
+        max_corrs/0.3 candidates, b -> a seeded with the answers, keep the max_corrs with the smallest cycle error."""
+        temp_max_corrs = int(max_corrs / 0.3)
+        if queries_a is not None:
+            temp_max_corrs = min(temp_max_corrs, queries_a.shape[0])
+            queries_a = queries_a.copy()
+        corr_f, idx_f = self.cotr_corr_multiscale(img_a.copy(), img_b.copy(), zoom_ins, converge_iters, temp_max_corrs,
+                                                  queries_a, return_idx=True)
+        assert corr_f.shape[0] > 0
+        corr_b, idx_b = self.cotr_corr_multiscale(img_b.copy(), img_a.copy(), zoom_ins, converge_iters, corr_f.shape[0],
+                                                  corr_f[:, 2:].copy(), return_idx=True)
+        assert corr_b.shape[0] > 0
+        cycle_errors = np.linalg.norm(corr_f[idx_b][:, :2] - corr_b[:, 2:], axis=1)
+        order = np.argsort(cycle_errors)
+        out = [corr_f[idx_b][order][:max_corrs]]
+        if return_idx:
+            out.append(idx_f[idx_b][order][:max_corrs])
+        if return_cycle_error:
+            out.append(cycle_errors[order][:max_corrs])
+        return out[0] if len(out) == 1 else out

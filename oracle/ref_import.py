@@ -84,6 +84,16 @@ def _install_stubs():
                 mod = types.ModuleType(name)
                 if name == 'cv2':
                     mod.INTER_LINEAR = 1
+
+                    def getAffineTransform(src, dst):
+                        """2x3 affine map through 3 point pairs (what cv2.getAffineTransform solves), float64;
+                        the reference needs it at COTR/inference/inference_helper.py:155-156."""
+                        src = np.asarray(src, dtype=np.float64)
+                        dst = np.asarray(dst, dtype=np.float64)
+                        a = np.concatenate([src, np.ones((3, 1))], axis=1)
+                        return np.linalg.solve(a, dst).T
+
+                    mod.getAffineTransform = getAffineTransform
                 sys.modules[name] = mod
     if not hasattr(np, 'int'):
         np.int = int  # removed in numpy 2.x; used at COTR/inference/sparse_engine.py:171

@@ -1,8 +1,16 @@
 """Deterministic stand-ins used to pin the engine's STATE MACHINE (not the network): a synthetic image pair and a
 fake 'model' whose answer is a smooth per-sample function of the crop and the query, evaluated sample by sample in
 float64 numpy so it does not depend on how crops are batched.  Test infrastructure."""
+import hashlib
+
 import numpy as np
 import torch
+
+
+def digest(arr):
+    """sha256 of an array's dtype, shape and bytes: bit-exact comparison of whole maps without storing them."""
+    a = np.ascontiguousarray(arr)
+    return hashlib.sha256(str((a.dtype.str, a.shape)).encode() + a.tobytes()).digest()
 
 
 def synthetic_pair(seed=0, shape_a=(300, 420), shape_b=(350, 330)):
@@ -61,3 +69,25 @@ def pil_cropper_factory(img_a, img_b, device):
             out[i] = ((t - mean) / std).to(out.device)
         return out[:len(boxes)]
     return crop
+
+
+class CyclicFakeModel(FakeModel):
+    """Approximately cycle-consistent stand-in (left-half queries land in the right half and vice versa, with a small
+    smooth, image-dependent displacement), so that the reference's dense pass (cotr_flow) yields confident pixels."""
+
+    def forward(self, img, queries):
+        self.calls.append((tuple(img.shape), tuple(queries.shape)))
+        im = img.detach().cpu().numpy().astype(np.float64)
+        qs = queries.detach().cpu().numpy().astype(np.float64)
+        out = np.zeros(qs.shape, dtype=np.float32)
+        for b in range(im.shape[0]):
+            right, left = im[b, :, :, 256:], im[b, :, :, :256]
+            c = float(np.tanh(np.mean(right * self.ramp_x) - np.mean(left * self.ramp_x)))
+            x, y = qs[b, :, 0], qs[b, :, 1]
+            is_left = x < 0.5
+            xl = np.where(is_left, x, x - 0.5)                      # position inside the own half
+            dx = 0.01 * np.sin(2 * np.pi * y + c)
+            dy = 0.01 * np.sin(4 * np.pi * xl + c)
+            out[b, :, 0] = np.where(is_left, x + 0.5 + dx, x - 0.5 - dx)
+            out[b, :, 1] = np.where(is_left, y + dy, y - dy)
+        return {'pred_corrs': torch.from_numpy(out).to(img.device)}

@@ -17,13 +17,57 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import ref_import  # noqa: E402
-from tests.engine_fixtures import FakeModel, synthetic_pair  # noqa: E402
+from tests.engine_fixtures import CyclicFakeModel, FakeModel, digest, synthetic_pair  # noqa: E402
 
 CASES = {                      # name: (seed, n_queries, converge_iters, force)
     'engine_c1_force': (0, 24, 1, True),
     'engine_c3_force': (1, 24, 3, True),
     'engine_c3_filter': (2, 40, 3, False),
 }
+
+
+# default path (dense initial pass, sparse_engine.py:116-195): name: (seed, max_corrs, converge_iters, queries, force, cycle)
+DENSE_CASES = {
+    'engine_dense_default': (3, 40, 1, None, False, False),        # 80 tasks, stops early once 40 are good
+    'engine_dense_default_c3': (4, 25, 3, None, False, False),     # tasks need 4..6 steps: groups of 32 interleave
+    'engine_dense_queries_filter': (5, 30, 2, 50, False, False),
+    'engine_dense_queries_force': (6, 30, 1, 30, True, False),
+    'engine_cycle_default': (7, 15, 1, None, False, True),
+    'engine_cycle_queries': (8, 12, 2, 60, False, True),
+}
+
+
+def dense_goldens(SparseEngine, cotr_flow, zoom_ins):
+    for name, (seed, max_corrs, conv, nq, force, cycle) in DENSE_CASES.items():
+        img_a, img_b = synthetic_pair(seed)
+        rng = np.random.default_rng(seed + 100)
+        queries = None
+        if nq is not None:    # some outside the image on purpose (skipped by the reference unless force)
+            queries = np.stack([rng.uniform(-8, img_a.shape[1] + 8, nq), rng.uniform(-8, img_a.shape[0] + 8, nq)], 1)
+        model = CyclicFakeModel()
+        out = {}
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            flow = cotr_flow(model, img_a, img_b)
+            engine = SparseEngine(model, 32, mode='tile')
+            np.random.seed(seed)
+            if cycle:
+                corrs, idx, err = engine.cotr_corr_multiscale_with_cycle_consistency(
+                    img_a, img_b, zoom_ins, conv, max_corrs=max_corrs, queries_a=queries, return_idx=True,
+                    return_cycle_error=True)
+                out['cycle_error'] = err
+            else:
+                corrs, idx = engine.cotr_corr_multiscale(img_a, img_b, zoom_ins, conv, max_corrs=max_corrs,
+                                                         queries_a=queries, return_idx=True, force=force)
+        idx = np.array([-1 if i is None else i for i in idx], dtype=np.int64)
+        for k, v in zip(('corr_a', 'con_a', 'resample_a', 'corr_b', 'con_b', 'resample_b'), flow):
+            out['flow_' + k] = np.ascontiguousarray(v[::9, ::9])             # a sample for diagnostics ...
+            out['sha_' + k] = np.frombuffer(digest(v), dtype=np.uint8)       # ... and a digest of the whole map
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), corrs=corrs, idx=idx,
+                            queries=np.zeros((0, 2)) if queries is None else queries,
+                            meta=np.array([seed, max_corrs, conv, -1 if nq is None else nq, int(force), int(cycle)]),
+                            total_tasks=np.array(engine.total_tasks), **out)
+        print(name, 'kept', len(corrs), 'crops', engine.total_tasks, 'confident a/b',
+              float((flow[1] < 0.02).mean()), float((flow[4] < 0.02).mean()))
 
 
 def main():
@@ -33,10 +77,14 @@ def main():
     os.chdir(ref_import.REFERENCE_ROOT)                  # COTR/global_configs asserts ./out and ./tb_out exist
     try:
         from COTR.inference.sparse_engine import SparseEngine
-        from COTR.inference.inference_helper import cotr_corr_base
+        from COTR.inference.inference_helper import cotr_corr_base, cotr_flow
     finally:
         os.chdir(cwd)
     zoom_ins = np.linspace(0.5, 0.0625, 4)               # demo_single_pair.py:37
+    if '--sparse-only' not in sys.argv:
+        dense_goldens(SparseEngine, cotr_flow, zoom_ins)
+    if '--dense-only' in sys.argv:
+        return
     for name, (seed, n, conv, force) in CASES.items():
         img_a, img_b = synthetic_pair(seed)
         rng = np.random.default_rng(seed + 100)

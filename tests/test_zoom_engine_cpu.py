@@ -63,3 +63,77 @@ def test_corr_base_matches_reference(name, golden_dir):
     img_a, img_b = synthetic_pair(int(g['meta'][0]))
     eng = ZoomEngine(FakeModel(), make_cropper=pil_cropper_factory)
     assert np.array_equal(eng.corr_base(img_a, img_b, g['queries']), g['init'])
+
+
+# ---- default path: dense initial pass + task generation + early exit + cycle-consistency wrapper ---------------------
+DENSE_CASES = ['engine_dense_default', 'engine_dense_default_c3', 'engine_dense_queries_filter',
+               'engine_dense_queries_force', 'engine_cycle_default', 'engine_cycle_queries']
+FLOW_KEYS = ('corr_a', 'con_a', 'resample_a', 'corr_b', 'con_b', 'resample_b')
+
+
+def run_dense_case(g, eng):
+    seed, max_corrs, conv, nq, force, cycle = (int(v) for v in g['meta'])
+    img_a, img_b = synthetic_pair(seed)
+    queries = None if nq < 0 else g['queries']
+    np.random.seed(seed)                                 # gen_tasks draws from numpy's global RNG like the reference
+    if cycle:
+        return eng.cotr_corr_multiscale_with_cycle_consistency(img_a, img_b, ZOOMS, conv, max_corrs=max_corrs,
+                                                               queries_a=queries, return_idx=True, return_cycle_error=True)
+    return eng.cotr_corr_multiscale(img_a, img_b, ZOOMS, conv, max_corrs=max_corrs, queries_a=queries, return_idx=True,
+                                    force=bool(force))
+
+
+@pytest.mark.parametrize('name', DENSE_CASES[:2])
+def test_flow_matches_reference_cotr_flow(name, golden_dir):
+    """ZoomEngine.flow vs cotr_flow (inference_helper.py:104-182) of the reference: whole maps by digest."""
+    from tests.engine_fixtures import CyclicFakeModel, digest
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    img_a, img_b = synthetic_pair(int(g['meta'][0]))
+    model = CyclicFakeModel()
+    out = ZoomEngine(model, make_cropper=pil_cropper_factory).flow(img_a, img_b)
+    for k, v in zip(FLOW_KEYS, out):
+        assert np.array_equal(v[::9, ::9], g['flow_' + k]), k
+        assert digest(v) == g['sha_' + k].tobytes(), k
+    assert model.calls == [((4, 3, 256, 512), (4, 131072, 2))]     # all four patch pairs in ONE model call
+
+
+@pytest.mark.parametrize('name', DENSE_CASES)
+@pytest.mark.parametrize('max_pairs', [256, 40])
+def test_default_path_matches_reference_engine(name, max_pairs, golden_dir):
+    """cotr_corr_multiscale / ..._with_cycle_consistency without ``areas``: same correspondences, in the same order,
+    as SparseEngine(model, 32, 'tile') - including where its group-of-32 loop stops (sparse_engine.py:208-218)."""
+    from tests.engine_fixtures import CyclicFakeModel
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    eng = ZoomEngine(CyclicFakeModel(), max_pairs=max_pairs, make_cropper=pil_cropper_factory)
+    out = run_dense_case(g, eng)
+    assert np.array_equal(out[0], g['corrs'])
+    assert np.array_equal(out[1], g['idx'])
+    if len(out) == 3:
+        assert np.array_equal(out[2], g['cycle_error'])
+
+
+def test_reference_schedule_emulation():
+    """_reference_schedule against a literal simulation of the reference loop."""
+    from cotr_amd.inference.zoom_engine import _reference_schedule
+    rng = np.random.default_rng(0)
+    for trial in range(50):
+        n = int(rng.integers(0, 200))
+        steps = rng.integers(1, 5, n)
+        good = rng.random(n) < 0.6
+        max_corrs = int(rng.integers(1, 80))
+        status = np.zeros(n, dtype=np.int64)             # literal version: per-task counters, list order
+        while True:
+            num_g = int((good & (status == steps)).sum())
+            batch = [i for i in range(n) if status[i] < steps[i]][:32]
+            if not batch or num_g >= max_corrs:
+                break
+            for i in batch:
+                status[i] += 1
+        want = status == steps
+        assert np.array_equal(_reference_schedule(steps, good, 32, max_corrs, n), want)
+        # with only a prefix known it either asks for more or gives the prefix of the full answer
+        for known in range(0, n, 37):
+            got = _reference_schedule(steps[:known], good[:known], 32, max_corrs, n)
+            assert got is None or np.array_equal(got, want[:known])

@@ -39,3 +39,27 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t
 print(f'reference loop shape (32 per call, PIL crops on the host, same HIP model): {n_ref} queries in {dt:.3f} s = '
       f'{n_ref / dt:.0f} correspondences/s', flush=True)
+# dense initial pass (cotr_flow): 4 patch pairs x 131072 queries in one model call + host post-processing
+eng = ZoomEngine(m)
+eng.flow(img_a[:300, :420], img_b[:350, :330])                   # warm-up (also the big-Q decode scratch)
+for tag, (ia, ib) in (('2x2 patch pairs (cathedral sizes)', (img_a, img_b)),):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    out = eng.flow(ia, ib)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    pa, pb = eng._square_patches(ia), eng._square_patches(ib)
+    boxes = np.array([[i[0], i[1], i[2], j[0], j[1], j[2]] for i in pa for j in pb], dtype=np.int32)
+    crop = eng.make_cropper(ia, ib, torch.device('cuda'))
+    buf = torch.empty((len(boxes), 3, 256, 512), device='cuda')
+    q = torch.rand(len(boxes), 131072, 2, device='cuda')
+    imgs = crop(boxes, buf)
+    m(imgs, q)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    m(imgs, q)
+    torch.cuda.synchronize()
+    dm = time.perf_counter() - t
+    print(f'dense pass, {tag}: {dt:.3f} s total, of which the model call ({len(boxes)} x 131072 queries) {dm:.3f} s = '
+          f'{len(boxes) * 131072 / dm:.0f} query-corr/s; the rest is the reference\'s host post-processing '
+          f'(grid_sample, PIL float resize, merge)', flush=True)
