@@ -48,6 +48,9 @@ _PROTOS = {
     'cotr_op_posenc': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_crop_resize_pairs': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
                                               c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_dense_cycle': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_void_p]),
+    'cotr_dense_merge': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        c_float_p, c_float_p, ctypes.c_void_p]),
     'cotr_set_encode_chunk': (ctypes.c_int, [ctypes.c_int]),
     'cotr_gemm_num_configs': (ctypes.c_int, []),
     'cotr_set_ffn_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),

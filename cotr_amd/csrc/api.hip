@@ -949,6 +949,19 @@ int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* 
   return op_ret(launch_crop_resize(img_a, ha, wa, img_b, hb, wb, boxes, n, out, max_size, static_cast<hipStream_t>(stream)));
 }
 
+int cotr_dense_cycle(const float* pred, int n_pairs, const double* affine, float* maps, cotr_stream stream) {
+  if (n_pairs < 0 || (n_pairs > 0 && (!pred || !affine || !maps))) return COTR_ERR_ARG;
+  return op_ret(launch_dense_cycle(pred, affine, maps, n_pairs, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_dense_merge(const float* maps, const int32_t* boxes, int n_pairs, int side, int H, int W, float* flow,
+                     float* conf, cotr_stream stream) {
+  if (n_pairs <= 0 || !maps || !boxes || !flow || !conf || (side != 0 && side != 1) || H <= 0 || W <= 0 ||
+      (int64_t)H * W > (int64_t)1 << 30)
+    return COTR_ERR_ARG;
+  return op_ret(launch_dense_merge(maps, boxes, n_pairs, side, H, W, flow, conf, static_cast<hipStream_t>(stream)));
+}
+
 // fused FFN block: y = LayerNorm(x + linear2(relu(linear1(x)))) in two launches; scratch >= ffn chunks * M * 256 floats
 int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
                       const float* ln_b, float* scratch, float* y, int M, cotr_stream stream) {

@@ -71,6 +71,11 @@ int launch_head2(const float* x, const float* w, const float* b, float* y, int n
 int launch_crop_resize(const uint8_t* img_a, int ha, int wa, const uint8_t* img_b, int hb, int wb,
                        const int32_t* boxes, int n, float* out, int max_size, hipStream_t s);
 
+// dense-pass post-processing (dense_post.hip): cycle error + affine, then Pillow float resize + merge per image
+int launch_dense_cycle(const float* pred, const double* aff, float* maps, int n_pairs, hipStream_t s);
+int launch_dense_merge(const float* maps, const int32_t* boxes, int n_pairs, int side, int H, int W, float* flow,
+                       float* conf, hipStream_t s);
+
 // fused feed-forward block (ffn.hip) and its reduce + bias + residual + LayerNorm tail (pointwise.hip)
 int ffn_fused_chunks(int M);
 int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch, hipStream_t s);

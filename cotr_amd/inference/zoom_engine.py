@@ -38,30 +38,55 @@ def _affine_from_3pts(src, dst):
     return np.linalg.solve(a, np.asarray(dst, dtype=np.float64)).T
 
 
-def _float_image_resize(img, shape):
-    """``utils.float_image_resize`` (COTR/utils/utils.py:69-83): per-channel Pillow mode-'F' bilinear resize."""
-    import PIL.Image
-    layers = [np.array(PIL.Image.fromarray(l).resize(shape[::-1], resample=PIL.Image.BILINEAR)) for l in img.transpose(2, 0, 1)]
-    return np.stack(layers, axis=-1)
+def _patch_affines(p_i, p_j, shape_a, shape_b):
+    """(T_i, T_j) of inference_helper.py:151-156: network frame [-1,1]^2 -> normalised image frame of the patch in
+    image b (for the left half's answers) and in image a (for the right half's)."""
+    base = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]])
+
+    def corners(p, shape):
+        x, y, s = p
+        return (np.array([[x, y], [x + s, y], [x + s, y + s], [x, y + s]]) / np.array([shape[1], shape[0]])) * 2 + np.array([-1, -1])
+    real_j, real_i = corners(p_j, shape_b), corners(p_i, shape_a)
+    return (_affine_from_3pts(base[:3].astype(np.float32), real_j[:3].astype(np.float32)),
+            _affine_from_3pts(base[:3].astype(np.float32), real_i[:3].astype(np.float32)))
 
 
-def _merge_flow_patches(corrs):
-    """``merge_flow_patches`` (inference_helper.py:61-75): per pixel keep the patch with the lowest cycle error.
-    corrs: list of (patch [h,w,3], x, y, w, h, ow, oh)."""
-    oh, ow = corrs[0][6], corrs[0][5]
-    confidence = np.ones([oh, ow]) * 100
-    flow = np.zeros([oh, ow, 2])
-    cmap = np.ones([oh, ow]) * -1
-    for i, (patch, x, y, w, h, _ow, _oh) in enumerate(corrs):
-        temp = np.ones([oh, ow]) * 100
-        temp[y:y + h, x:x + w] = patch[..., 2]
-        tempf = np.zeros([oh, ow, 2])
-        tempf[y:y + h, x:x + w] = patch[..., :2]
-        min_ind = np.stack([temp, confidence], axis=-1).argmin(axis=-1) == 0
-        confidence[min_ind] = temp[min_ind]
-        flow[min_ind] = tempf[min_ind]
-        cmap[min_ind] = i
-    return flow, confidence, cmap
+class _DeviceDensePost:
+    """Dense-pass post-processing on the GPU: cotr_dense_cycle (1 launch) + cotr_dense_merge (1 launch per image);
+    only the merged maps come back to the host."""
+
+    def __init__(self, device):
+        from .. import _lib
+        self._lib = _lib
+        self.lib = _lib.load_library()
+        self.device = device
+
+    def __call__(self, pred, pairs, shape_a, shape_b):
+        lib, dev = self.lib, self.device
+        n = len(pairs)
+        pred = pred.detach().to(dev, torch.float32).contiguous()
+        assert pred.shape == (n, MAX_SIZE, MAX_SIZE * 2, 2) or pred.shape == (n, MAX_SIZE * MAX_SIZE * 2, 2)
+        aff = np.stack([np.stack(_patch_affines(p_i, p_j, shape_a, shape_b)) for p_i, p_j in pairs])     # [n,2,2,3] f64
+        aff_d = torch.from_numpy(np.ascontiguousarray(aff)).to(dev)
+        maps = torch.empty((n, MAX_SIZE, MAX_SIZE * 2, 3), dtype=torch.float32, device=dev)
+        out = []
+        with torch.cuda.device(dev):
+            stream = self._lib.current_stream_ptr()
+            rc = lib.cotr_dense_cycle(pred.data_ptr(), n, aff_d.data_ptr(), maps.data_ptr(), stream)
+            if rc != 0:
+                raise self._lib.CotrHipError(f'cotr_dense_cycle failed (code {rc})')
+            for side, shape in ((0, shape_a), (1, shape_b)):
+                boxes = torch.tensor([list(p[side]) for p in pairs], dtype=torch.int32).to(dev)
+                flow = torch.empty((shape[0], shape[1], 2), dtype=torch.float32, device=dev)
+                conf = torch.empty((shape[0], shape[1]), dtype=torch.float32, device=dev)
+                rc = lib.cotr_dense_merge(maps.data_ptr(), boxes.data_ptr(), n, side, shape[0], shape[1], flow.data_ptr(),
+                                          conf.data_ptr(), stream)
+                if rc != 0:
+                    raise self._lib.CotrHipError(f'cotr_dense_merge failed (code {rc})')
+                out += [flow, conf]
+        # the reference's maps are float64 numpy arrays holding float32 values
+        return tuple(t.cpu().numpy().astype(np.float64) for t in out)
+
 
 RefineResult = namedtuple('RefineResult', ['loc_from', 'loc_to', 'good', 'loc_history', 'model_calls', 'crops', 'steps'])
 
@@ -139,15 +164,18 @@ class ZoomEngine:
                 deterministic stand-in).
     max_pairs   crops per model call (the library itself walks them 32 at a time through the backbone).
     make_cropper  factory (img_a, img_b, device) -> callable(boxes, out); default: the HIP kernel.
+    make_dense_post  factory (device) -> callable(pred, pairs, shape_a, shape_b) -> corr_a, con_a, corr_b, con_b;
+                default: the HIP kernels (cotr_dense_cycle / cotr_dense_merge).
     """
 
-    def __init__(self, model, max_pairs=256, make_cropper=None, batch_size=32, mode='tile'):
+    def __init__(self, model, max_pairs=256, make_cropper=None, batch_size=32, mode='tile', make_dense_post=None):
         if mode != 'tile':
             raise NotImplementedError("only SparseEngine's mode='tile' is mirrored (demo_single_pair / guided matching / wbs)")
         self.model = model
         self.batch_size = int(batch_size)   # the reference walks tasks in groups of this size: decides where it stops
         self.max_pairs = int(max_pairs)
         self.make_cropper = make_cropper or _DeviceCropper
+        self.make_dense_post = make_dense_post or _DeviceDensePost
         self.total_tasks = 0       # same bookkeeping as SparseEngine.total_tasks: crops pushed through the model
 
     # ------------------------------------------------------------------------------------------------
@@ -296,13 +324,14 @@ class ZoomEngine:
         return np.concatenate([queries_a, best], axis=1)
 
     # ------------------------------------------------------------------------------------------------
-    def flow(self, img_a, img_b):
+    def flow(self, img_a, img_b, resample=True):
         """``cotr_flow`` (inference_helper.py:168-182): the dense initial pass.  Every pair of square patches of the two
-        images gets ONE forward with the 256x512 grid of queries (131072, both halves; :116-127), the self-composition
-        of the answer gives a per-pixel cycle error (:137-145), maps are moved to image coordinates, resized to the patch
-        and merged by lowest cycle error.  All patch pairs are cropped in one launch and go through the model as one
-        batch.  -> corr_a, con_a, resample_a, corr_b, con_b, resample_b (as the reference)."""
-        import torch.nn.functional as F
+        images gets ONE forward with the 256x512 grid of queries (131072, both halves; :116-127); the self-composition
+        of the answer gives a per-pixel cycle error (:137-145); the maps are moved to image coordinates, resized to the
+        patch and merged by lowest cycle error.  All patch pairs are cropped in one launch, go through the model as
+        one batch, and the post-processing stays on the device (2 + 1 launches; only the merged maps come back).
+        -> corr_a, con_a, resample_a, corr_b, con_b, resample_b like the reference (resample_* = the other image
+        warped by the flow, a visualisation aid: None with resample=False)."""
         img_a = np.ascontiguousarray(img_a)
         img_b = np.ascontiguousarray(img_b)
         pa, pb = self._square_patches(img_a), self._square_patches(img_b)
@@ -315,47 +344,24 @@ class ZoomEngine:
         jj, ii = np.meshgrid(np.arange(MAX_SIZE * 2), np.arange(MAX_SIZE))
         q_grid = np.stack([jj / (MAX_SIZE * 2), ii / MAX_SIZE], axis=-1)               # [256,512,2] float64
         q = torch.from_numpy(q_grid.reshape(1, -1, 2)).float().to(device).expand(len(pairs), -1, -1).contiguous()
-        out_all = self.model(img, q)['pred_corrs'].detach().cpu().numpy()
+        pred = self.model(img, q)['pred_corrs']
         self.total_tasks += len(pairs)
-        (ha, wa), (hb, wb) = img_a.shape[:2], img_b.shape[:2]
-        base = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]])
-        corrs_a, corrs_b = [], []
-        for k, (pi, pj) in enumerate(pairs):
-            out_list = out_all[k].reshape(MAX_SIZE, MAX_SIZE * 2, -1)
-            in_grid = torch.from_numpy(q_grid).float()[None] * 2 - 1
-            out_grid = torch.from_numpy(out_list).float()[None] * 2 - 1
-            cycle_grid = F.grid_sample(out_grid.permute(0, 3, 1, 2), out_grid, align_corners=False).permute(0, 2, 3, 1)
-            confidence = torch.norm(cycle_grid[0, ...] - in_grid[0, ...], dim=-1)
-            corr = out_grid[0].clone()
-            corr[:, :MAX_SIZE, 0] = corr[:, :MAX_SIZE, 0] * 2 - 1
-            corr[:, MAX_SIZE:, 0] = corr[:, MAX_SIZE:, 0] * 2 + 1
-            corr = torch.cat([corr, confidence[..., None]], dim=-1).numpy()
-            c_i, c_j = corr[:, :MAX_SIZE, :], corr[:, MAX_SIZE:, :]
-
-            def corners(px, py, ps, ow, oh):
-                return (np.array([[px, py], [px + ps, py], [px + ps, py + ps], [px, py + ps]]) / np.array([ow, oh])) * 2 + \
-                    np.array([-1, -1])
-            real_j, real_i = corners(pj[0], pj[1], pj[2], wb, hb), corners(pi[0], pi[1], pi[2], wa, ha)
-            t_i = _affine_from_3pts(base[:3].astype(np.float32), real_j[:3].astype(np.float32))
-            t_j = _affine_from_3pts(base[:3].astype(np.float32), real_i[:3].astype(np.float32))
-            c_i[..., :2] = c_i[..., :2] @ t_i[:2, :2] + t_i[:, 2]
-            c_j[..., :2] = c_j[..., :2] @ t_j[:2, :2] + t_j[:, 2]
-            corrs_a.append((_float_image_resize(c_i, (pi[2], pi[2])), pi[0], pi[1], pi[2], pi[2], wa, ha))
-            corrs_b.append((_float_image_resize(c_j, (pj[2], pj[2])), pj[0], pj[1], pj[2], pj[2], wb, hb))
-        corr_a, con_a, _ = _merge_flow_patches(corrs_a)
-        corr_b, con_b, _ = _merge_flow_patches(corrs_b)
-
-        def resample(img_src, corr):
-            t = torch.from_numpy(np.transpose(img_src, (2, 0, 1)))[None].float()
-            r = F.grid_sample(t, torch.from_numpy(corr)[None].float(), align_corners=False)[0]
-            return np.transpose(r.numpy(), (1, 2, 0))
-        return corr_a, con_a, resample(img_b, corr_a), corr_b, con_b, resample(img_a, corr_b)
+        corr_a, con_a, corr_b, con_b = self.make_dense_post(device)(pred, pairs, img_a.shape, img_b.shape)
+        res_a = res_b = None
+        if resample:                                                                    # :178-181
+            def warp(img_src, corr):
+                t = torch.from_numpy(np.transpose(img_src, (2, 0, 1)))[None].float().to(device)
+                g = torch.from_numpy(corr)[None].float().to(device)
+                r = torch.nn.functional.grid_sample(t, g, align_corners=False)[0]
+                return np.transpose(r.cpu().numpy(), (1, 2, 0))
+            res_a, res_b = warp(img_b, corr_a), warp(img_a, corr_b)
+        return corr_a, con_a, res_a, corr_b, con_b, res_b
 
     def gen_tasks(self, img_a, img_b, max_corrs, queries_a, force):
         """``SparseEngine.gen_tasks`` without ``areas`` (sparse_engine.py:108-195, mode 'tile'): dense pass, confident
         pixels, relative scale from the confident areas.  -> loc_from [N,2], loc_to [N,2], identifier [N] (-1 = None),
         area_a, area_b.  Uses numpy's global RNG exactly where the reference does (np.random.choice, :151,154)."""
-        corr_a, con_a, _, corr_b, con_b, _ = self.flow(img_a, img_b)
+        corr_a, con_a, _, corr_b, con_b, _ = self.flow(img_a, img_b, resample=False)
         mask_a, mask_b = con_a < THRESHOLD_SPARSE, con_b < THRESHOLD_SPARSE
         area_a = (con_a < THRESHOLD_AREA).sum() / mask_a.size
         area_b = (con_b < THRESHOLD_AREA).sum() / mask_b.size

@@ -141,6 +141,21 @@ int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
 int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* img_b, int hb, int wb,
                            const int32_t* boxes, int n, float* out, int max_size, cotr_stream stream);
 
+/* ---- dense initial pass: post-processing on the device ---------------------------------------
+ * Replaces the host round trip of COTR/inference/inference_helper.py:137-160 (cotr_patch_flow_exhaustive.one_pass
+ * tail) and :61-75 (merge_flow_patches) + COTR/utils/utils.py:69-83 (float_image_resize).
+ *
+ * cotr_dense_cycle: pred [n_pairs,256,512,2] = the network's answer for the query grid (j/512, i/256) ->
+ *   maps [n_pairs,256,512,3] = (x, y, cycle error): self-composition through bilinear grid_sample (zeros padding,
+ *   align_corners=False), x re-centred per half (:140-142), then the 2x3 affine of that half applied in double
+ *   (:157-158).  affine [n_pairs][2][6] doubles (device): [p][0] left half -> image b, [p][1] right half -> image a.
+ * cotr_dense_merge: for one image (side 0 = a / left halves, 1 = b / right halves) resize each entry's 256x256x3
+ *   half to its patch boxes[p] = (x, y, size) with Pillow's mode-'F' BILINEAR (bit-exact) and keep per pixel the
+ *   entry with the lowest cycle error, later entries winning ties -> flow [H,W,2], conf [H,W] (100 where uncovered). */
+int cotr_dense_cycle(const float* pred, int n_pairs, const double* affine, float* maps, cotr_stream stream);
+int cotr_dense_merge(const float* maps, const int32_t* boxes, int n_pairs, int side, int H, int W, float* flow,
+                     float* conf, cotr_stream stream);
+
 /* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
 int cotr_gemm_num_configs(void);
 /* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB

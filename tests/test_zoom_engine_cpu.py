@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from cotr_amd.inference import ZoomEngine, patch_boxes
+from oracle.dense_post import host_dense_post_factory
 from tests.engine_fixtures import FakeModel, synthetic_pair, pil_cropper_factory
 
 CASES = ['engine_c1_force', 'engine_c3_force', 'engine_c3_filter']
@@ -85,13 +86,14 @@ def run_dense_case(g, eng):
 
 @pytest.mark.parametrize('name', DENSE_CASES[:2])
 def test_flow_matches_reference_cotr_flow(name, golden_dir):
-    """ZoomEngine.flow vs cotr_flow (inference_helper.py:104-182) of the reference: whole maps by digest."""
+    """ZoomEngine.flow (engine plumbing) + oracle/dense_post.py (the host restatement of the post-processing) vs
+    cotr_flow (inference_helper.py:104-182) of the reference: whole maps by digest."""
     from tests.engine_fixtures import CyclicFakeModel, digest
     torch.set_num_threads(1)
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     img_a, img_b = synthetic_pair(int(g['meta'][0]))
     model = CyclicFakeModel()
-    out = ZoomEngine(model, make_cropper=pil_cropper_factory).flow(img_a, img_b)
+    out = ZoomEngine(model, make_cropper=pil_cropper_factory, make_dense_post=host_dense_post_factory).flow(img_a, img_b)
     for k, v in zip(FLOW_KEYS, out):
         assert np.array_equal(v[::9, ::9], g['flow_' + k]), k
         assert digest(v) == g['sha_' + k].tobytes(), k
@@ -106,7 +108,8 @@ def test_default_path_matches_reference_engine(name, max_pairs, golden_dir):
     from tests.engine_fixtures import CyclicFakeModel
     torch.set_num_threads(1)
     g = np.load(os.path.join(golden_dir, name + '.npz'))
-    eng = ZoomEngine(CyclicFakeModel(), max_pairs=max_pairs, make_cropper=pil_cropper_factory)
+    eng = ZoomEngine(CyclicFakeModel(), max_pairs=max_pairs, make_cropper=pil_cropper_factory,
+                     make_dense_post=host_dense_post_factory)
     out = run_dense_case(g, eng)
     assert np.array_equal(out[0], g['corrs'])
     assert np.array_equal(out[1], g['idx'])

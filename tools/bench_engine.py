@@ -39,7 +39,7 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t
 print(f'reference loop shape (32 per call, PIL crops on the host, same HIP model): {n_ref} queries in {dt:.3f} s = '
       f'{n_ref / dt:.0f} correspondences/s', flush=True)
-# dense initial pass (cotr_flow): 4 patch pairs x 131072 queries in one model call + host post-processing
+# dense initial pass (cotr_flow): 4 patch pairs x 131072 queries in one model call + device post-processing
 eng = ZoomEngine(m)
 eng.flow(img_a[:300, :420], img_b[:350, :330])                   # warm-up (also the big-Q decode scratch)
 for tag, (ia, ib) in (('2x2 patch pairs (cathedral sizes)', (img_a, img_b)),):
@@ -61,5 +61,5 @@ for tag, (ia, ib) in (('2x2 patch pairs (cathedral sizes)', (img_a, img_b)),):
     torch.cuda.synchronize()
     dm = time.perf_counter() - t
     print(f'dense pass, {tag}: {dt:.3f} s total, of which the model call ({len(boxes)} x 131072 queries) {dm:.3f} s = '
-          f'{len(boxes) * 131072 / dm:.0f} query-corr/s; the rest is the reference\'s host post-processing '
-          f'(grid_sample, PIL float resize, merge)', flush=True)
+          f'{len(boxes) * 131072 / dm:.0f} query-corr/s; the rest: crop launch, query grid upload, cotr_dense_cycle + '
+          f'2 x cotr_dense_merge, D2H of the merged maps, the two visualisation warps', flush=True)
