@@ -6,6 +6,11 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LDS-DMA (global_load_lds) data is ordered for OTHER wavefronts' ds_reads only by the issuing wavefront's vmcnt wait
+// followed by a barrier.  The compiler does not always put that wait before s_barrier (it may sink it to the issuing
+// wavefront's own first ds_read, which leaves the other wavefronts' reads unordered): state it explicitly.
+#define LDS_DMA_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 // ---------------------------------------------------------------------------------------------
 // C[M,N] = epilogue( A'[M,K] . W[N,K]^T )
 //   A' row m, column k:
@@ -50,6 +55,7 @@ struct GemmParams {
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s);            // tuned / modelled config
 int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s);  // explicit config (tuning, tests)
 int gemm_pick_config(int mode, const GemmParams& p);
+int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s);  // gemm_big.hip: 0 = 128x128, 1 = 128x64
 int gemm_num_configs();
 bool gemm_cfg_supports_ln(int cfg);
 const float* gemm_zero_buffer();  // per-process device buffer of zeros (LDS-DMA padding source)

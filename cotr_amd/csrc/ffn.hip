@@ -71,7 +71,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   for (int sub = 0; sub < nsub; ++sub) {
     // W2 fragment of this sub-chunk for this wave's 32 output columns: lane (n = l31, half hh) holds
     // W2[32*wave + l31][h0 + sub*64 + j*8 + hh*4 .. +3], j = 0..7
-    __syncthreads();  // X and W1_sub have landed (drains the LDS-DMA), previous phase 2 is done with Hs
+    LDS_DMA_WAIT_ALL();
+    __syncthreads();  // X and W1_sub have landed, previous phase 2 is done with Hs
     f32x4 w2f[8];     // issued after the barrier (which drains vmcnt), in flight under phase 1
     const float* w2g = p.W2 + (size_t)(32 * wave + l31) * FF_H + h0 + sub * 64 + hh * 4;
 #pragma unroll

@@ -442,10 +442,12 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 
   if constexpr (DB == 2) {
     dma_tile(0, 0);
+    LDS_DMA_WAIT_ALL();
     __syncthreads();
     for (int st = 0; st < steps; ++st) {
       if (st + 1 < steps) dma_tile(st + 1, (st + 1) & 1);
       compute(st & 1);
+      LDS_DMA_WAIT_ALL();
       __syncthreads();
     }
   } else if constexpr (DB) {
@@ -543,7 +545,8 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 // (tools/tune_gemm.py -> gemm_tuned.inc) with a heuristic for shapes not in the table.
 // ---------------------------------------------------------------------------------------------
 struct GemmCfg {
-  int kind;  // 0 = spatial (WM=WN=2), 1 = k-split, 2 = k-split with two LDS stages, 3 = k-split LDS-DMA (two stages)
+  int kind;  // 0 = spatial (WM=WN=2), 1 = k-split, 2 = k-split with two LDS stages, 3 = k-split LDS-DMA (two stages),
+             // 4 = large tile, LDS-DMA, swizzled LDS, coalesced epilogue (gemm_big.hip)
   int a, tm, tn;  // spatial: a unused; k-split: a = NWK
 };
 static const GemmCfg kCfgs[] = {
@@ -573,6 +576,8 @@ static const GemmCfg kCfgs[] = {
     {2, 8, 1, 0},   // 23 k-split 8 waves, 32x16, double-buffered
     {3, 8, 1, 0},   // 24 k-split 8 waves, 32x16, LDS-DMA double-buffered
     {1, 4, 1, 0},   // 25 k-split 4 waves, 32x16
+    {4, 0, 2, 2},   // 26 large tile 128x128 (gemm_big.hip)
+    {4, 0, 2, 1},   // 27 large tile 128x64
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -655,6 +660,8 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 23: return launch_ks<8, 1, 0, MODE, 1>(p, s);
     case 24: return launch_ks<8, 1, 0, MODE, 2>(p, s);
     case 25: return launch_ks<4, 1, 0, MODE, 0>(p, s);
+    case 26: return launch_gemm_big(MODE, 0, p, s);
+    case 27: return launch_gemm_big(MODE, 1, p, s);
     default: return -1;
   }
 }
@@ -670,6 +677,11 @@ static const TunedEntry kTuned[] = {
 
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
+  if (c.kind == 4) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
+    if (p.A2 != nullptr || p.ldc % 4 != 0 || ((uintptr_t)p.C & 15)) return false;
+    if (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15))) return false;
+    return p.N % (64 * c.tn) == 0;
+  }
   const int bn = c.tn == 0 ? 16 : (c.kind == 0 ? 2 : 1) * c.tn * 32;
   if (c.kind != 0) {  // dynamic LDS of the k-split kernels must fit the CU's 160 KB
     const size_t rows = (size_t)c.tm * 32 + (c.tn == 0 ? 16 : c.tn * 32);
@@ -683,6 +695,12 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
 
 // rough cost model (cycles) for shapes outside the tuned table
 static double model_cost(const GemmCfg& c, const GemmParams& p) {
+  if (c.kind == 4) {  // pays off once the chip is covered several times over
+    const int bm = 128, bn = 64 * c.tn;
+    const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
+    const double rounds = ceil(wgs / 512.0);
+    return rounds * ((p.K / BK) * (2 * c.tn * 16 * 64.0 * 2 + 150.0) + 3500.0) * (wgs < 1024 ? 4.0 : 1.0);
+  }
   const int waves = c.kind == 0 ? 4 : c.a;
   const int bm = (c.kind == 0 ? 2 : 1) * c.tm * 32, bn = c.tn == 0 ? 16 : (c.kind == 0 ? 2 : 1) * c.tn * 32;
   const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);

@@ -1,0 +1,227 @@
+// Large-tile fp32 MFMA GEMM / implicit-GEMM convolution for the batched regime (many image pairs per call: zoom-in
+// engine at B=32, dense pass, config 3), gfx950.  Same contract and fused epilogue as gemm.hip (GemmParams).
+//
+// Workgroup = 4 wavefronts (2 x 2), tile 128 x (64*TN); a wavefront owns 64 x (32*TN) = 2 x TN MFMA blocks of
+// v_mfma_f32_32x32x2_f32, so every ds_read_b128 fragment feeds 4*TN (A) / 8 (B) MFMAs.
+//
+// Operand path: global -> LDS directly (global_load_lds_dwordx4), two stages, ONE barrier per 32-deep K step; the
+// transfer of step t+1 is in flight under the 16*2*TN MFMAs per wavefront of step t.  One DMA instruction moves
+// 8 rows x 128 B into 1 KB of contiguous LDS (the destination of LDS-DMA is lane-linear), so the tile is stored
+// unpadded [row][32 floats] and the 16-byte chunks of a row are XOR-swizzled with (row >> 1) & 7 by choosing which
+// global chunk each lane fetches: the fragment reads (32 consecutive rows, same logical chunk) then cover all 64
+// banks once per 16 lanes - conflict-free without padding.
+//
+// Epilogue: accumulators go through LDS (wave-private, 32 rows at a time) so that residual reads and output writes
+// are float4 and a wavefront writes 4 x 256 B (TN = 2) contiguous row segments per instruction instead of 64
+// scattered dwords; the K-short, residual-carrying 1x1 expansions of the ResNet bottlenecks are bandwidth-bound on
+// exactly this traffic.
+#include "common.h"
+
+#define BK 32
+
+template <int TN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
+  constexpr int BM = 128, BN = 64 * TN;
+  constexpr int STAGE = (BM + BN) * BK;   // floats per stage
+  constexpr int QW = BN / 32;             // W-tile DMA instructions per wavefront
+  constexpr int EP = 32 * TN + 4;         // padded row of the epilogue staging tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int tiles_n = p.N / BN;
+  const int m0 = (blockIdx.x / tiles_n) * BM;
+  const int n0 = (blockIdx.x % tiles_n) * BN;
+  const int KT = p.K / BK;
+
+  // ---- LDS-DMA bookkeeping: lane -> (row lane>>3 of the instruction's 8 rows, physical 16-B chunk lane&7) ----
+  const int drow = lane >> 3, pch = lane & 7;
+  const float* a_ptr[4];
+  bool a_ok[4];
+  int c_hi0[4], c_wi0[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = wave * 32 + q * 8 + drow;          // tile-local A row
+    const int lch = pch ^ ((row >> 1) & 7);            // logical chunk this lane fetches
+    const int m = m0 + row;
+    a_ok[q] = m < p.M;
+    const int mm = a_ok[q] ? m : 0;
+    if constexpr (MODE == GEMM_DENSE) {
+      a_ptr[q] = p.A + (size_t)mm * p.lda + lch * 4;
+      c_hi0[q] = c_wi0[q] = 0;
+    } else {
+      const int W2o = 2 * p.Wout;
+      const int b = mm / (p.Hout * W2o);
+      const int rem = mm - b * (p.Hout * W2o);
+      const int ho = rem / W2o;
+      const int wo = rem - ho * W2o;
+      const int side = wo / p.Wout;
+      const int wl = wo - side * p.Wout;
+      c_hi0[q] = ho * p.stride - p.pad;
+      c_wi0[q] = wl * p.stride - p.pad;
+      a_ptr[q] = p.A + ((size_t)b * p.Hin * (2 * p.Win) + (size_t)side * p.Win) * p.Cin + lch * 4;
+    }
+  }
+  const float* w_ptr[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    const int row = wave * (BN / 4) + q * 8 + drow;    // tile-local W row
+    const int lch = pch ^ ((row >> 1) & 7);
+    w_ptr[q] = p.W + (size_t)(n0 + row) * p.K + lch * 4;
+  }
+  const int tiles_per_tap = (MODE == GEMM_CONV) ? p.Cin / BK : 1;
+
+  auto dma_tile = [&](int kt, int buf) {
+    float* As = smem + buf * STAGE;
+    float* Ws = As + BM * BK;
+    if constexpr (MODE == GEMM_DENSE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* src = a_ok[q] ? a_ptr[q] + kt * BK : p.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(As + (wave * 32 + q * 8) * BK), 16, 0, 0);
+      }
+    } else {
+      const int tap = kt / tiles_per_tap;
+      const int c0 = (kt - tap * tiles_per_tap) * BK;
+      const int ky = tap / p.ksize;
+      const int kx = tap - ky * p.ksize;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int hi = c_hi0[q] + ky, wi = c_wi0[q] + kx;
+        const bool ok = a_ok[q] && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
+        const float* src = ok ? a_ptr[q] + ((size_t)hi * (2 * p.Win) + wi) * p.Cin + c0 : p.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(As + (wave * 32 + q * 8) * BK), 16, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QW; ++q)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[q] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(Ws + (wave * (BN / 4) + q * 8) * BK), 16, 0, 0);
+  };
+
+  // ---- main loop -----------------------------------------------------------------------------------------------
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int sw = (l31 >> 1) & 7;                        // swizzle of this lane's fragment rows (row bases are multiples of 32)
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // both stages are requested up front; the residual tile (epilogue layout: row it*RPI + er, 4 columns at ec) follows
+  // them so that its HBM latency is paid under the first barrier / the MFMAs instead of after them
+  dma_tile(0, 0);
+  if (KT > 1) dma_tile(1, 1);
+  constexpr int C4 = 8 * TN;                            // float4 per staged epilogue row
+  constexpr int RPI = 64 / C4;                          // rows per wave instruction
+  constexpr int NIT = 32 / RPI;
+  const int er = lane / C4, ec = (lane % C4) * 4;
+  const int ncol = n0 + wn * 32 * TN + ec;
+  f32x4 res[2][NIT];
+  if (p.residual) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = m0 + wm * 64 + a * 32 + it * RPI + er;
+        res[a][it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m < p.M ? m : 0) * p.ldr + ncol);
+      }
+  }
+  for (int kt = 0; kt < KT; ++kt) {
+    LDS_DMA_WAIT_ALL();                                 // this wavefront's share of tile kt (and kt+1) has landed ...
+    __syncthreads();                                    // ... and so has everybody else's; stage (kt+1)&1 is free
+    if (kt >= 1 && kt + 1 < KT) dma_tile(kt + 1, (kt + 1) & 1);
+    const float* As = smem + (kt & 1) * STAGE + (wm * 64 + l31) * BK;
+    const float* Ws = smem + (kt & 1) * STAGE + BM * BK + (wn * 32 * TN + l31) * BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = ((j * 2 + hh) ^ sw) * 4;
+      f32x4 af[2], bf[TN];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const f32x4*>(As + a * 32 * BK + ch);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = *reinterpret_cast<const f32x4*>(Ws + b * 32 * BK + ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                      // every wavefront is done reading the operand stages
+
+  // ---- epilogue through LDS: 32 rows x (32*TN) columns of this wavefront at a time -------------------------------
+  float* Es = smem + wave * 32 * EP;
+  f32x4 sc, bi, cs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sc[e] = p.scale ? p.scale[ncol + e] : 1.f;
+    bi[e] = p.bias ? p.bias[ncol + e] : 0.f;
+    cs[e] = (ncol + e < p.colscale_n) ? p.colscale : 1.f;
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Es[((r & 3) + 8 * (r >> 2) + 4 * hh) * EP + b * 32 + l31] = acc[a][b][r];
+    const int mb = m0 + wm * 64 + a * 32;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = it * RPI + er;
+      const int m = mb + row;
+      f32x4 v = *reinterpret_cast<const f32x4*>(Es + row * EP + ec);
+      if (m < p.M) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = v[e];
+          x = p.scale ? fmaf(x, sc[e], bi[e]) : x + bi[e];
+          x *= cs[e];
+          if (p.residual) x += res[a][it][e];
+          if (p.relu) x = (x < 0.f) ? 0.f : x;
+          v[e] = x;
+        }
+        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + ncol) = v;
+      }
+    }
+  }
+}
+
+template <int TN, int MODE>
+static int launch_big_t(const GemmParams& p0, hipStream_t s) {
+  constexpr int BM = 128, BN = 64 * TN;
+  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  static_assert(smem >= (size_t)4 * 32 * (32 * TN + 4) * sizeof(float), "epilogue staging fits in the operand stages");
+  GemmParams p = p0;
+  if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0 || p.A2 != nullptr) return -1;
+  if (p.ldc % 4 != 0 || (p.residual && p.ldr % 4 != 0)) return -1;
+  if (((uintptr_t)p.C & 15) || ((uintptr_t)p.residual & 15)) return -1;
+  if (p.zeros == nullptr) p.zeros = gemm_zero_buffer();
+  if (p.zeros == nullptr) return -2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return -2;
+    attr_set = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE>), dim3(tiles), dim3(256), smem, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// variant 0: 128 x 128 tile, 1: 128 x 64
+int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s) {
+  if (mode == GEMM_DENSE) {
+    if (p.lda % 4 != 0) return -1;
+    return variant == 0 ? launch_big_t<2, GEMM_DENSE>(p, s) : launch_big_t<1, GEMM_DENSE>(p, s);
+  }
+  if (mode == GEMM_CONV) return variant == 0 ? launch_big_t<2, GEMM_CONV>(p, s) : launch_big_t<1, GEMM_CONV>(p, s);
+  return -1;
+}

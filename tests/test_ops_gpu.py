@@ -151,3 +151,90 @@ def test_fused_ffn_block(M):
     assert lib.cotr_op_ffn_block(*[G.P(v) for v in t], G.P(scratch), G.P(y), M, G.sptr()) == 0
     e = G.rel_err(y, ref)
     assert e < 2e-5, e
+
+
+# ---- every launch configuration of the GEMM / implicit-GEMM kernels on the same problem -----------------------------
+def _cfgs():
+    from cotr_amd import _lib
+    return range(_lib.load_library().cotr_gemm_num_configs())
+
+
+def test_every_gemm_config_linear():
+    """All configurations (spatial, k-split, LDS-DMA, large-tile) compute the same bias+residual+ReLU linear; a
+    configuration may decline a shape (rc -1: tile does not divide N), never return a wrong result."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    d = G.dev()
+    ran = 0
+    for M, N, K in [(1000, 256, 256), (300, 128, 64), (4133, 1024, 256)]:
+        g = _g(M + N)
+        x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+        b, r = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        ref = F.relu(F.linear(x, w, b) + r)
+        xd, wd, bd, rd = x.to(d), w.to(d), b.to(d), r.to(d)
+        for cfg in _cfgs():
+            y = torch.full((M, N), float('nan'), device=d)
+            rc = lib.cotr_op_linear_cfg(G.P(xd), G.P(wd), G.P(bd), G.P(rd), 1, G.P(y), M, N, K, cfg, G.sptr())
+            if rc != 0:
+                continue
+            e = G.rel_err(y, ref)
+            assert e < 2e-5, (cfg, M, N, K, e)
+            ran += 1
+    assert ran >= 60
+
+
+def test_every_gemm_config_conv():
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    d = G.dev()
+    ran = 0
+    for B, H, cin, cout, k, stride in [(3, 16, 64, 128, 3, 1), (2, 16, 128, 256, 3, 2), (5, 8, 64, 256, 1, 1), (2, 32, 256, 128, 1, 2)]:
+        g = _g(B + H + cin + cout)
+        x = torch.randn(B, cin, H, 2 * H, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+        sc, b = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+        conv = lambda t: F.conv2d(t, w, stride=stride, padding=k // 2)
+        pre = G.per_half(conv, x) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+        res = torch.randn(pre.shape, generator=g)
+        ref = F.relu(pre + res)
+        xd, wd = G.nchw_to_sbs(x).to(d), G.pack_conv_weight(w).to(d)
+        scd, bd, rd = sc.to(d), b.to(d), G.nchw_to_sbs(res).to(d)
+        ho = ref.shape[2]
+        for cfg in _cfgs():
+            y = torch.full((B, ho, 2 * ho, cout), float('nan'), device=d)
+            rc = lib.cotr_op_conv_cfg(G.P(xd), G.P(wd), G.P(scd), G.P(bd), G.P(rd), 1, G.P(y), B, H, H, cin, cout, k, stride,
+                                      cfg, G.sptr())
+            if rc != 0:
+                continue
+            e = G.rel_err(G.sbs_to_nchw(y.cpu()), ref)
+            assert e < 3e-5, (cfg, B, H, cin, cout, k, stride, e)
+            ran += 1
+    assert ran >= 80
+
+
+def test_large_tile_configs_are_repeatable():
+    """The LDS-DMA kernels order other wavefronts' reads by an explicit vmcnt(0) before the barrier (common.h,
+    LDS_DMA_WAIT_ALL); without it thousands of workgroups in flight produced rare stale tiles.  Many workgroups, several
+    runs, bit-equal results, and equal to the register-staged configuration to rounding."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    d = G.dev()
+    g = _g(3)
+    for M, N, K in [(65536, 512, 128), (131072, 64, 256)]:
+        x, w = torch.randn(M, K, generator=g).to(d), (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d)
+        b, r = torch.randn(N, generator=g).to(d), torch.randn(M, N, generator=g).to(d)
+        ref = torch.empty(M, N, device=d)
+        assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(r), 1, G.P(ref), M, N, K, 2, G.sptr()) == 0
+        for cfg in (26, 27, 19, 20):
+            outs = []
+            for _ in range(4):
+                y = torch.full((M, N), float('nan'), device=d)
+                rc = lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(r), 1, G.P(y), M, N, K, cfg, G.sptr())
+                if rc != 0:
+                    break
+                outs.append(y)
+            if not outs:
+                continue
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, outs[0]) for o in outs[1:]), (cfg, M, N, K)
+            assert G.rel_err(outs[0], ref) < 2e-5, (cfg, M, N, K)
