@@ -188,3 +188,31 @@ def test_dense_pass_shape_q131072():
     idx = torch.arange(0, 131072, 997)
     ref = cotr_oracle.cotr_forward(sd, img, qs[:, idx])
     assert cotr_oracle.px_err(out[:, idx], ref) < PX_BAR
+
+
+def test_config3_256_pairs_x_1000_queries():
+    """BASELINE.json configs[3]: model(img[256,3,256,512], q[256,1000,2]) on one GPU (8 backbone passes of 32 pairs,
+    8 decoder passes).  The oracle would need minutes for this, so full size is checked through properties the path
+    guarantees: pairs never interact (a pair's answer == the same pair alone, to launch-configuration rounding, and
+    == the oracle for a sample), a permutation of the pairs permutes the answers, same call twice is bit-identical."""
+    sd = synth_state_dict(0)
+    B, Q = 256, 1000
+    base_img, base_q = synth_inputs(8, Q, seed=21)
+    g = torch.Generator().manual_seed(22)
+    gain = 0.5 + torch.rand(B, 1, 1, 1, generator=g)
+    shift = 0.3 * torch.randn(B, 3, 1, 1, generator=g)
+    img = base_img.repeat(B // 8, 1, 1, 1) * gain + shift               # 256 distinct pairs from 8 textures
+    qs = torch.rand(B, Q, 2, generator=g)
+    m = hip_model()
+    img_d, qs_d = img.cuda(), qs.cuda()
+    out = m(img_d, qs_d)['pred_corrs']
+    assert out.shape == (B, Q, 2) and not torch.isnan(out).any()
+    assert torch.equal(m(img_d, qs_d)['pred_corrs'], out)
+    perm = torch.randperm(B, generator=g)
+    out_p = m(img_d[perm.cuda()], qs_d[perm.cuda()])['pred_corrs']
+    assert cotr_oracle.px_err(out_p.cpu(), out.cpu()[perm]) < SHAPE_NOISE_PX
+    for b in (0, 37, 255):
+        alone = m(img_d[b:b + 1], qs_d[b:b + 1])['pred_corrs'].cpu()
+        assert cotr_oracle.px_err(alone, out[b:b + 1].cpu()) < SHAPE_NOISE_PX
+    ref = cotr_oracle.cotr_forward(sd, img[100:101], qs[100:101, :64])
+    assert cotr_oracle.px_err(out[100:101, :64].cpu(), ref) < PX_BAR
