@@ -51,6 +51,8 @@ _PROTOS = {
     'cotr_dense_cycle': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_void_p]),
     'cotr_dense_merge': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                         c_float_p, c_float_p, ctypes.c_void_p]),
+    'cotr_resize_f32': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_void_p]),
     'cotr_set_encode_chunk': (ctypes.c_int, [ctypes.c_int]),
     'cotr_gemm_num_configs': (ctypes.c_int, []),
     'cotr_set_ffn_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),

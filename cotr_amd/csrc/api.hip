@@ -962,6 +962,11 @@ int cotr_dense_merge(const float* maps, const int32_t* boxes, int n_pairs, int s
   return op_ret(launch_dense_merge(maps, boxes, n_pairs, side, H, W, flow, conf, static_cast<hipStream_t>(stream)));
 }
 
+int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, cotr_stream stream) {
+  if (!src || !dst || Hs <= 0 || Ws <= 0 || Hd <= 0 || Wd <= 0 || C <= 0 || (int64_t)Hd * Wd > (int64_t)1 << 30) return COTR_ERR_ARG;
+  return op_ret(launch_resize_f32(src, Hs, Ws, C, dst, Hd, Wd, static_cast<hipStream_t>(stream)));
+}
+
 // fused FFN block: y = LayerNorm(x + linear2(relu(linear1(x)))) in two launches; scratch >= ffn chunks * M * 256 floats
 int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
                       const float* ln_b, float* scratch, float* y, int M, cotr_stream stream) {

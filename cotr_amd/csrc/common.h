@@ -82,6 +82,8 @@ int launch_dense_cycle(const float* pred, const double* aff, float* maps, int n_
 int launch_dense_merge(const float* maps, const int32_t* boxes, int n_pairs, int side, int H, int W, float* flow,
                        float* conf, hipStream_t s);
 
+int launch_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, hipStream_t s);
+
 // fused feed-forward block (ffn.hip) and its reduce + bias + residual + LayerNorm tail (pointwise.hip)
 int ffn_fused_chunks(int M);
 int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch, hipStream_t s);

@@ -164,6 +164,75 @@ __global__ __launch_bounds__(256) void dense_merge_kernel(const float* __restric
   conf[idx] = best;
 }
 
+// ---- generic Pillow mode-'F' BILINEAR resize of a [Hs,Ws,C] float map to [Hd,Wd,C] (utils.float_image_resize) ----
+struct GTaps {
+  int lo, n;
+  double center, ss, ww;
+};
+
+__device__ __forceinline__ GTaps gtaps_for(int in_size, int out_size, int xx) {
+  GTaps t;
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  t.ss = 1.0 / filterscale;
+  t.center = ((double)xx + 0.5) * scale;
+  int lo = (int)(t.center - support + 0.5);
+  if (lo < 0) lo = 0;
+  int hi = (int)(t.center + support + 0.5);
+  if (hi > in_size) hi = in_size;
+  t.lo = lo;
+  t.n = hi - lo;
+  t.ww = 0.0;
+  for (int x = 0; x < t.n; ++x) t.ww += tri(((double)(x + lo) - t.center + 0.5) * t.ss);
+  return t;
+}
+
+__device__ __forceinline__ double gtap_weight(const GTaps& t, int x) {
+  double w = tri(((double)(x + t.lo) - t.center + 0.5) * t.ss);
+  if (t.ww != 0.0) w /= t.ww;
+  return w;
+}
+
+// Pillow runs the horizontal pass only if the width changes and the vertical pass only if the height changes; the
+// intermediate image is float, so rounding the row sums to float in between reproduces it in every case.
+__global__ __launch_bounds__(256) void resize_f32_kernel(const float* __restrict__ src, int Hs, int Ws, int C,
+                                                         float* __restrict__ dst, int Hd, int Wd) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Hd * Wd) return;
+  const int px = idx % Wd, py = idx / Wd;
+  const bool horiz = Ws != Wd, vert = Hs != Hd;
+  GTaps tx, ty;
+  if (horiz) tx = gtaps_for(Ws, Wd, px);
+  if (vert) ty = gtaps_for(Hs, Hd, py);
+  const int ny = vert ? ty.n : 1, y0 = vert ? ty.lo : py;
+  const int nx = horiz ? tx.n : 1, x0 = horiz ? tx.lo : px;
+  for (int c = 0; c < C; ++c) {
+    double acc = 0.0;
+    float last = 0.f;
+    for (int y = 0; y < ny; ++y) {
+      const float* r = src + ((size_t)(y0 + y) * Ws) * C + c;
+      float rowv;
+      if (horiz) {
+        double row = 0.0;
+        for (int x = 0; x < nx; ++x) row += (double)r[(size_t)(x0 + x) * C] * gtap_weight(tx, x);
+        rowv = (float)row;
+      } else {
+        rowv = r[(size_t)x0 * C];
+      }
+      if (vert) acc += (double)rowv * gtap_weight(ty, y);
+      last = rowv;
+    }
+    dst[(size_t)idx * C + c] = vert ? (float)acc : last;
+  }
+}
+
+int launch_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, hipStream_t s) {
+  if (Hd <= 0 || Wd <= 0) return 0;
+  hipLaunchKernelGGL(resize_f32_kernel, dim3((Hd * Wd + 255) / 256), dim3(256), 0, s, src, Hs, Ws, C, dst, Hd, Wd);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_dense_cycle(const float* pred, const double* aff, float* maps, int n_pairs, hipStream_t s) {
   if (n_pairs <= 0) return 0;
   const int total = n_pairs * NET_H * NET_W;

@@ -87,6 +87,20 @@ class _DeviceDensePost:
         # the reference's maps are float64 numpy arrays holding float32 values
         return tuple(t.cpu().numpy().astype(np.float64) for t in out)
 
+    def resize(self, arr, shape):
+        """``utils.float_image_resize`` (utils.py:69-83) of a [H,W] or [H,W,C] map to ``shape`` = (H', W'): float32 result,
+        like the Pillow mode-'F' round trip of the reference."""
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        src = torch.from_numpy(a.reshape(a.shape[0], a.shape[1], -1)).to(self.device)
+        dst = torch.empty((shape[0], shape[1], src.shape[2]), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.cotr_resize_f32(src.data_ptr(), src.shape[0], src.shape[1], src.shape[2], dst.data_ptr(), shape[0],
+                                          shape[1], self._lib.current_stream_ptr())
+        if rc != 0:
+            raise self._lib.CotrHipError(f'cotr_resize_f32 failed (code {rc})')
+        out = dst.cpu().numpy()
+        return out[..., 0] if a.ndim == 2 else out
+
 
 RefineResult = namedtuple('RefineResult', ['loc_from', 'loc_to', 'good', 'loc_history', 'model_calls', 'crops', 'steps'])
 
@@ -169,8 +183,9 @@ class ZoomEngine:
     """
 
     def __init__(self, model, max_pairs=256, make_cropper=None, batch_size=32, mode='tile', make_dense_post=None):
-        if mode != 'tile':
-            raise NotImplementedError("only SparseEngine's mode='tile' is mirrored (demo_single_pair / guided matching / wbs)")
+        if mode not in ('stretching', 'tile'):                      # sparse_engine.py:19
+            raise ValueError(f'unsupported mode: {mode}')
+        self.mode = mode
         self.model = model
         self.batch_size = int(batch_size)   # the reference walks tasks in groups of this size: decides where it stops
         self.max_pairs = int(max_pairs)
@@ -358,10 +373,24 @@ class ZoomEngine:
         return corr_a, con_a, res_a, corr_b, con_b, res_b
 
     def gen_tasks(self, img_a, img_b, max_corrs, queries_a, force):
-        """``SparseEngine.gen_tasks`` without ``areas`` (sparse_engine.py:108-195, mode 'tile'): dense pass, confident
+        """``SparseEngine.gen_tasks`` without ``areas`` (sparse_engine.py:108-195): dense pass, confident
         pixels, relative scale from the confident areas.  -> loc_from [N,2], loc_to [N,2], identifier [N] (-1 = None),
         area_a, area_b.  Uses numpy's global RNG exactly where the reference does (np.random.choice, :151,154)."""
-        corr_a, con_a, _, corr_b, con_b, _ = self.flow(img_a, img_b, resample=False)
+        if self.mode == 'stretching' and (img_a.shape[0] != img_a.shape[1] or img_b.shape[0] != img_b.shape[1]):
+            # sparse_engine.py:114-129: dense pass on the images stretched to squares (Pillow 8-bit bilinear, once per
+            # pair, on the host like the reference), maps brought back to the image shape by the float resize
+            import PIL.Image
+
+            def stretch(img):
+                size = max(*img.shape[:2])
+                return np.array(PIL.Image.fromarray(img).resize((size, size), resample=PIL.Image.BILINEAR))
+            corr_a, con_a, _, corr_b, con_b, _ = self.flow(stretch(img_a), stretch(img_b), resample=False)
+            device = next(self.model.parameters()).device
+            post = self.make_dense_post(device)
+            corr_a, con_a = post.resize(corr_a, img_a.shape[:2]), post.resize(con_a, img_a.shape[:2])
+            corr_b, con_b = post.resize(corr_b, img_b.shape[:2]), post.resize(con_b, img_b.shape[:2])
+        else:
+            corr_a, con_a, _, corr_b, con_b, _ = self.flow(img_a, img_b, resample=False)
         mask_a, mask_b = con_a < THRESHOLD_SPARSE, con_b < THRESHOLD_SPARSE
         area_a = (con_a < THRESHOLD_AREA).sum() / mask_a.size
         area_b = (con_b < THRESHOLD_AREA).sum() / mask_b.size

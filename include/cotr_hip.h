@@ -156,6 +156,11 @@ int cotr_dense_cycle(const float* pred, int n_pairs, const double* affine, float
 int cotr_dense_merge(const float* maps, const int32_t* boxes, int n_pairs, int side, int H, int W, float* flow,
                      float* conf, cotr_stream stream);
 
+/* src [Hs,Ws,C] float -> dst [Hd,Wd,C] with Pillow's mode-'F' BILINEAR resample, channel by channel, bit-exact:
+ * utils.float_image_resize (COTR/utils/utils.py:69-83), used by SparseEngine's 'stretching' mode to bring the dense maps
+ * of the squared images back to the image shape (sparse_engine.py:124-129). */
+int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, cotr_stream stream);
+
 /* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
 int cotr_gemm_num_configs(void);
 /* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB

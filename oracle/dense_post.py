@@ -98,6 +98,19 @@ def dense_post(pred, pairs, shape_a, shape_b):
     return corr_a, con_a, corr_b, con_b
 
 
+class _HostDensePost:
+    def __call__(self, pred, pairs, shape_a, shape_b):
+        return dense_post(pred, pairs, shape_a, shape_b)
+
+    def resize(self, arr, shape):
+        """``utils.float_image_resize`` incl. its 2-D special case (utils.py:69-83); float64 input goes through Pillow's
+        'F;64F' conversion to float32, as in the reference."""
+        arr = np.asarray(arr)
+        if arr.ndim == 2:
+            return float_image_resize(arr[..., None], shape)[..., 0]
+        return float_image_resize(arr, shape)
+
+
 def host_dense_post_factory(device):
     """Drop-in for ZoomEngine(make_dense_post=...) in CPU tests of the engine logic."""
-    return dense_post
+    return _HostDensePost()

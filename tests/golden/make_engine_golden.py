@@ -34,11 +34,15 @@ DENSE_CASES = {
     'engine_dense_queries_force': (6, 30, 1, 30, True, False),
     'engine_cycle_default': (7, 15, 1, None, False, True),
     'engine_cycle_queries': (8, 12, 2, 60, False, True),
+    'engine_stretch_default': (9, 30, 1, None, False, False, 'stretching'),     # sparse_engine.py:114-129
+    'engine_stretch_cycle': (10, 12, 1, None, False, True, 'stretching'),
 }
 
 
 def dense_goldens(SparseEngine, cotr_flow, zoom_ins):
-    for name, (seed, max_corrs, conv, nq, force, cycle) in DENSE_CASES.items():
+    for name, case in DENSE_CASES.items():
+        seed, max_corrs, conv, nq, force, cycle = case[:6]
+        mode = case[6] if len(case) > 6 else 'tile'
         img_a, img_b = synthetic_pair(seed)
         rng = np.random.default_rng(seed + 100)
         queries = None
@@ -48,7 +52,7 @@ def dense_goldens(SparseEngine, cotr_flow, zoom_ins):
         out = {}
         with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
             flow = cotr_flow(model, img_a, img_b)
-            engine = SparseEngine(model, 32, mode='tile')
+            engine = SparseEngine(model, 32, mode=mode)
             np.random.seed(seed)
             if cycle:
                 corrs, idx, err = engine.cotr_corr_multiscale_with_cycle_consistency(
@@ -64,7 +68,7 @@ def dense_goldens(SparseEngine, cotr_flow, zoom_ins):
             out['sha_' + k] = np.frombuffer(digest(v), dtype=np.uint8)       # ... and a digest of the whole map
         np.savez_compressed(os.path.join(HERE, name + '.npz'), corrs=corrs, idx=idx,
                             queries=np.zeros((0, 2)) if queries is None else queries,
-                            meta=np.array([seed, max_corrs, conv, -1 if nq is None else nq, int(force), int(cycle)]),
+                            meta=np.array([seed, max_corrs, conv, -1 if nq is None else nq, int(force), int(cycle), int(mode == 'stretching')]),
                             total_tasks=np.array(engine.total_tasks), **out)
         print(name, 'kept', len(corrs), 'crops', engine.total_tasks, 'confident a/b',
               float((flow[1] < 0.02).mean()), float((flow[4] < 0.02).mean()))

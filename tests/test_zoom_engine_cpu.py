@@ -68,12 +68,13 @@ def test_corr_base_matches_reference(name, golden_dir):
 
 # ---- default path: dense initial pass + task generation + early exit + cycle-consistency wrapper ---------------------
 DENSE_CASES = ['engine_dense_default', 'engine_dense_default_c3', 'engine_dense_queries_filter',
-               'engine_dense_queries_force', 'engine_cycle_default', 'engine_cycle_queries']
+               'engine_dense_queries_force', 'engine_cycle_default', 'engine_cycle_queries',
+               'engine_stretch_default', 'engine_stretch_cycle']
 FLOW_KEYS = ('corr_a', 'con_a', 'resample_a', 'corr_b', 'con_b', 'resample_b')
 
 
 def run_dense_case(g, eng):
-    seed, max_corrs, conv, nq, force, cycle = (int(v) for v in g['meta'])
+    seed, max_corrs, conv, nq, force, cycle = (int(v) for v in g['meta'][:6])
     img_a, img_b = synthetic_pair(seed)
     queries = None if nq < 0 else g['queries']
     np.random.seed(seed)                                 # gen_tasks draws from numpy's global RNG like the reference
@@ -108,8 +109,9 @@ def test_default_path_matches_reference_engine(name, max_pairs, golden_dir):
     from tests.engine_fixtures import CyclicFakeModel
     torch.set_num_threads(1)
     g = np.load(os.path.join(golden_dir, name + '.npz'))
+    mode = 'stretching' if len(g['meta']) > 6 and int(g['meta'][6]) else 'tile'
     eng = ZoomEngine(CyclicFakeModel(), max_pairs=max_pairs, make_cropper=pil_cropper_factory,
-                     make_dense_post=host_dense_post_factory)
+                     make_dense_post=host_dense_post_factory, mode=mode)
     out = run_dense_case(g, eng)
     assert np.array_equal(out[0], g['corrs'])
     assert np.array_equal(out[1], g['idx'])

@@ -238,3 +238,35 @@ def test_dense_pass_through_the_real_model():
         q_row = seen['q'].view(4, 256, 512, 2)[:, row].contiguous()
         small = hip(seen['img'], q_row)['pred_corrs']
         assert (big[:, row] - small).abs().max().item() * 256 < 1e-3      # px in the 256x512 network frame
+
+
+@pytest.mark.parametrize('src_shape,dst_shape', [((420, 420), (300, 420)), ((350, 350), (350, 330)), ((256, 512), (700, 300)),
+                                                 ((64, 48), (64, 48)), ((300, 200), (37, 411))])
+@pytest.mark.parametrize('channels', [1, 2])
+def test_resize_f32_is_pillow_exact(src_shape, dst_shape, channels):
+    """cotr_resize_f32 == utils.float_image_resize (Pillow mode 'F' BILINEAR; utils.py:69-83), bit for bit: the map
+    resize of SparseEngine's 'stretching' mode (sparse_engine.py:124-129)."""
+    from cotr_amd.inference.zoom_engine import _DeviceDensePost
+    rng = np.random.default_rng(src_shape[0] + dst_shape[1] + channels)
+    arr = rng.standard_normal(src_shape + (channels,)).astype(np.float32)
+    arr[::7, ::5] = 100.0
+    want = dense_post.float_image_resize(arr, dst_shape)
+    got = _DeviceDensePost(torch.device('cuda:0')).resize(arr, dst_shape)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    if channels == 1:
+        assert np.array_equal(_DeviceDensePost(torch.device('cuda:0')).resize(arr[..., 0], dst_shape), want[..., 0])
+
+
+def test_stretching_mode_on_device():
+    """mode='stretching' with device crops + device maps vs the host recipe: maps to 2e-6, then the whole default path
+    runs and returns in-bounds correspondences."""
+    from tests.engine_fixtures import CyclicFakeModel
+    img_a, img_b = synthetic_pair(13)
+    dev = ZoomEngine(CyclicFakeModel().cuda(), mode='stretching')
+    np.random.seed(0)
+    corrs = dev.cotr_corr_multiscale(img_a, img_b, ZOOMS, 1, max_corrs=25)
+    assert corrs.shape == (25, 4) and np.isfinite(corrs).all() and (corrs > 0).all()
+    assert (corrs[:, 0] < img_a.shape[1]).all() and (corrs[:, 1] < img_a.shape[0]).all()
+    assert (corrs[:, 2] < img_b.shape[1]).all() and (corrs[:, 3] < img_b.shape[0]).all()
+    with pytest.raises(ValueError):
+        ZoomEngine(CyclicFakeModel().cuda(), mode='pyramid')
