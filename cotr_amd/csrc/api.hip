@@ -465,7 +465,9 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
   return COTR_OK;
 }
 
-int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
+// feat_out == nullptr: the whole query-independent half (cotr_encode); otherwise only the backbone, its layer3 output
+// [B,16,32,1024] (NHWC, both halves side by side = 512 token rows per pair) copied to feat_out (cotr_backbone)
+static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream stream, float* feat_out) {
   if (!h) return COTR_ERR_ARG;
   if (!h->loaded) { h->err = "cotr_encode before cotr_load_weights"; return COTR_ERR_STATE; }
   if (!img || B <= 0) { h->err = "cotr_encode: null image or B <= 0"; return COTR_ERR_ARG; }
@@ -475,7 +477,7 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
   const size_t KVLD = (size_t)L * 2 * D;
   h->enc_B = 0;
   h->taps.clear();
-  {
+  if (!feat_out) {
     int r = ensure(h, h->memkv, (size_t)B * TOK * (D + KVLD));
     if (r) return r;
   }
@@ -551,6 +553,11 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
       if (int r = tap_save(h, names[st], x, (size_t)Bc * H * 2 * W * kStages[st].planes * 4, s)) return r;
       prof_mark(h, names[st], s);
     }
+    if (feat_out) {
+      HIPCHK(h, hipMemcpyAsync(feat_out + (size_t)b0 * TOK * CFEAT, x, (size_t)Bc * TOK * CFEAT * sizeof(float),
+                               hipMemcpyDeviceToDevice, s));
+      continue;
+    }
     // ---- input_proj: x is [Bc*512, 1024] --------------------------------------------------
     const int M = Bc * TOK;
     int r;
@@ -578,11 +585,19 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
     if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
     prof_mark(h, "dec_kv", s);
   }
+  if (feat_out) return COTR_OK;
   h->taps["memory"] = {memory, (size_t)B * TOK * D};
   h->taps["kv"] = {kv, (size_t)B * TOK * KVLD};
   h->taps["pos"] = {h->pos, (size_t)TOK * D};
   h->enc_B = B;
   return COTR_OK;
+}
+
+int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) { return encode_impl(h, img, B, stream, nullptr); }
+
+int cotr_backbone(cotr_handle h, const float* img, int B, float* features, cotr_stream stream) {
+  if (!features) return COTR_ERR_ARG;
+  return encode_impl(h, img, B, stream, features);
 }
 
 }  // extern "C"

@@ -227,9 +227,15 @@ class COTR(nn.Module):
     # ------------------------------------------------------------------ the path
     def _check_mode(self):
         if self.training:
-            raise NotImplementedError(
-                'cotr_amd implements the inference forward (model.eval()); the training step is the next '
-                'scope row (SURVEY.md 8f).')
+            raise NotImplementedError('encode()/decode() are the inference split (model.eval()); in training mode call '
+                                      'model(img, queries) - see cotr_amd/training.py')
+
+    def train(self, mode=True):
+        # parameters updated by an optimiser while training must be re-packed into the HIP library before the next
+        # inference call (the frozen backbone the training step uses is not touched by the optimiser)
+        if self.training and not mode:
+            self._weights_dirty = True
+        return super().train(mode)
 
     @staticmethod
     def _as_batch(samples):
@@ -271,9 +277,16 @@ class COTR(nn.Module):
                        self._handle, 'cotr_decode')
         return out
 
-    @torch.no_grad()
     def forward(self, samples, queries):
-        self._check_mode()
+        if self.training:       # stage-1 training step: HIP backbone + HIP GEMMs under an autograd tape (training.py)
+            from .. import training
+            img = self._as_batch(samples)
+            assert queries.ndim == 3 and queries.shape[2] == 2 and queries.shape[0] == img.shape[0]
+            return {'pred_corrs': training.forward_train(self, img, queries)}
+        return self._forward_eval(samples, queries)
+
+    @torch.no_grad()
+    def _forward_eval(self, samples, queries):
         img = self._as_batch(samples)
         b, q, two = queries.shape
         assert two == 2 and b == img.shape[0]

@@ -1,0 +1,276 @@
+"""Training step for the reference's stage 1 (frozen backbone, ``train_cotr.py --lr_backbone=0``) - SURVEY.md 8f row 4,
+FIRST VERSION.
+
+What runs where:
+* backbone (ResNet-50 to layer3, FrozenBN; 70 % of the forward FLOPs, no gradient in stage 1): the hand-written HIP
+  kernels, through ``cotr_backbone`` (C ABI) - once per step, shared by the prediction and the cycle pass;
+* every contraction of the trainable part (input_proj, q/k/v and output projections, both FFN layers, the first two
+  layers of corr_embed) FORWARD AND BACKWARD: the library's fp32-MFMA GEMM kernels (``cotr_op_linear``), wrapped in a
+  ``torch.autograd.Function``:  dX = dY . W  and  dW = dY^T . X  are the same kernel on transposed operands;
+* the autograd tape, the small ops between the contractions (softmax(q k^T) v per head, LayerNorm, dropout, residual adds,
+  the lin_sine encodings and their derivative for the cycle pass, the 256 -> 2 output layer) and Adam: PyTorch on the GPU.
+  Hand-written backward kernels for attention / LayerNorm are the next step of this row; until then this module is the
+  only place where torch ops compute anything, and only under ``model.train()``.
+
+Semantics follow the reference line by line: ``COTR.forward`` (COTR/models/cotr_model.py:26-40) with dropout active
+(COTR/models/transformer.py:143-159,185-201; ``nn.MultiheadAttention(dropout=...)``), ``COTRTrainer.train_batch``
+(COTR/trainers/cotr_trainer.py:118-150), the checkpoint dictionary of ``save_model`` (:75-88).  Because
+``model(img, queries)`` works in training mode and the parameters are ordinary ``nn.Parameter`` objects, the reference's own
+trainer / ``torch.optim.Adam(optim_list)`` (train_cotr.py:49-57) also run unchanged on this model.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+MAX_SIZE = 256
+TOK = 512          # 16 x 32 feature positions of a side-by-side pair
+CFEAT = 1024
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _gemm(a, w, bias=None):
+    """y[M,N] = a[M,K] . w[N,K]^T (+ bias) on the library's GEMM kernels; fp32, contiguous CUDA tensors."""
+    lib = _lib.load_library()
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and k % 32 == 0 and n % 16 == 0, (a.shape, w.shape)
+    y = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if m == 0:
+        return y
+    with torch.cuda.device(a.device):
+        rc = lib.cotr_op_linear(a.data_ptr(), None, 0, w.data_ptr(), None, None if bias is None else bias.data_ptr(), None, 0,
+                                y.data_ptr(), m, n, k, _lib.current_stream_ptr())
+    if rc != 0:
+        raise _lib.CotrHipError(f'cotr_op_linear failed (code {rc}) for M,N,K = {m},{n},{k}')
+    return y
+
+
+def _t_pad(t):
+    """[M,C] -> contiguous [C, M rounded up to 32] (zero padded): the K-major operand of dW = dY^T . X."""
+    m, c = t.shape
+    mp = (m + 31) // 32 * 32
+    out = torch.zeros((c, mp), dtype=t.dtype, device=t.device)
+    out[:, :m] = t.t()
+    return out
+
+
+class _HipLinear(torch.autograd.Function):
+    """nn.Linear on the HIP GEMM kernels, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        w = w.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return _gemm(x, w, None if b is None else b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _gemm(dy, w.t().contiguous())            # [M,N] . (W^T)[K,N]^T
+        if ctx.needs_input_grad[1]:
+            dw = _gemm(_t_pad(dy), _t_pad(x))             # (dY^T)[N,M] . (X^T)[K,M]^T
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def hip_linear(x, w, b=None):
+    return _HipLinear.apply(x, w, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def lin_sine(x, depth=64):
+    """NerfPositionalEncoding 'lin_sine' (COTR/models/position_encoding.py:30-45): cat([sin(k pi x)]_k, [cos(k pi x)]_k)
+    over a last dimension of size 2, k = 1..depth; differentiable (the cycle pass feeds predictions back as queries)."""
+    kpi = torch.tensor([(i + 1) * math.pi for i in range(depth)], dtype=x.dtype, device=x.device)
+    arg = x.unsqueeze(-2) * kpi.view(-1, 1)                       # [..., depth, 2]
+    return torch.cat([torch.sin(arg).flatten(-2), torch.cos(arg).flatten(-2)], dim=-1)
+
+
+def image_pos_table(device, h=16, w=32, hidden=256):
+    """PositionEmbeddingSine with an all-False mask (position_encoding.py:60-72), fp32 like the reference -> [h*w, hidden]."""
+    ones = torch.ones(1, h, w, dtype=torch.bool, device=device)
+    y = ones.cumsum(1, dtype=torch.float32)
+    x = ones.cumsum(2, dtype=torch.float32)
+    y = (y - 0.5) / (y[:, -1:, :] + 1e-6)
+    x = (x - 0.5) / (x[:, :, -1:] + 1e-6)
+    return lin_sine(torch.stack([x, y], dim=-1), hidden // 4)[0].reshape(h * w, hidden)
+
+
+def _heads(t, b, length, nheads):
+    return t.view(b, length, nheads, -1).permute(0, 2, 1, 3)        # [B, heads, L, hd]
+
+
+def _attention(q, k, v, b, lq, lk, nheads, p_drop, training):
+    """softmax(q k^T) v per head; q already scaled (nn.MultiheadAttention scales q by head_dim^-0.5 before q.k^T)."""
+    qh, kh, vh = _heads(q, b, lq, nheads), _heads(k, b, lk, nheads), _heads(v, b, lk, nheads)
+    attn = torch.softmax(qh @ kh.transpose(-1, -2), dim=-1)
+    attn = F.dropout(attn, p_drop, training)
+    return (attn @ vh).permute(0, 2, 1, 3).reshape(b * lq, -1)
+
+
+def _ln(x, norm):
+    return F.layer_norm(x, (x.shape[-1],), norm.weight, norm.bias, norm.eps)
+
+
+def _ffn(x, layer, p_drop, training):
+    hid = F.dropout(F.relu(hip_linear(x, layer.linear1.weight, layer.linear1.bias)), p_drop, training)
+    return hip_linear(hid, layer.linear2.weight, layer.linear2.bias)
+
+
+def backbone_features(model, img):
+    """layer3 features [B*512, 1024] of the frozen backbone on the HIP kernels (no gradient)."""
+    lib = model._ensure_ready(img.device)
+    img = img.detach().contiguous().float()
+    feat = torch.empty((img.shape[0] * TOK, CFEAT), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        _lib.check(lib.cotr_backbone(model._handle, img.data_ptr(), img.shape[0], feat.data_ptr(), _lib.current_stream_ptr()),
+                   model._handle, 'cotr_backbone')
+    return feat
+
+
+def forward_train(model, img, queries, features=None):
+    """``COTR.forward`` in training mode -> pred_corrs [B,Q,2] with an autograd graph over the trainable part.
+    Row layout is batch-major: row b*L + l is token / query l of pair b."""
+    if any(p.requires_grad for p in model.backbone.parameters()):
+        raise NotImplementedError('training the backbone (--lr_backbone > 0, the reference\'s stages 2-3) is not implemented: '
+                                  'this step covers stage 1 (frozen backbone)')
+    tr = model.transformer
+    nheads, d = tr.nhead, tr.d_model
+    scale = float(d // nheads) ** -0.5
+    training = model.training
+    b, nq, _ = queries.shape
+    if features is None:
+        features = backbone_features(model, img)
+    pos = image_pos_table(img.device, hidden=d)                                                        # [512, d]
+    src = hip_linear(features, model.input_proj.weight.view(d, CFEAT), model.input_proj.bias)          # cotr_model.py:37
+
+    def add_pos(x):
+        return (x.view(b, TOK, d) + pos).view(b * TOK, d)
+
+    for layer in tr.encoder.layers:                                                                    # transformer.py:143-159
+        p = layer.self_attn.dropout
+        w, bias = layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias
+        qk = hip_linear(add_pos(src), w[:2 * d], bias[:2 * d])
+        v = hip_linear(src, w[2 * d:], bias[2 * d:])
+        ao = _attention(qk[:, :d] * scale, qk[:, d:], v, b, TOK, TOK, nheads, p, training)
+        ao = hip_linear(ao, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)
+        src = _ln(src + F.dropout(ao, p, training), layer.norm1)
+        src = _ln(src + F.dropout(_ffn(src, layer, p, training), p, training), layer.norm2)
+    memory, mem_pos = src, add_pos(src)
+
+    query_pos = lin_sine(queries.reshape(-1, 2).float(), d // 4)                                       # cotr_model.py:34-36
+    tgt = torch.zeros_like(query_pos)                                                                  # transformer.py:54
+    for layer in tr.decoder.layers:                                                                    # transformer.py:185-201
+        p = layer.multihead_attn.dropout
+        w, bias = layer.multihead_attn.in_proj_weight, layer.multihead_attn.in_proj_bias
+        q = hip_linear(tgt + query_pos, w[:d], bias[:d]) * scale
+        k = hip_linear(mem_pos, w[d:2 * d], bias[d:2 * d])
+        v = hip_linear(memory, w[2 * d:], bias[2 * d:])
+        ao = _attention(q, k, v, b, nq, TOK, nheads, p, training)
+        ao = hip_linear(ao, layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias)
+        tgt = _ln(tgt + F.dropout(ao, p, training), layer.norm2)
+        tgt = _ln(tgt + F.dropout(_ffn(tgt, layer, p, training), p, training), layer.norm3)
+    hs = _ln(tgt, tr.decoder.norm)                       # only the last layer's output reaches the loss (cotr_model.py:39)
+    mlp = model.corr_embed.layers                        # position_encoding.py:23-26
+    x = F.relu(hip_linear(hs, mlp[0].weight, mlp[0].bias))
+    x = F.relu(hip_linear(x, mlp[1].weight, mlp[1].bias))
+    return F.linear(x, mlp[2].weight, mlp[2].bias).view(b, nq, 2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=True):
+    """The loss of ``COTRTrainer.train_batch`` / ``validate_batch`` (cotr_trainer.py:124-142) -> (loss, pred)."""
+    feats = backbone_features(model, img)                 # frozen: the cycle pass sees the same features
+    pred = forward_train(model, img, query, feats)
+    loss = F.mse_loss(pred, target)
+    if cycle_consis and bidirectional:
+        cycle = forward_train(model, img, pred, feats)
+        mask = torch.norm(cycle - query, dim=-1) < 10 / MAX_SIZE
+        if mask.sum() > 0:
+            loss = loss + F.mse_loss(cycle[mask], query[mask])
+    elif cycle_consis:
+        img_rev = torch.cat([img[..., MAX_SIZE:], img[..., :MAX_SIZE]], dim=-1)
+        q_rev = pred.clone()
+        q_rev[..., 0] = q_rev[..., 0] - 0.5
+        cycle = forward_train(model, img_rev, q_rev)
+        cycle = torch.stack([cycle[..., 0] - 0.5, cycle[..., 1]], dim=-1)
+        mask = torch.norm(cycle - query, dim=-1) < 10 / MAX_SIZE
+        if mask.sum() > 0:
+            loss = loss + F.mse_loss(cycle[mask], query[mask])
+    return loss, pred
+
+
+def train_batch(model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None):
+    """One optimisation step, ``COTRTrainer.train_batch`` (cotr_trainer.py:118-150); with ``group`` the gradients are
+    averaged over the process group (one rank per GPU, RCCL) before the optimiser step.  -> (loss value, pred)."""
+    assert model.training
+    optim.zero_grad()
+    loss, pred = compute_loss(model, img, query, target, cycle_consis, bidirectional)
+    value = loss.item()
+    if math.isnan(value):
+        optim.zero_grad()
+    else:
+        loss.backward()
+        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            sync_gradients([p for g in optim.param_groups for p in g['params']], group)
+    optim.step()
+    return value, pred.detach()
+
+
+def sync_gradients(params, group=None, bucket_elems=1 << 24):
+    """Average the gradients over the ranks: flat fp32 buckets (64 MB: the whole trainable part of stage 1 is one bucket;
+    xGMI rings are per-link bound, few large messages beat many small ones), one all-reduce each."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    params = [p for p in params if p.grad is not None]
+    i = 0
+    while i < len(params):
+        j, n = i, 0
+        while j < len(params) and (n == 0 or n + params[j].numel() <= bucket_elems):
+            n += params[j].numel()
+            j += 1
+        flat = torch.cat([p.grad.reshape(-1) for p in params[i:j]])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world
+        off = 0
+        for p in params[i:j]:
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+            off += p.numel()
+        i = j
+
+
+def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0):
+    """``torch.optim.Adam(optim_list)`` of train_cotr.py:49-57."""
+    groups = [{'params': model.transformer.parameters(), 'lr': learning_rate},
+              {'params': model.corr_embed.parameters(), 'lr': learning_rate},
+              {'params': model.query_proj.parameters(), 'lr': learning_rate},
+              {'params': model.input_proj.parameters(), 'lr': learning_rate}]
+    groups = [g for g in ({**g, 'params': list(g['params'])} for g in groups) if g['params']]
+    if lr_backbone > 0:
+        groups.append({'params': list(model.backbone.parameters()), 'lr': lr_backbone})
+    return torch.optim.Adam(groups)
+
+
+def save_checkpoint(path, model, optim, epoch, iteration):
+    """The dictionary of ``COTRTrainer.save_model`` (cotr_trainer.py:75-88)."""
+    torch.save({'epoch': epoch, 'iteration': iteration, 'optim_state_dict': optim.state_dict(),
+                'model_state_dict': model.state_dict()}, path)
+
+
+def load_checkpoint(path, model, optim=None):
+    ck = torch.load(path, map_location='cpu')
+    model.load_state_dict(ck['model_state_dict'])
+    if optim is not None and 'optim_state_dict' in ck:
+        optim.load_state_dict(ck['optim_state_dict'])
+    return ck.get('epoch', 0), ck.get('iteration', 0)

@@ -70,6 +70,12 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
  * Follows COTR/models/backbone.py:79-92,114-123, cotr_model.py:37, transformer.py:49-55,143-159,192-195. */
 int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream);
 
+/* Backbone only: features [B,16,32,1024] (NHWC over the side-by-side pair = 512 token rows of 1024 channels per pair,
+ * token h*32+w like flatten(2) of the reference's [B,1024,16,32]).  Replaces self.backbone(samples)[0][-1].tensors
+ * (COTR/models/backbone.py:79-92) for callers that run the rest themselves: the training step with a frozen backbone
+ * (train_cotr.py:54-55 with --lr_backbone=0, the reference's stage 1). */
+int cotr_backbone(cotr_handle h, const float* img, int B, float* features, cotr_stream stream);
+
 /* Query-dependent half against the cached encode: lin_sine query encoding, 6 cross-attention
  * decoder layers, decoder.norm and the corr_embed MLP on the LAST layer only (the reference runs
  * them on all 6 and keeps [-1]: transformer.py:107-117, cotr_model.py:38-39).
