@@ -72,8 +72,13 @@ def test_no_cpu_fallback_and_shape_contract():
         m(torch.zeros(1, 3, 256, 512), torch.zeros(1, 4, 2))
     with pytest.raises(AssertionError):                       # COTR/models/backbone.py:80
         m(torch.zeros(1, 3, 256, 500), torch.zeros(1, 4, 2))
-    with pytest.raises(NotImplementedError):                  # training step is a later scope row
+    with pytest.raises(_lib.CotrHipError):                    # training mode: no CPU fallback either
         m.train()(torch.zeros(1, 3, 256, 512), torch.zeros(1, 4, 2))
+    with pytest.raises(NotImplementedError):                  # encode()/decode() are the inference split
+        m.train().encode(torch.zeros(1, 3, 256, 512))
+    with pytest.raises(NotImplementedError):                  # stages 2-3 (trainable backbone) are not implemented
+        m2 = build_model(cotr_amd.default_args(lr_backbone=1e-5)).train()
+        m2(torch.zeros(1, 3, 256, 512), torch.zeros(1, 4, 2))
     with pytest.raises(NotImplementedError):
         build_model(cotr_amd.default_args(layer='layer2', dim_feedforward=512))
     assert isinstance(NestedTensor(torch.zeros(1, 3, 256, 512), None).decompose()[0], torch.Tensor)
