@@ -71,3 +71,34 @@ class PairShardedModel:
         counts = [shard_range(Q, world, r)[1] - shard_range(Q, world, r)[0] for r in range(world)]
         finish, _ = all_gather_rows(local.transpose(0, 1).contiguous(), counts, self.group)  # rows = queries
         return {'pred_corrs': finish().transpose(0, 1).contiguous()}
+
+
+def sharded_zoom_engine(*args, group=None, **kwargs):
+    """``ZoomEngine`` whose zoom-in refinement is sharded over the ranks of ``group``: tasks (one query each) are
+    independent (COTR/inference/refinement_task.py: a task only sees its own crops), so every rank refines a contiguous
+    block with its own GPU and the per-task results (a few floats each) are all-gathered; no collective in the data path.
+    The dense initial pass, task generation and the early-exit bookkeeping are replicated (deterministic, same RNG
+    state on every rank), so all ranks return the same correspondences as a single-GPU run, bit for bit."""
+    from .inference.zoom_engine import RefineResult, ZoomEngine
+    import numpy as np
+
+    class ShardedZoomEngine(ZoomEngine):
+        def refine(self, img_a, img_b, loc_from, loc_to, *a, **kw):
+            if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+                return super().refine(img_a, img_b, loc_from, loc_to, *a, **kw)
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            loc_from = np.array(loc_from, dtype=np.float64).reshape(-1, 2)
+            loc_to = np.array(loc_to, dtype=np.float64).reshape(-1, 2)
+            lo, hi = shard_range(len(loc_from), world, rank)
+            local = super().refine(img_a, img_b, loc_from[lo:hi], loc_to[lo:hi], *a, **kw)
+            parts = [None] * world
+            dist.all_gather_object(parts, (local.loc_to, local.good, local.loc_history, local.steps, local.model_calls,
+                                           local.crops), group=group)
+            # every rank also counts the crops of the other ranks: total_tasks stays the whole job's number
+            self.total_tasks += sum(p[5] for r, p in enumerate(parts) if r != rank)
+            # RefineResult(loc_from, loc_to, good, loc_history [levels+1, N, 2], model_calls, crops, steps)
+            return RefineResult(loc_from, np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+                                np.concatenate([p[2] for p in parts], axis=1), max(p[4] for p in parts),
+                                sum(p[5] for p in parts), np.concatenate([p[3] for p in parts]))
+
+    return ShardedZoomEngine(*args, **kwargs)

@@ -60,3 +60,40 @@ def test_sharded_equals_single_process(tmp_path, B, Q):
         assert r0['calls'] == [(2, Q, 2)] and r1['calls'] == [(1, Q, 2)]     # pairs sharded 2 + 1
     else:
         assert r0['calls'] == [(1, 4, 2)] and r1['calls'] == [(1, 3, 2)]     # queries sharded 4 + 3
+
+
+# ---- zoom-in tasks sharded over ranks (cotr_amd.dist.sharded_zoom_engine) ------------------------------------------
+def _engine_worker(rank, world, port, golden_dir, out_dir):
+    import numpy as np
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from cotr_amd.dist import sharded_zoom_engine
+    from oracle.dense_post import host_dense_post_factory
+    from tests.engine_fixtures import CyclicFakeModel, FakeModel, pil_cropper_factory, synthetic_pair
+    from tests.test_zoom_engine_cpu import ZOOMS, run_dense_case
+    ok = True
+    g = np.load(os.path.join(golden_dir, 'engine_c3_filter.npz'))          # known-scale path, converge_iters = 3
+    seed, n, conv, force = (int(v) for v in g['meta'])
+    img_a, img_b = synthetic_pair(seed)
+    eng = sharded_zoom_engine(FakeModel(), max_pairs=16, make_cropper=pil_cropper_factory)
+    res = eng.refine(img_a, img_b, g['init'][:, :2], g['init'][:, 2:], 1.0, 1.0, ZOOMS, conv, force=bool(force))
+    ok &= np.array_equal(res.loc_history.transpose(1, 0, 2), g['loc_history']) and np.array_equal(res.loc_to, g['best'])
+    ok &= res.crops == int(g['total_tasks']) and eng.total_tasks == int(g['total_tasks'])
+    for name in ('engine_dense_default_c3', 'engine_cycle_queries'):           # default path incl. early exit
+        g = np.load(os.path.join(golden_dir, name + '.npz'))
+        eng = sharded_zoom_engine(CyclicFakeModel(), max_pairs=40, make_cropper=pil_cropper_factory,
+                                  make_dense_post=host_dense_post_factory)
+        out = run_dense_case(g, eng)
+        ok &= np.array_equal(out[0], g['corrs']) and np.array_equal(out[1], g['idx'])
+    torch.save(bool(ok), os.path.join(out_dir, f'e{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_sharded_zoom_engine_equals_reference_engine(tmp_path, golden_dir):
+    """Two ranks, each refining half of the tasks: every rank ends with the reference engine's golden result."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_engine_worker, args=(2, port, golden_dir, str(tmp_path)), nprocs=2, join=True)
+    assert all(torch.load(os.path.join(str(tmp_path), f'e{r}.pt')) for r in range(2))
