@@ -87,6 +87,51 @@ def kernel_breakdown(model, img, qs, step_ms, reps=5):
     return {'launches_per_forward': n_launch, 'event_overhead_us_per_launch': round(overhead * 1e3, 2), 'families': out}
 
 
+def other_regimes(sd, dev):
+    """NOT the headline: the same path (a) with three independent calls in flight (three handles, three streams - the
+    one-pair forward leaves CUs idle between its ~120 dependent launches) and (b) at the batched shapes the callers use."""
+    import cotr_amd
+    from cotr_amd.models import build_model
+    from cotr_amd.utils.synth import synth_inputs
+    out = {}
+    models = []
+    for _ in range(3):
+        m = build_model(cotr_amd.default_args()).to(dev).eval()
+        m.load_state_dict(sd)
+        models.append(m)
+    streams = [torch.cuda.Stream(device=dev) for _ in models]
+    img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1)
+    img, qs = img.to(dev), qs.to(dev)
+
+    def run(n):
+        for i in range(n):
+            with torch.cuda.stream(streams[i % 3]):
+                models[i % 3](img, qs)
+    run(30)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(150)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 150
+    out['three_calls_in_flight'] = {'ms_per_call': dt * 1e3, 'query_corr_per_s': QUERIES / dt,
+                                    'tflops': flop(1, QUERIES) / dt / 1e12}
+    m = models[0]
+    for tag, b, q, n in (('batch_32_pairs_x_1000_queries', 32, 1000, 5), ('engine_batch_32_pairs_x_1_query', 32, 1, 10)):
+        img, qs = synth_inputs(b, q, seed=2)
+        img, qs = img.to(dev), qs.to(dev)
+        for _ in range(2):
+            m(img, qs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            m(img, qs)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out[tag] = {'ms_per_call': dt * 1e3, 'query_corr_per_s': b * q / dt, 'pairs_per_s': b / dt,
+                    'tflops': flop(b, q) / dt / 1e12, 'frac_of_fp32_mfma_peak': flop(b, q) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+    return out
+
+
 def hbm_traffic_bytes():
     """HBM<->L2 bytes per forward from the committed rocprofv3 PMC passes (profiles/r1_pmc_hbm_traffic.txt:
     FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes), or None."""
@@ -223,6 +268,7 @@ def main():
                                             'WRITE_SIZE from profiles/r1_pmc_hbm_traffic.txt; minimum is 75.4 MB')
         if world == 1:
             line['roofline']['kernels'] = kernel_breakdown(model, img, qs, kernel_ms)
+            line['also_measured'] = other_regimes(synth_state_dict(0), dev)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
