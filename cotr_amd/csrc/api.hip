@@ -905,7 +905,7 @@ int cotr_set_ffn_fusion_max_rows(int rows) {
 }
 
 int cotr_set_attention_splits(int ns) {
-  if (ns != 0 && ns != 4 && ns != 8 && ns != 16) return COTR_ERR_ARG;
+  if (ns != 0 && ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16) return COTR_ERR_ARG;
   set_attention_splits(ns);
   return COTR_OK;
 }

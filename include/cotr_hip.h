@@ -174,7 +174,7 @@ int cotr_gemm_num_configs(void);
 int cotr_set_encode_chunk(int pairs);
 /* the fused FFN block (ffn.hip) is used for GEMMs with at most this many rows (default 1024); 0 = never */
 int cotr_set_ffn_fusion_max_rows(int rows);
-/* key splits (wavefronts per workgroup) of the attention kernel: 4, 8, 16, or 0 = automatic */
+/* key splits (wavefronts per workgroup) of the attention kernel: 1, 2, 4, 8, 16, or 0 = automatic */
 int cotr_set_attention_splits(int ns);
 /* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured
  * with HIP events around a captured graph of `iters` launches on a private stream */
