@@ -173,6 +173,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='only the timed steps (for rocprofv3 runs)')
+    ap.add_argument('--xcd-mapping', type=int, default=None, help='cotr_set_xcd_mapping policy (experiments)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -194,6 +196,9 @@ def main():
     from cotr_amd.models import build_model
     from cotr_amd.utils.synth import synth_state_dict, synth_inputs
 
+    if args.xcd_mapping is not None:
+        from cotr_amd import _lib
+        _lib.load_library().cotr_set_xcd_mapping(args.xcd_mapping)
     model = build_model(cotr_amd.default_args()).to(dev).eval()
     model.load_state_dict(synth_state_dict(0))
     img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1 + rank)
@@ -266,7 +271,7 @@ def main():
         line['roofline']['traffic'] = hbm_traffic_bytes()
         line['roofline']['traffic_note'] = ('bytes per forward crossing L2<->fabric (MALL/HBM), rocprofv3 PMC FETCH_SIZE x2 + '
                                             'WRITE_SIZE from profiles/r1_pmc_hbm_traffic.txt; minimum is 75.4 MB')
-        if world == 1:
+        if world == 1 and not args.no_extras:
             line['roofline']['kernels'] = kernel_breakdown(model, img, qs, kernel_ms)
             line['also_measured'] = other_regimes(synth_state_dict(0), dev)
         if world == 1 and not args.no_cpu_baseline:

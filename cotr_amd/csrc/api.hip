@@ -904,6 +904,18 @@ int cotr_set_ffn_fusion_max_rows(int rows) {
   return COTR_OK;
 }
 
+}  // extern "C"
+void set_attention_head_major(int v);  // attention.hip
+void set_ffn_chunk_major(int v);       // ffn.hip
+extern "C" {
+int cotr_set_xcd_mapping(int policy) {
+  if (policy < 0 || policy > 15 || (policy & 3) == 3) return COTR_ERR_ARG;
+  gemm_set_xcd_policy(policy & 3);
+  set_ffn_chunk_major((policy >> 2) & 1);
+  set_attention_head_major((policy >> 3) & 1);
+  return COTR_OK;
+}
+
 int cotr_set_attention_splits(int ns) {
   if (ns != 0 && ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16) return COTR_ERR_ARG;
   set_attention_splits(ns);

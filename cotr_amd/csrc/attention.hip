@@ -28,7 +28,7 @@ template <int NS>
 __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restrict__ q, int ldq,
                                                             const float* __restrict__ k,
                                                             const float* __restrict__ v, int ldkv,
-                                                            float* __restrict__ o, int ldo, int nq) {
+                                                            float* __restrict__ o, int ldo, int nq, int head_major) {
   constexpr int NBLK = ATT_KEYS / NS / 32;  // key blocks per wavefront
   constexpr int RPW = 16 / NS;              // accumulator rows finished per wavefront in the merge
   __shared__ float lds_o[NS][16][64];
@@ -39,8 +39,13 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, pair = blockIdx.z;
-  const int qi = blockIdx.x * 32 + l31;
+  // head_major: head index fastest over consecutive workgroups (8 heads <-> 8 XCDs), so K_h/V_h of a pair cross the
+  // fabric once chip-wide instead of once per XCD
+  const int qtiles = gridDim.x >> 3;
+  const int head = head_major ? (blockIdx.x & 7) : (blockIdx.x / qtiles);
+  const int qtile = head_major ? (blockIdx.x >> 3) : (blockIdx.x % qtiles);
+  const int pair = blockIdx.z;
+  const int qi = qtile * 32 + l31;
   const bool q_ok = qi < nq;
   const size_t qrow = (size_t)pair * nq + (q_ok ? qi : 0);
 
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
   __syncthreads();
   for (int i = t; i < 256; i += NS * 64) {  // 32 rows x 128 B, one float4 per thread: coalesced row stores
     const int row = i >> 3, c4 = (i & 7) * 4;
-    const int qo = blockIdx.x * 32 + row;
+    const int qo = qtile * 32 + row;
     if (qo < nq)
       *reinterpret_cast<f32x4*>(o + ((size_t)pair * nq + qo) * ldo + head * ATT_HD + c4) =
           *reinterpret_cast<const f32x4*>(&lds_out[row][c4]);
@@ -152,6 +157,8 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
 }
 
 static int g_att_splits = 0;  // 0 = automatic
+static int g_att_head_major = 0;  // measured: -88 MB of fabric traffic per forward, +0.4 % time -> off (cotr_set_xcd_mapping bit 3)
+void set_attention_head_major(int v) { g_att_head_major = v; }
 void set_attention_splits(int ns) { g_att_splits = ns; }
 
 int init_attention_attributes() { return 0; }
@@ -160,24 +167,24 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
                      int nb, int nq, hipStream_t s) {
   if (nb <= 0 || nq <= 0) return 0;
   if (ldq % 4 || ldkv % 4 || ldo % 4) return -1;
-  dim3 grid((nq + 31) / 32, 8, nb);
+  dim3 grid(((nq + 31) / 32) * 8, 1, nb);
   int ns = g_att_splits;
   if (ns == 0) ns = 4;
   switch (ns) {
     case 1:
-      hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(64), 0, s, q, ldq, k, v, ldkv, o, ldo, nq);
+      hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(64), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
       break;
     case 2:
-      hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(128), 0, s, q, ldq, k, v, ldkv, o, ldo, nq);
+      hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(128), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
       break;
     case 4:
-      hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq);
+      hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
       break;
     case 8:
-      hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(512), 0, s, q, ldq, k, v, ldkv, o, ldo, nq);
+      hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(512), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
       break;
     case 16:
-      hipLaunchKernelGGL(attention_kernel<16>, grid, dim3(1024), 0, s, q, ldq, k, v, ldkv, o, ldo, nq);
+      hipLaunchKernelGGL(attention_kernel<16>, grid, dim3(1024), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
       break;
     default:
       return -1;

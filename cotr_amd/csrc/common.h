@@ -50,13 +50,43 @@ struct GemmParams {
   float colscale;
   int colscale_n;
   const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
+  int xcd_msplit;      // workgroup -> tile mapping, see gemm_tile_coords
 };
+
+// blockIdx -> (row tile, column tile).  Consecutive workgroups land on consecutive XCDs (8, each with its own 4 MB L2), so the
+// mapping decides which operand every XCD's L2 pulls a private copy of through the fabric:
+//   default  column tile fastest: with tiles_n a multiple of 8 an XCD owns 1/8 of the column tiles and walks ALL row tiles:
+//            W crosses the fabric once chip-wide, the activations once per XCD (right when weights >> activations: layer3,
+//            the transformer at one pair)
+//   M-split  an XCD owns every 8th ROW tile and walks all column tiles: activations once chip-wide, W once per XCD
+//            (right when the activation operand is the larger one: layer1/layer2 at any batch, everything when batched)
+// Time-neutral at one pair (the path is latency-bound there); it is what the L2<->fabric byte counters see.
+__device__ __forceinline__ bool gemm_tile_coords(const GemmParams& p, int bm, int bn, int& m0, int& n0) {
+  const int tiles_n = p.N / bn;
+  const int bid = blockIdx.x;
+  if (p.xcd_msplit) {
+    const int tiles_m = (p.M + bm - 1) / bm;
+    const int mt = (bid / (8 * tiles_n)) * 8 + (bid & 7);
+    if (mt >= tiles_m) return false;
+    m0 = mt * bm;
+    n0 = ((bid >> 3) % tiles_n) * bn;
+  } else {
+    m0 = (bid / tiles_n) * bm;
+    n0 = (bid % tiles_n) * bn;
+  }
+  return true;
+}
+static inline int gemm_grid_tiles(const GemmParams& p, int bm, int bn) {
+  const int tiles_m = (p.M + bm - 1) / bm;
+  return (p.xcd_msplit ? (tiles_m + 7) / 8 * 8 : tiles_m) * (p.N / bn);
+}
 
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s);            // tuned / modelled config
 int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s);  // explicit config (tuning, tests)
 int gemm_pick_config(int mode, const GemmParams& p);
 int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s);  // gemm_big.hip: 0 = 128x128, 1 = 128x64
 int gemm_num_configs();
+void gemm_set_xcd_policy(int v);  // 0 column tiles over XCDs, 1 by operand size (default), 2 row tiles over XCDs
 bool gemm_cfg_supports_ln(int cfg);
 const float* gemm_zero_buffer();  // per-process device buffer of zeros (LDS-DMA padding source)
 

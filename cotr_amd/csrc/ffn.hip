@@ -26,7 +26,7 @@ struct FfnParams {
   const float* W2;   // [256][1024]
   float* P;          // [nch][M][256] partial outputs
   const float* zeros;
-  int M, nch;
+  int M, nch, chunk_major;
 };
 
 __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
@@ -38,8 +38,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int m0 = blockIdx.x * 32;
-  const int chunk = blockIdx.y;
+  // chunk_major: chunk index fastest over consecutive workgroups (= consecutive XCDs): an XCD works on 1/8 of the hidden
+  // units, so W1/W2 (2 MB per block) cross the fabric once chip-wide instead of once per XCD; X (<= 1 MB) is replicated
+  const int tiles = gridDim.x / p.nch;
+  const int chunk = p.chunk_major ? blockIdx.x % p.nch : blockIdx.x / tiles;
+  const int m0 = (p.chunk_major ? blockIdx.x / p.nch : blockIdx.x % tiles) * 32;
   const int hw = FF_H / p.nch;            // hidden units of this workgroup
   const int h0 = chunk * hw;
   const int nsub = hw / 64;
@@ -131,6 +134,9 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
 
 static const size_t kFfnSmem = (size_t)(32 * FF_LD + 64 * FF_LD + 8 * 16 * 64 + 32 * FF_HLD) * sizeof(float);
 
+static int g_ffn_chunk_major = 0;  // measured: -112 MB of fabric traffic per forward but +2 % time -> off (cotr_set_xcd_mapping bit 2)
+void set_ffn_chunk_major(int v) { g_ffn_chunk_major = v; }
+
 // hidden-unit chunks per row tile: enough workgroups to cover the 256 CUs, at most 16 partial outputs
 int ffn_fused_chunks(int M) {
   const int tiles = (M + 31) / 32;
@@ -151,8 +157,8 @@ int launch_ffn_fused(const float* X, const float* W1, const float* b1, const flo
     attr_set = true;
   }
   FfnParams p;
-  p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch;
+  p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch; p.chunk_major = g_ffn_chunk_major;
   if (p.zeros == nullptr) return -2;
-  hipLaunchKernelGGL(ffn_fused_kernel, dim3((M + 31) / 32, nch), dim3(512), kFfnSmem, s, p);
+  hipLaunchKernelGGL(ffn_fused_kernel, dim3(((M + 31) / 32) * nch), dim3(512), kFfnSmem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -32,11 +32,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   float* Ws = smem + BM * LDSLD;
 
   const int t = threadIdx.x;
-  // column tile fastest: consecutive workgroups (= consecutive XCDs) share a row tile; with tiles_n a multiple of
-  // 8 an XCD owns 1/8 of the column tiles, so W is fetched once chip-wide (a row-split alternative measured neutral)
-  const int tiles_n = p.N / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM;
-  const int n0 = (blockIdx.x % tiles_n) * BN;
+  int m0, n0;
+  if (!gemm_tile_coords(p, BM, BN, m0, n0)) return;
   const int lr = t >> 3, lc = (t & 7) * 4;
   const int KT = p.K / BK;
 
@@ -254,9 +251,8 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int t = threadIdx.x;
-  const int tiles_n = p.N / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM;
-  const int n0 = (blockIdx.x % tiles_n) * BN;
+  int m0, n0;
+  if (!gemm_tile_coords(p, BM, BN, m0, n0)) return;
   const int lr = t / C4, lc4 = t % C4;
   const int ktl = lc4 >> 3;            // which 32-wide k-tile of the step this thread loads
   const int lcc = (lc4 & 7) * 4;       // column inside that k-tile
@@ -586,8 +582,7 @@ template <int WM, int WN, int TM, int TN, int MODE>
 static int launch_t(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int tiles = tiles_m * (p.N / BN);
+  const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, MODE>), dim3(tiles), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -612,8 +607,7 @@ static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
       return -2;
     attr_set = true;
   }
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int tiles = tiles_m * (p.N / BN);
+  const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles), dim3(NWK * 64), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -751,8 +745,21 @@ int gemm_pick_config(int mode, const GemmParams& p) {
   return best;
 }
 
-int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s) {
-  if (p.N % 16 != 0 || cfg < 0 || cfg >= kNumCfgs || !cfg_fits(cfg, p)) return -1;
+static int g_xcd_policy = 1;  // 0 = column tiles over XCDs always, 1 = by operand size, 2 = row tiles over XCDs always
+void gemm_set_xcd_policy(int v) { g_xcd_policy = v; }
+
+int launch_gemm_cfg(int mode, int cfg, const GemmParams& p0, hipStream_t s) {
+  if (p0.N % 16 != 0 || cfg < 0 || cfg >= kNumCfgs || !cfg_fits(cfg, p0)) return -1;
+  GemmParams p = p0;
+  {
+    // which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
+    const GemmCfg& c = kCfgs[cfg];
+    const int bm = c.kind == 4 ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
+    const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
+    const double w_bytes = (double)p.N * p.K * 4.0;
+    const bool fits = (p.M + bm - 1) / bm >= 8;
+    p.xcd_msplit = mode != GEMM_STEM && fits && (g_xcd_policy == 2 || (g_xcd_policy == 1 && a_bytes >= 2.0 * w_bytes));
+  }
   switch (mode) {
     case GEMM_DENSE:
       if (p.lda % 4 != 0 || (p.A2 && p.lda2 % 4 != 0)) return -1;

@@ -28,9 +28,8 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int tiles_n = p.N / BN;
-  const int m0 = (blockIdx.x / tiles_n) * BM;
-  const int n0 = (blockIdx.x % tiles_n) * BN;
+  int m0, n0;
+  if (!gemm_tile_coords(p, BM, BN, m0, n0)) return;
   const int KT = p.K / BK;
 
   // ---- LDS-DMA bookkeeping: lane -> (row lane>>3 of the instruction's 8 rows, physical 16-B chunk lane&7) ----
@@ -211,7 +210,7 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
       return -2;
     attr_set = true;
   }
-  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_big_kernel<TN, MODE>), dim3(tiles), dim3(256), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -174,6 +174,13 @@ int cotr_gemm_num_configs(void);
 int cotr_set_encode_chunk(int pairs);
 /* the fused FFN block (ffn.hip) is used for GEMMs with at most this many rows (default 1024); 0 = never */
 int cotr_set_ffn_fusion_max_rows(int rows);
+/* workgroup -> XCD mapping (which operand crosses the fabric once chip-wide instead of once per XCD), a bit field:
+ *   bits 0-1  GEMM / conv kernels: 0 = column tiles spread over the 8 XCDs (weights once, activations per XCD),
+ *             2 = row tiles spread over the XCDs (the other way round), 1 = per launch by operand size
+ *   bit 2     fused FFN: hidden-unit chunks spread over the XCDs (W1/W2 once) instead of row tiles
+ *   bit 3     attention: heads spread over the XCDs (K_h/V_h once) instead of query tiles
+ * Experiments / profiling only; see DESIGN.md for the measured trade-off. */
+int cotr_set_xcd_mapping(int policy);
 /* key splits (wavefronts per workgroup) of the attention kernel: 1, 2, 4, 8, 16, or 0 = automatic */
 int cotr_set_attention_splits(int ns);
 /* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured

@@ -8,7 +8,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   out=$root/gpurun_out/pmc_${tag}_$ctr
   mkdir -p $out
   cd /tmp
-  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -o $tag -- python $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/run.log 2>&1
+  rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $out -o $tag -- python $root/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras $PMC_EXTRA > $out/run.log 2>&1
   cd $root
   ls $out | head
 done
