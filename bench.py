@@ -175,6 +175,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='only the timed steps (for rocprofv3 runs)')
     ap.add_argument('--xcd-mapping', type=int, default=None, help='cotr_set_xcd_mapping policy (experiments)')
+    ap.add_argument('--fused-stem', type=int, default=None, help='cotr_set_fused_stem (experiments)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -199,6 +200,9 @@ def main():
     if args.xcd_mapping is not None:
         from cotr_amd import _lib
         _lib.load_library().cotr_set_xcd_mapping(args.xcd_mapping)
+    if args.fused_stem is not None:
+        from cotr_amd import _lib
+        _lib.load_library().cotr_set_fused_stem(args.fused_stem)
     model = build_model(cotr_amd.default_args()).to(dev).eval()
     model.load_state_dict(synth_state_dict(0))
     img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1 + rank)

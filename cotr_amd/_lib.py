@@ -39,6 +39,7 @@ _PROTOS = {
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_stem': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_stem_pool': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_maxpool': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p]),
     'cotr_op_attention': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int, c_float_p,
@@ -59,6 +60,7 @@ _PROTOS = {
     'cotr_set_ffn_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_splits': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_fused_stem': (ctypes.c_int, [ctypes.c_int]),
     'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     'cotr_bench_conv': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 9 +

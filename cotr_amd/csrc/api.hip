@@ -148,6 +148,8 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
   return COTR_OK;
 }
 
+bool g_fused_stem = true;  // cotr_set_fused_stem
+
 GemmParams base_params() {
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -518,9 +520,15 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     const float* img_c = img + (size_t)b0 * 3 * 256 * 512;
     // ---- backbone -------------------------------------------------------------------------
     int ci = 0;
-    { int r = stem(h, h->convs[ci++], img_c, b_stem, Bc, s); if (r) return r; }
-    KCHK(h, launch_maxpool(b_stem, b_pool, Bc, 128, 128, 64, s), "maxpool");
-    prof_mark(h, "maxpool", s, 2);
+    if (g_fused_stem && !h->keep_taps) {  // conv1 + bn1 + relu + maxpool in one launch; the 'stem' tap needs the unfused pair
+      const ConvW& c0 = h->convs[ci++];
+      KCHK(h, launch_stem_pool(img_c, c0.w, 160, c0.scale, c0.bias, b_pool, Bc, s), "stem_pool");
+      prof_mark(h, "stem_pool conv7x7+bn+relu+maxpool", s, 2);
+    } else {
+      { int r = stem(h, h->convs[ci++], img_c, b_stem, Bc, s); if (r) return r; }
+      KCHK(h, launch_maxpool(b_stem, b_pool, Bc, 128, 128, 64, s), "maxpool");
+      prof_mark(h, "maxpool", s, 2);
+    }
     prof_mark(h, "stem+pool", s);
     if (int r = tap_save(h, "stem", b_stem, n_stem * Bc, s)) return r;
     if (int r = tap_save(h, "pool", b_pool, n_pool * Bc, s)) return r;
@@ -830,6 +838,11 @@ int cotr_op_stem(const float* img, const float* w, const float* scale, const flo
   return op_ret(launch_gemm(GEMM_STEM, p, static_cast<hipStream_t>(stream)));
 }
 
+int cotr_op_stem_pool(const float* img, const float* w, const float* scale, const float* bias, float* y, int B,
+                      cotr_stream stream) {
+  return op_ret(launch_stem_pool(img, w, 160, scale, bias, y, B, static_cast<hipStream_t>(stream)));
+}
+
 int cotr_op_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, cotr_stream stream) {
   return op_ret(launch_maxpool(x, y, B, Hin, Win, C, static_cast<hipStream_t>(stream)));
 }
@@ -908,6 +921,11 @@ int cotr_set_ffn_fusion_max_rows(int rows) {
 void set_attention_head_major(int v);  // attention.hip
 void set_ffn_chunk_major(int v);       // ffn.hip
 extern "C" {
+int cotr_set_fused_stem(int enable) {
+  g_fused_stem = enable != 0;
+  return COTR_OK;
+}
+
 int cotr_set_xcd_mapping(int policy) {
   if (policy < 0 || policy > 15 || (policy & 3) == 3) return COTR_ERR_ARG;
   gemm_set_xcd_policy(policy & 3);

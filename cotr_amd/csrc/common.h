@@ -103,6 +103,10 @@ int launch_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, hip
 int launch_head2(const float* x, const float* w, const float* b, float* y, int nb, int nq, int q_total,
                  hipStream_t s);
 
+// conv1 7x7/2 + FrozenBN + ReLU + maxpool 3x3/2 in one launch (stem_pool.hip): img NCHW [B,3,256,512] -> [B,64,128,64]
+int launch_stem_pool(const float* img, const float* w, int wk, const float* scale, const float* bias, float* out, int B,
+                     hipStream_t s);
+
 // batched crop + Pillow-bilinear resize to 256x256 + side-by-side + ImageNet normalise (crop_resize.hip)
 int launch_crop_resize(const uint8_t* img_a, int ha, int wa, const uint8_t* img_b, int hb, int wb,
                        const int32_t* boxes, int n, float* out, int max_size, hipStream_t s);

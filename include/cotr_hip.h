@@ -123,6 +123,9 @@ int cotr_op_conv(const float* x, const float* w, const float* scale, const float
 int cotr_op_stem(const float* img, const float* w, const float* scale, const float* bias, float* y, int B,
                  cotr_stream stream);
 int cotr_op_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, cotr_stream stream);
+/* conv1 + FrozenBN + ReLU + maxpool fused (stem_pool.hip): img [B,3,256,512] NCHW, w [64][160] -> y [B,64,128,64] NHWC sbs */
+int cotr_op_stem_pool(const float* img, const float* w, const float* scale, const float* bias, float* y, int B,
+                      cotr_stream stream);
 /* q [nb*nq, ldq] (pre-scaled), k/v [nb*512, ldkv]; 8 heads x 32; o [nb*nq, ldo] */
 int cotr_op_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
                       int nb, int nq, cotr_stream stream);
@@ -174,6 +177,9 @@ int cotr_gemm_num_configs(void);
 int cotr_set_encode_chunk(int pairs);
 /* the fused FFN block (ffn.hip) is used for GEMMs with at most this many rows (default 1024); 0 = never */
 int cotr_set_ffn_fusion_max_rows(int rows);
+/* 1 (default): conv1 + bn1 + relu + maxpool of the ResNet stem as one launch (stem_pool.hip); 0: implicit-GEMM stem + separate
+ * max-pool kernel (also used whenever debug taps are on: the 'stem' tap is the un-pooled conv output) */
+int cotr_set_fused_stem(int enable);
 /* workgroup -> XCD mapping (which operand crosses the fabric once chip-wide instead of once per XCD), a bit field:
  *   bits 0-1  GEMM / conv kernels: 0 = column tiles spread over the 8 XCDs (weights once, activations per XCD),
  *             2 = row tiles spread over the XCDs (the other way round), 1 = per launch by operand size

@@ -82,6 +82,11 @@ def test_stem_conv7x7_and_maxpool():
     assert lib.cotr_op_maxpool(G.P(y), G.P(yp), 2, 128, 128, 64, G.sptr()) == 0
     e = G.rel_err(G.sbs_to_nchw(yp.cpu()), ref_pool)
     assert e < 2e-5, e
+    # the one-launch version of the same two ops (stem_pool.hip)
+    yf = torch.full((2, 64, 128, 64), float('nan'), device=d)
+    assert lib.cotr_op_stem_pool(G.P(img_d), G.P(wp_d), G.P(sc_d), G.P(b_d), G.P(yf), 2, G.sptr()) == 0
+    e = G.rel_err(G.sbs_to_nchw(yf.cpu()), ref_pool)
+    assert e < 2e-5, e
 
 
 @pytest.mark.parametrize('nb,nq,gain', [(2, 200, 1.0), (1, 512, 1.0), (3, 1, 1.0), (1, 129, 6.0)])
