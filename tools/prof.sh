@@ -7,6 +7,6 @@ root=$PWD
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $out -o $tag -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $out/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv rocpd -d $out -o $tag -- python $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras "$@" > $out/run.log 2>&1
 cd $root
 ls $out | head -30
