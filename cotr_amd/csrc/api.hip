@@ -149,6 +149,7 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
 }
 
 bool g_fused_stem = true;  // cotr_set_fused_stem
+bool g_ffn_tail = false;   // cotr_set_ffn_tail: measured slower, off
 
 GemmParams base_params() {
   GemmParams p;
@@ -188,6 +189,11 @@ int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, c
               const float* nw, const float* nb, float* hid, float* tmp, float* y, int M, hipStream_t s) {
   if (M <= g_ffn_fuse_max_rows) {
     const int nch = ffn_fused_chunks(M);
+    if (g_ffn_tail) {  // partial sums + bias + residual + LayerNorm by the last workgroup of each row tile: one launch
+      KCHK(h, launch_ffn_fused_ln(x, l1w, l1b, l2w, hid, M, nch, l2b, x, nw, nb, y, s), "ffn_fused_ln");
+      if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused+ln %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
+      return COTR_OK;
+    }
     KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
     if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
     KCHK(h, launch_ln_reduce(hid, nch, l2b, x, nw, nb, y, M, s), "ln_reduce");
@@ -921,6 +927,11 @@ int cotr_set_ffn_fusion_max_rows(int rows) {
 void set_attention_head_major(int v);  // attention.hip
 void set_ffn_chunk_major(int v);       // ffn.hip
 extern "C" {
+int cotr_set_ffn_tail(int enable) {
+  g_ffn_tail = enable != 0;
+  return COTR_OK;
+}
+
 int cotr_set_fused_stem(int enable) {
   g_fused_stem = enable != 0;
   return COTR_OK;
@@ -1017,6 +1028,7 @@ int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const fl
                       const float* ln_b, float* scratch, float* y, int M, cotr_stream stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nch = ffn_fused_chunks(M);
+  if (g_ffn_tail) return op_ret(launch_ffn_fused_ln(x, w1, b1, w2, scratch, M, nch, b2, x, ln_w, ln_b, y, s));
   int r = launch_ffn_fused(x, w1, b1, w2, scratch, M, nch, s);
   if (r == 0) r = launch_ln_reduce(scratch, nch, b2, x, ln_w, ln_b, y, M, s);
   return op_ret(r);

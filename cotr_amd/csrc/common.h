@@ -121,5 +121,8 @@ int launch_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int H
 // fused feed-forward block (ffn.hip) and its reduce + bias + residual + LayerNorm tail (pointwise.hip)
 int ffn_fused_chunks(int M);
 int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch, hipStream_t s);
+// same + the reduce / bias / residual / LayerNorm tail inside the kernel (last-arriving workgroup of a row tile)
+int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                        const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
 int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                      float* y, int rows, hipStream_t s);

@@ -27,7 +27,22 @@ struct FfnParams {
   float* P;          // [nch][M][256] partial outputs
   const float* zeros;
   int M, nch, chunk_major;
+  // tail (optional): the LAST of the nch workgroups of a row tile to finish sums the partial outputs in chunk order, adds
+  // bias + residual and applies LayerNorm - what ln_reduce_kernel does in a second launch.  No workgroup waits for
+  // another (arrival counter per row tile, reset by the last arriver), the sum order is fixed: same bits as ln_reduce.
+  int* counters;     // [row tiles], zero between launches; nullptr = no tail
+  const float* b2;   // linear2 bias [256]
+  const float* residual;  // [M][256]
+  const float* ln_w;
+  const float* ln_b;
+  float* Y;          // [M][256]
 };
+
+__device__ __forceinline__ float ffn_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
 
 __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -128,8 +143,49 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    if (m < p.M) out[(size_t)m * FF_D + 32 * wave + l31] = acc2[r];
+    if (m < p.M) {
+      // with the tail, partials are exchanged between workgroups of different XCDs inside this launch: agent-scope
+      // (sc1) stores / loads go to the memory side and bypass the per-XCD L2s, so no L2 write-back / invalidate is needed
+      // (a __threadfence() pair here cost ~50 us per launch)
+      if (p.counters != nullptr)
+        __hip_atomic_store(&out[(size_t)m * FF_D + 32 * wave + l31], acc2[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        out[(size_t)m * FF_D + 32 * wave + l31] = acc2[r];
+    }
   }
+
+  if (p.counters == nullptr) return;
+  // ---- tail: last arriver of this row tile reduces + normalises ----------------------------------------------------
+  __shared__ int s_last;
+  __builtin_amdgcn_s_waitcnt(0);                     // this thread's partial stores have reached the memory side ...
+  __syncthreads();                                   // ... and so have everybody's, before the arrival is counted
+  const int tile = m0 / 32;
+  if (t == 0) s_last = (atomicAdd(&p.counters[tile], 1) == p.nch - 1);
+  __syncthreads();
+  if (!s_last) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wave * 4 + i;
+    if (row >= p.M) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.b2 + lane * 4);
+    v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * FF_D + lane * 4);
+    for (int c = 0; c < p.nch; ++c) {
+      const float* src = p.P + ((size_t)c * p.M + row) * FF_D + lane * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float mean = ffn_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+    const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+    const float var = ffn_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(p.ln_w + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + lane * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = d[e] * rstd * ww[e] + bb[e];
+    *reinterpret_cast<f32x4*>(p.Y + (size_t)row * FF_D + lane * 4) = o;
+  }
+  if (t == 0) p.counters[tile] = 0;                  // everybody has arrived: ready for the next launch
 }
 
 static const size_t kFfnSmem = (size_t)(32 * FF_LD + 64 * FF_LD + 8 * 16 * 64 + 32 * FF_HLD) * sizeof(float);
@@ -145,8 +201,28 @@ int ffn_fused_chunks(int M) {
   return nch;
 }
 
+// per-process arrival counters of the tail (1024 rows / 32 = at most 32 row tiles are ever fused)
+static int* ffn_counters() {
+  static int* c = nullptr;
+  if (c == nullptr) {
+    if (hipMalloc(reinterpret_cast<void**>(&c), 4096) != hipSuccess) return nullptr;
+    if (hipMemset(c, 0, 4096) != hipSuccess) return nullptr;
+  }
+  return c;
+}
+
+int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                        const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
+
 int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
                      hipStream_t s) {
+  return launch_ffn_fused_ln(X, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+// with b2 != nullptr the kernel also does  Y = LayerNorm(residual + sum of partials + b2)  (no second launch)
+int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                        const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y,
+                        hipStream_t s) {
   if (M <= 0) return 0;
   if (nch < 1 || nch > 16 || FF_H % (nch * 64) != 0) return -1;
   static bool attr_set = false;
@@ -158,6 +234,12 @@ int launch_ffn_fused(const float* X, const float* W1, const float* b1, const flo
   }
   FfnParams p;
   p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch; p.chunk_major = g_ffn_chunk_major;
+  p.counters = nullptr; p.b2 = b2; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y;
+  if (b2 != nullptr) {
+    if (!residual || !ln_w || !ln_b || !Y || (M + 31) / 32 > 1024) return -1;
+    p.counters = ffn_counters();
+    if (p.counters == nullptr) return -2;
+  }
   if (p.zeros == nullptr) return -2;
   hipLaunchKernelGGL(ffn_fused_kernel, dim3(((M + 31) / 32) * nch), dim3(512), kFfnSmem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -177,6 +177,10 @@ int cotr_gemm_num_configs(void);
 int cotr_set_encode_chunk(int pairs);
 /* the fused FFN block (ffn.hip) is used for GEMMs with at most this many rows (default 1024); 0 = never */
 int cotr_set_ffn_fusion_max_rows(int rows);
+/* 1: the fused FFN kernel also sums its partial outputs and applies bias + residual + LayerNorm (last-arriving workgroup
+ * of each row tile; same bits as the separate ln_reduce launch); 0 (default): two launches - the single-launch form
+ * measured SLOWER (one CU has to pull the 512 KB of partials of its row tile), see DESIGN.md 4b */
+int cotr_set_ffn_tail(int enable);
 /* 1 (default): conv1 + bn1 + relu + maxpool of the ResNet stem as one launch (stem_pool.hip); 0: implicit-GEMM stem + separate
  * max-pool kernel (also used whenever debug taps are on: the 'stem' tap is the un-pooled conv output) */
 int cotr_set_fused_stem(int enable);

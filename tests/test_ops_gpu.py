@@ -158,6 +158,38 @@ def test_fused_ffn_block(M):
     assert e < 2e-5, e
 
 
+def test_ffn_tail_equals_separate_reduce_launch():
+    """The in-kernel tail of the fused FFN (last-arriving workgroup of a row tile sums the partial outputs in chunk order,
+    adds bias + residual, LayerNorm) gives the SAME BITS as the separate ln_reduce launch, launch after launch with
+    changing inputs (stale partials of the previous launch in another XCD's L2 would show up here)."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    d = G.dev()
+    g = _g(77)
+    for M in (512, 1000, 33):
+        w1, b1 = (torch.randn(1024, 256, generator=g) / 16).to(d), (torch.randn(1024, generator=g) * 0.1).to(d)
+        w2, b2 = (torch.randn(256, 1024, generator=g) / 32).to(d), (torch.randn(256, generator=g) * 0.1).to(d)
+        lw, lb = (torch.rand(256, generator=g) + 0.5).to(d), (torch.randn(256, generator=g) * 0.1).to(d)
+        scratch = torch.empty(lib.cotr_op_ffn_chunks(M) * M * 256, device=d)
+        xs = [torch.randn(M, 256, generator=g).to(d) for _ in range(12)]
+        outs = {}
+        try:
+            for tail in (0, 1):
+                assert lib.cotr_set_ffn_tail(tail) == 0
+                ys = []
+                for x in xs:                                   # back to back on the stream, same scratch and counters
+                    y = torch.empty(M, 256, device=d)
+                    assert lib.cotr_op_ffn_block(G.P(x), G.P(w1), G.P(b1), G.P(w2), G.P(b2), G.P(lw), G.P(lb), G.P(scratch),
+                                                 G.P(y), M, G.sptr()) == 0
+                    ys.append(y)
+                torch.cuda.synchronize()
+                outs[tail] = ys
+        finally:
+            lib.cotr_set_ffn_tail(0)
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b), M
+
+
 # ---- every launch configuration of the GEMM / implicit-GEMM kernels on the same problem -----------------------------
 def _cfgs():
     from cotr_amd import _lib
