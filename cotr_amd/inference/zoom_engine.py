@@ -506,3 +506,23 @@ class ZoomEngine:
         if return_cycle_error:
             out.append(cycle_errors[order][:max_corrs])
         return out[0] if len(out) == 1 else out
+
+
+class SparseEngine(ZoomEngine):
+    """Same constructor as ``COTR.inference.sparse_engine.SparseEngine(model, batch_size, mode='stretching')`` (:18-21), so
+    the reference's demos switch engines by changing one import; ``batch_size`` only decides where the early exit falls
+    (the reference's group size), the launches themselves are one per zoom level."""
+
+    def __init__(self, model, batch_size, mode='stretching'):
+        super().__init__(model, batch_size=batch_size, mode=mode)
+
+
+class FasterSparseEngine(SparseEngine):
+    """Constructor of ``COTR.inference.sparse_engine.FasterSparseEngine`` (:273-276).  The reference's version merges
+    nearby tasks into shared crops to save model calls ("it will make spatial accuracy slightly worse", :268-271); here
+    every task keeps its own crop - whole zoom levels are batched instead - so results are those of ``SparseEngine``.
+    ``max_load`` is accepted for signature compatibility and ignored."""
+
+    def __init__(self, model, batch_size, mode='stretching', max_load=256):
+        super().__init__(model, batch_size, mode)
+        self.max_load = max_load

@@ -142,3 +142,16 @@ def test_reference_schedule_emulation():
         for known in range(0, n, 37):
             got = _reference_schedule(steps[:known], good[:known], 32, max_corrs, n)
             assert got is None or np.array_equal(got, want[:known])
+
+
+def test_reference_constructor_signatures(golden_dir):
+    """SparseEngine(model, 32, mode='tile') / FasterSparseEngine(model, 32, 'tile', max_load=256) as the demos build them
+    (demo_single_pair.py:35, demo_reconstruction.py) give the reference SparseEngine's golden result."""
+    from cotr_amd.inference import FasterSparseEngine, SparseEngine
+    from tests.engine_fixtures import CyclicFakeModel
+    g = np.load(os.path.join(golden_dir, 'engine_cycle_default.npz'))
+    for eng in (SparseEngine(CyclicFakeModel(), 32, mode='tile'), FasterSparseEngine(CyclicFakeModel(), 32, 'tile', max_load=256)):
+        eng.make_cropper, eng.make_dense_post = pil_cropper_factory, host_dense_post_factory
+        out = run_dense_case(g, eng)
+        assert np.array_equal(out[0], g['corrs']) and np.array_equal(out[2], g['cycle_error'])
+    assert SparseEngine(CyclicFakeModel(), 32).mode == 'stretching'        # the reference's default (sparse_engine.py:18)
