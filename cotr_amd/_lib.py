@@ -23,6 +23,7 @@ _PROTOS = {
                                          ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_int]),
     'cotr_encode': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_backbone': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_void_p]),
+    'cotr_backbone_upto': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p]),
     'cotr_decode': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_void_p]),
     'cotr_forward': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p,
                                     ctypes.c_void_p]),

@@ -475,7 +475,7 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
 
 // feat_out == nullptr: the whole query-independent half (cotr_encode); otherwise only the backbone, its layer3 output
 // [B,16,32,1024] (NHWC, both halves side by side = 512 token rows per pair) copied to feat_out (cotr_backbone)
-static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream stream, float* feat_out) {
+static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream stream, float* feat_out, int upto = 3) {
   if (!h) return COTR_ERR_ARG;
   if (!h->loaded) { h->err = "cotr_encode before cotr_load_weights"; return COTR_ERR_STATE; }
   if (!img || B <= 0) { h->err = "cotr_encode: null image or B <= 0"; return COTR_ERR_ARG; }
@@ -566,12 +566,14 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       const char* names[3] = {"layer1", "layer2", "layer3"};
       if (int r = tap_save(h, names[st], x, (size_t)Bc * H * 2 * W * kStages[st].planes * 4, s)) return r;
       prof_mark(h, names[st], s);
+      if (feat_out && st + 1 == upto) {  // cotr_backbone: [Bc, H, 2W, 4*planes] of this stage, NHWC over the pair
+        const size_t per_pair = (size_t)H * 2 * W * kStages[st].planes * 4;
+        HIPCHK(h, hipMemcpyAsync(feat_out + (size_t)b0 * per_pair, x, (size_t)Bc * per_pair * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+        break;
+      }
     }
-    if (feat_out) {
-      HIPCHK(h, hipMemcpyAsync(feat_out + (size_t)b0 * TOK * CFEAT, x, (size_t)Bc * TOK * CFEAT * sizeof(float),
-                               hipMemcpyDeviceToDevice, s));
-      continue;
-    }
+    if (feat_out) continue;
     // ---- input_proj: x is [Bc*512, 1024] --------------------------------------------------
     const int M = Bc * TOK;
     int r;
@@ -612,6 +614,11 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) { re
 int cotr_backbone(cotr_handle h, const float* img, int B, float* features, cotr_stream stream) {
   if (!features) return COTR_ERR_ARG;
   return encode_impl(h, img, B, stream, features);
+}
+
+int cotr_backbone_upto(cotr_handle h, const float* img, int B, int stage, float* features, cotr_stream stream) {
+  if (!features || stage < 1 || stage > 3) return COTR_ERR_ARG;
+  return encode_impl(h, img, B, stream, features, stage);
 }
 
 }  // extern "C"

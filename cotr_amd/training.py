@@ -1,5 +1,6 @@
-"""Training step for the reference's stage 1 (frozen backbone, ``train_cotr.py --lr_backbone=0``) - SURVEY.md 8f row 4,
-FIRST VERSION.
+"""Training step, FIRST VERSION: the reference's stage 1 (frozen backbone, ``train_cotr.py
+--lr_backbone=0``) and, with layer2 / layer3 of the backbone as torch convolutions under autograd, its stages 2-3
+(``--lr_backbone > 0``).
 
 What runs where:
 * backbone (ResNet-50 to layer3, FrozenBN; 70 % of the forward FLOPs, no gradient in stage 1): the hand-written HIP
@@ -137,19 +138,58 @@ def backbone_features(model, img):
     return feat
 
 
+def _frozen_bn(x, bn):
+    """FrozenBatchNorm2d.forward (COTR/models/backbone.py:46-56): buffers only, no gradient of its own."""
+    scale = bn.weight * (bn.running_var + 1e-5).rsqrt()
+    return x * scale.view(1, -1, 1, 1) + (bn.bias - bn.running_mean * scale).view(1, -1, 1, 1)
+
+
+def _bottleneck(x, blk):
+    """torchvision ResNet v1.5 Bottleneck (stride on the 3x3) with FrozenBN, as the reference's backbone body builds it."""
+    out = F.relu(_frozen_bn(blk.conv1(x), blk.bn1))
+    out = F.relu(_frozen_bn(blk.conv2(out), blk.bn2))
+    out = _frozen_bn(blk.conv3(out), blk.bn3)
+    idt = _frozen_bn(blk.downsample[0](x), blk.downsample[1]) if hasattr(blk, 'downsample') else x
+    return F.relu(out + idt)
+
+
+def backbone_features_trainable(model, img):
+    """Stages 2-3 of the reference's recipe (--lr_backbone > 0): only layer2 / layer3 train (backbone.py:66-69), so conv1 +
+    layer1 still run on the HIP kernels (cotr_backbone_upto, no gradient) and layer2 / layer3 run as torch convolutions under
+    autograd, each 256-wide half on its own like BackboneBase.forward (backbone.py:79-92).  -> [B*512, 1024] with graph."""
+    lib = model._ensure_ready(img.device)
+    img = img.detach().contiguous().float()
+    b = img.shape[0]
+    l1 = torch.empty((b, 64, 128, 256), dtype=torch.float32, device=img.device)             # NHWC over the pair
+    with torch.cuda.device(img.device):
+        _lib.check(lib.cotr_backbone_upto(model._handle, img.data_ptr(), b, 1, l1.data_ptr(), _lib.current_stream_ptr()),
+                   model._handle, 'cotr_backbone_upto')
+    body = model.backbone[0].body
+    x = l1.permute(0, 3, 1, 2)                                                               # [B,256,64,128]
+    halves = []
+    for half in (x[..., :64], x[..., 64:]):
+        y = half
+        for blk in list(body.layer2) + list(body.layer3):
+            y = _bottleneck(y, blk)
+        halves.append(y)
+    feat = torch.cat(halves, dim=-1)                                                         # [B,1024,16,32]
+    return feat.permute(0, 2, 3, 1).reshape(b * TOK, CFEAT)
+
+
+def _backbone_trains(model):
+    return any(p.requires_grad for p in model.backbone.parameters())
+
+
 def forward_train(model, img, queries, features=None):
     """``COTR.forward`` in training mode -> pred_corrs [B,Q,2] with an autograd graph over the trainable part.
     Row layout is batch-major: row b*L + l is token / query l of pair b."""
-    if any(p.requires_grad for p in model.backbone.parameters()):
-        raise NotImplementedError('training the backbone (--lr_backbone > 0, the reference\'s stages 2-3) is not implemented: '
-                                  'this step covers stage 1 (frozen backbone)')
     tr = model.transformer
     nheads, d = tr.nhead, tr.d_model
     scale = float(d // nheads) ** -0.5
     training = model.training
     b, nq, _ = queries.shape
     if features is None:
-        features = backbone_features(model, img)
+        features = backbone_features_trainable(model, img) if _backbone_trains(model) else backbone_features(model, img)
     pos = image_pos_table(img.device, hidden=d)                                                        # [512, d]
     src = hip_linear(features, model.input_proj.weight.view(d, CFEAT), model.input_proj.bias)          # cotr_model.py:37
 
@@ -189,7 +229,8 @@ def forward_train(model, img, queries, features=None):
 # ----------------------------------------------------------------------------------------------------------------------
 def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=True):
     """The loss of ``COTRTrainer.train_batch`` / ``validate_batch`` (cotr_trainer.py:124-142) -> (loss, pred)."""
-    feats = backbone_features(model, img)                 # frozen: the cycle pass sees the same features
+    # no dropout / batch statistics in the backbone: the prediction and the cycle pass see the same features
+    feats = backbone_features_trainable(model, img) if _backbone_trains(model) else backbone_features(model, img)
     pred = forward_train(model, img, query, feats)
     loss = F.mse_loss(pred, target)
     if cycle_consis and bidirectional:

@@ -75,6 +75,10 @@ int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream);
  * (COTR/models/backbone.py:79-92) for callers that run the rest themselves: the training step with a frozen backbone
  * (train_cotr.py:54-55 with --lr_backbone=0, the reference's stage 1). */
 int cotr_backbone(cotr_handle h, const float* img, int B, float* features, cotr_stream stream);
+/* Same, stopping after `stage` = 1, 2 or 3 (layer1 [B,64,128,256], layer2 [B,32,64,512], layer3 [B,16,32,1024], NHWC over
+ * the pair): the part of the backbone that stays frozen when the reference trains layer2/layer3 (--lr_backbone > 0 trains
+ * only parameters whose name contains layer2/3/4, COTR/models/backbone.py:66-69; stages 2-3 of readme.md:50-52). */
+int cotr_backbone_upto(cotr_handle h, const float* img, int B, int stage, float* features, cotr_stream stream);
 
 /* Query-dependent half against the cached encode: lin_sine query encoding, 6 cross-attention
  * decoder layers, decoder.norm and the corr_embed MLP on the LAST layer only (the reference runs

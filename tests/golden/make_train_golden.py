@@ -35,11 +35,11 @@ def train_case(seed=0, B=2, Q=24):
     return sd, img, query, target
 
 
-def main():
+def main(lr_backbone=0.0, out_name='train_step_b2_q24.npz'):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     sd, img, query, target = train_case()
-    model = ref_import.build_reference_model(ref_import.default_args(dropout=0.0, lr_backbone=0.0))
+    model = ref_import.build_reference_model(ref_import.default_args(dropout=0.0, lr_backbone=lr_backbone))
     model.load_state_dict(sd)
     model.train()
     # cotr_trainer.py:124-135
@@ -51,7 +51,8 @@ def main():
     cycle_loss = torch.nn.functional.mse_loss(cycle[mask], query[mask])
     # the cycle term alone (it is ~1e-4 of the loss: its gradient - through the prediction fed back as queries and the
     # derivative of the lin_sine encoding - would be invisible in the total)
-    params = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not ('decoder' in n and 'norm1' in n)]
+    params = [(n, p) for n, p in model.named_parameters()
+              if p.requires_grad and not ('decoder' in n and 'norm1' in n) and 'layer4' not in n]
     cgrads = torch.autograd.grad(cycle_loss, [p for _, p in params], retain_graph=True)
     loss = loss + cycle_loss
     loss.backward()
@@ -60,7 +61,7 @@ def main():
     names, stats = [], []
     for name, p in model.named_parameters():
         if p.grad is None:
-            assert not p.requires_grad or 'norm1' in name and 'decoder' in name, name
+            assert not p.requires_grad or ('norm1' in name and 'decoder' in name) or 'layer4' in name, name
             continue
         gr = p.grad.double()
         names.append(name)
@@ -74,9 +75,13 @@ def main():
             out['cgrad.' + n] = g.numpy()
     out['grad_names'] = np.array(names)
     out['grad_stats'] = np.array(stats)
-    np.savez_compressed(os.path.join(HERE, 'train_step_b2_q24.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
     print('loss', loss.item(), 'cycle', cycle_loss.item(), 'mask', int(mask.sum()), '/', mask.numel(), 'params with grad', len(names))
 
 
 if __name__ == '__main__':
     main()
+    # stages 2-3 of the reference's recipe: layer2 / layer3 of the backbone train as well (backbone.py:66-69)
+    FULL[:] = ['corr_embed.layers.2.bias', 'input_proj.bias', 'backbone.0.body.layer2.0.conv1.weight',
+               'backbone.0.body.layer2.3.conv3.weight']
+    main(lr_backbone=1e-5, out_name='train_step_backbone_b2_q24.npz')

@@ -76,7 +76,7 @@ def test_no_cpu_fallback_and_shape_contract():
         m.train()(torch.zeros(1, 3, 256, 512), torch.zeros(1, 4, 2))
     with pytest.raises(NotImplementedError):                  # encode()/decode() are the inference split
         m.train().encode(torch.zeros(1, 3, 256, 512))
-    with pytest.raises(NotImplementedError):                  # stages 2-3 (trainable backbone) are not implemented
+    with pytest.raises(_lib.CotrHipError):                    # trainable backbone (stages 2-3): GPU only as well
         m2 = build_model(cotr_amd.default_args(lr_backbone=1e-5)).train()
         m2(torch.zeros(1, 3, 256, 512), torch.zeros(1, 4, 2))
     with pytest.raises(NotImplementedError):
