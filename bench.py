@@ -65,6 +65,7 @@ def kernel_breakdown(model, img, qs, step_ms, reps=5):
     rescaled to sum to the un-instrumented step time measured above."""
     import collections
     model.set_profiling(2)
+    import re
     fam = collections.OrderedDict()
     n_launch = 0
     for _ in range(reps):
@@ -74,17 +75,29 @@ def kernel_breakdown(model, img, qs, step_ms, reps=5):
         n_launch = len(prof)
         for name, ms in prof:
             key = name.split(' ')[0]
-            e = fam.setdefault(key, [0, 0.0])
+            e = fam.setdefault(key, [0, 0.0, 0.0])
             e[0] += 1
             e[1] += ms
+            mnk = re.search(r'(\d+)x(\d+)x(\d+)', name)          # GEMM / conv launches carry their M x N x K
+            if mnk:
+                e[2] += 2.0 * int(mnk.group(1)) * int(mnk.group(2)) * int(mnk.group(3))
     model.set_profiling(0)
     raw_total = sum(v[1] for v in fam.values()) / reps
     overhead = max(0.0, (raw_total - step_ms) / max(1, n_launch))      # ms per launch added by the event
     out = {}
-    for k, (cnt, ms) in fam.items():
+    for k, (cnt, ms, fl) in fam.items():
         launches = cnt // reps
-        out[k] = {'launches': launches, 'us': round(max(0.0, ms / reps - overhead * launches) * 1e3, 1)}
-    return {'launches_per_forward': n_launch, 'event_overhead_us_per_launch': round(overhead * 1e3, 2), 'families': out}
+        us = max(0.0, ms / reps - overhead * launches) * 1e3
+        out[k] = {'launches': launches, 'us': round(us, 1)}
+        if fl > 0 and us > 0:
+            out[k]['gflop'] = round(fl / reps / 1e9, 3)
+            out[k]['tflops'] = round(fl / reps / us / 1e6, 1)
+    dom = max(out, key=lambda k: out[k]['us'])
+    res = {'launches_per_forward': n_launch, 'event_overhead_us_per_launch': round(overhead * 1e3, 2), 'families': out}
+    if 'tflops' in out[dom]:
+        res['dominant_family'] = {'name': dom, **out[dom], 'avg_us_per_launch': round(out[dom]['us'] / out[dom]['launches'], 2),
+                                  'frac_of_fp32_mfma_peak': round(out[dom]['tflops'] / PEAK_FP32_MFMA_TFLOPS, 3)}
+    return res
 
 
 def other_regimes(sd, dev):
