@@ -150,6 +150,13 @@ class _DeviceCropper:
         self._lib = _lib
         self.lib = _lib.load_library()
         self.device = device
+        for name, im in (('img_a', img_a), ('img_b', img_b)):    # what PIL.Image.fromarray(patch) accepts in the reference
+            if not (isinstance(im, np.ndarray) and im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3):
+                raise ValueError(f'{name} must be an HxWx3 uint8 array (got {getattr(im, "dtype", type(im))}, '
+                                 f'shape {getattr(im, "shape", None)})')
+        if device.type != 'cuda':
+            raise _lib.CotrHipError('the device-side crop kernel needs the model (and its inputs) on the MI355X; for host-side '
+                                    'experiments pass make_cropper=...')
         self.a = torch.from_numpy(np.ascontiguousarray(img_a)).to(device)
         self.b = torch.from_numpy(np.ascontiguousarray(img_b)).to(device)
         self.shape_a, self.shape_b = img_a.shape, img_b.shape

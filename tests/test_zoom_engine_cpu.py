@@ -155,3 +155,17 @@ def test_reference_constructor_signatures(golden_dir):
         out = run_dense_case(g, eng)
         assert np.array_equal(out[0], g['corrs']) and np.array_equal(out[2], g['cycle_error'])
     assert SparseEngine(CyclicFakeModel(), 32).mode == 'stretching'        # the reference's default (sparse_engine.py:18)
+
+
+def test_default_cropper_fails_loudly_without_gpu_or_with_wrong_images():
+    """No host fallback for the crop kernel: a CPU model raises; so do float / grey images (the reference's PIL path would
+    reject them too)."""
+    from cotr_amd import _lib
+    eng = ZoomEngine(FakeModel())                       # parameters on the CPU -> device-side cropper refuses
+    img_a, img_b = synthetic_pair(0)
+    with pytest.raises(_lib.CotrHipError):
+        eng.refine(img_a, img_b, [[10.0, 10.0]], [[12.0, 12.0]], 1.0, 1.0, [0.5], 1)
+    with pytest.raises(ValueError):
+        eng.refine(img_a.astype(np.float32), img_b, [[10.0, 10.0]], [[12.0, 12.0]], 1.0, 1.0, [0.5], 1)
+    with pytest.raises(ValueError):
+        eng.refine(img_a[..., 0], img_b, [[10.0, 10.0]], [[12.0, 12.0]], 1.0, 1.0, [0.5], 1)
