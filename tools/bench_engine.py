@@ -63,3 +63,17 @@ for tag, (ia, ib) in (('2x2 patch pairs (cathedral sizes)', (img_a, img_b)),):
     print(f'dense pass, {tag}: {dt:.3f} s total, of which the model call ({len(boxes)} x 131072 queries) {dm:.3f} s = '
           f'{len(boxes) * 131072 / dm:.0f} query-corr/s; the rest: crop launch, query grid upload, cotr_dense_cycle + '
           f'2 x cotr_dense_merge, D2H of the merged maps, the two visualisation warps', flush=True)
+# dense pass + zoom, 10 k forced queries, converge_iters = 3, on a 512x512 synthetic pair
+if '--config2' in sys.argv:
+    ia, ib = synthetic_pair(4, (512, 512), (512, 512))
+    rng = np.random.default_rng(1)
+    q10k = np.stack([rng.uniform(5, 507, 10000), rng.uniform(5, 507, 10000)], 1)
+    eng = ZoomEngine(m, max_pairs=1024)
+    np.random.seed(0)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    corrs = eng.cotr_corr_multiscale(ia, ib, zooms, 3, max_corrs=10000, queries_a=q10k, force=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    print(f'config 2 (dense pass + 4 zoom levels, converge_iters 3, 10000 forced queries, 512x512 pair): {dt:.2f} s, '
+          f'{len(corrs)} correspondences = {len(corrs) / dt:.0f} corr/s, {eng.total_tasks} crops through the model', flush=True)
