@@ -574,6 +574,8 @@ static const GemmCfg kCfgs[] = {
     {1, 4, 1, 0},   // 25 k-split 4 waves, 32x16
     {4, 0, 2, 2},   // 26 large tile 128x128 (gemm_big.hip)
     {4, 0, 2, 1},   // 27 large tile 128x64
+    {5, 0, 2, 2},   // 28 large tile 128x128, three LDS stages (two tiles of LDS-DMA in flight, counted vmcnt)
+    {5, 0, 2, 1},   // 29 large tile 128x64, three LDS stages
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -656,6 +658,8 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 25: return launch_ks<4, 1, 0, MODE, 0>(p, s);
     case 26: return launch_gemm_big(MODE, 0, p, s);
     case 27: return launch_gemm_big(MODE, 1, p, s);
+    case 28: return launch_gemm_big(MODE, 2, p, s);
+    case 29: return launch_gemm_big(MODE, 3, p, s);
     default: return -1;
   }
 }
@@ -671,7 +675,7 @@ static const TunedEntry kTuned[] = {
 
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  if (c.kind == 4) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
+  if (c.kind >= 4) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
     if (p.A2 != nullptr || p.ldc % 4 != 0 || ((uintptr_t)p.C & 15)) return false;
     if (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15))) return false;
     return p.N % (64 * c.tn) == 0;
@@ -689,7 +693,7 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
 
 // rough cost model (cycles) for shapes outside the tuned table
 static double model_cost(const GemmCfg& c, const GemmParams& p) {
-  if (c.kind == 4) {  // pays off once the chip is covered several times over
+  if (c.kind >= 4) {  // pays off once the chip is covered several times over
     const int bm = 128, bn = 64 * c.tn;
     const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
     const double rounds = ceil(wgs / 512.0);
@@ -754,7 +758,7 @@ int launch_gemm_cfg(int mode, int cfg, const GemmParams& p0, hipStream_t s) {
   {
     // which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
     const GemmCfg& c = kCfgs[cfg];
-    const int bm = c.kind == 4 ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
+    const int bm = c.kind >= 4 ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
     const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
     const double w_bytes = (double)p.N * p.K * 4.0;
     const bool fits = (p.M + bm - 1) / bm >= 8;

@@ -19,7 +19,10 @@
 
 #define BK 32
 
-template <int TN, int MODE>
+// NST = LDS stages: 2 = every barrier drains the LDS-DMA queue (vmcnt(0)); 3 = ring with TWO tiles in flight: the wait before
+// the barrier of step t is a counted vmcnt that covers tile t only, tile t+1 stays in flight across the barrier (raw s_barrier,
+// no fence: __syncthreads() would drain the queue) and tile t+2 is requested right after it.
+template <int TN, int MODE, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage
@@ -130,12 +133,28 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
         res[a][it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m < p.M ? m : 0) * p.ldr + ncol);
       }
   }
+  int st = 0;                                           // stage of tile kt
   for (int kt = 0; kt < KT; ++kt) {
-    LDS_DMA_WAIT_ALL();                                 // this wavefront's share of tile kt (and kt+1) has landed ...
-    __syncthreads();                                    // ... and so has everybody else's; stage (kt+1)&1 is free
-    if (kt >= 1 && kt + 1 < KT) dma_tile(kt + 1, (kt + 1) & 1);
-    const float* As = smem + (kt & 1) * STAGE + (wm * 64 + l31) * BK;
-    const float* Ws = smem + (kt & 1) * STAGE + BM * BK + (wn * 32 * TN + l31) * BK;
+    if constexpr (NST == 2) {
+      LDS_DMA_WAIT_ALL();                               // this wavefront's share of tile kt (and kt+1) has landed ...
+      __syncthreads();                                  // ... and so has everybody else's; stage (kt+1)&1 is free
+      if (kt >= 1 && kt + 1 < KT) dma_tile(kt + 1, (kt + 1) & 1);
+      st = kt & 1;
+    } else {
+      // in flight, oldest first: [tile kt] [tile kt+1]; one tile = 4 + QW DMA instructions per wavefront.  (In the first
+      // steps the residual prefetch sits behind tile 1 and is waited for too - conservative, not wrong.)
+      if (kt + 1 < KT) {
+        if constexpr (QW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                     // everybody's share of tile kt is in LDS; stage (kt+2)%3 is free
+      asm volatile("" ::: "memory");                    // no LDS access of this step may be scheduled above the barrier
+      if (kt + 2 < KT) dma_tile(kt + 2, st == 0 ? 2 : st - 1);
+    }
+    const float* As = smem + st * STAGE + (wm * 64 + l31) * BK;
+    const float* Ws = smem + st * STAGE + BM * BK + (wn * 32 * TN + l31) * BK;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ch = ((j * 2 + hh) ^ sw) * 4;
@@ -151,6 +170,10 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
 #pragma unroll
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+    }
+    if constexpr (NST == 3) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are retired before the next barrier
+      st = st == 2 ? 0 : st + 1;
     }
   }
   __syncthreads();                                      // every wavefront is done reading the operand stages
@@ -192,10 +215,10 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
   }
 }
 
-template <int TN, int MODE>
+template <int TN, int MODE, int NST>
 static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   constexpr int BM = 128, BN = 64 * TN;
-  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  constexpr size_t smem = (size_t)NST * (BM + BN) * BK * sizeof(float);
   static_assert(smem >= (size_t)4 * 32 * (32 * TN + 4) * sizeof(float), "epilogue staging fits in the operand stages");
   GemmParams p = p0;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0 || p.A2 != nullptr) return -1;
@@ -205,22 +228,26 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   if (p.zeros == nullptr) return -2;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set = true;
   }
   const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE>), dim3(tiles), dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST>), dim3(tiles), dim3(256), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// variant 0: 128 x 128 tile, 1: 128 x 64
+// variant 0: 128 x 128 tile, 1: 128 x 64 (two LDS stages); 2, 3: the same tiles with the three-stage ring
 int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s) {
-  if (mode == GEMM_DENSE) {
-    if (p.lda % 4 != 0) return -1;
-    return variant == 0 ? launch_big_t<2, GEMM_DENSE>(p, s) : launch_big_t<1, GEMM_DENSE>(p, s);
+  if (mode == GEMM_DENSE && p.lda % 4 != 0) return -1;
+  if (mode != GEMM_DENSE && mode != GEMM_CONV) return -1;
+  const bool d = mode == GEMM_DENSE;
+  switch (variant) {
+    case 0: return d ? launch_big_t<2, GEMM_DENSE, 2>(p, s) : launch_big_t<2, GEMM_CONV, 2>(p, s);
+    case 1: return d ? launch_big_t<1, GEMM_DENSE, 2>(p, s) : launch_big_t<1, GEMM_CONV, 2>(p, s);
+    case 2: return d ? launch_big_t<2, GEMM_DENSE, 3>(p, s) : launch_big_t<2, GEMM_CONV, 3>(p, s);
+    case 3: return d ? launch_big_t<1, GEMM_DENSE, 3>(p, s) : launch_big_t<1, GEMM_CONV, 3>(p, s);
+    default: return -1;
   }
-  if (mode == GEMM_CONV) return variant == 0 ? launch_big_t<2, GEMM_CONV>(p, s) : launch_big_t<1, GEMM_CONV>(p, s);
-  return -1;
 }

@@ -262,7 +262,7 @@ def test_large_tile_configs_are_repeatable():
         b, r = torch.randn(N, generator=g).to(d), torch.randn(M, N, generator=g).to(d)
         ref = torch.empty(M, N, device=d)
         assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(r), 1, G.P(ref), M, N, K, 2, G.sptr()) == 0
-        for cfg in (26, 27, 19, 20):
+        for cfg in (26, 27, 28, 29, 19, 20):
             outs = []
             for _ in range(4):
                 y = torch.full((M, N), float('nan'), device=d)

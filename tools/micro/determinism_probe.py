@@ -11,7 +11,7 @@ for M, N, K in ((262144, 256, 64), (65536, 512, 128), (16384, 1024, 256), (26214
     x = torch.randn(M, K, generator=g).cuda(); w = (torch.randn(N, K, generator=g) / 8).cuda(); b = torch.randn(N, generator=g).cuda()
     r = torch.randn(M, N, generator=g).cuda()
     for res in (None, r):
-        for c in (2, 26, 27):
+        for c in (2, 26, 27, 28, 29):
             outs = []
             for it in range(6):
                 y = torch.full((M, N), float('nan'), device='cuda')
@@ -32,7 +32,7 @@ for B, hin, cin, cout, k, stride in ((32, 64, 64, 64, 3, 1), (32, 64, 128, 128, 
     w = (torch.randn(cout, k, k, cin, generator=g) / (cin * k * k) ** 0.5).cuda()
     sc, bi = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
     ho = (hin + 2 * (k // 2) - k) // stride + 1
-    for c in (2, 26, 27):
+    for c in (2, 26, 27, 28, 29):
         outs = []
         for it in range(6):
             y = torch.full((B, ho, 2 * ho, cout), float('nan'), device='cuda')
