@@ -448,10 +448,13 @@ class ZoomEngine:
                 np.array(ident, dtype=np.int64), area_a, area_b)
 
     def cotr_corr_multiscale(self, img_a, img_b, zoom_ins=(1.0,), converge_iters=1, max_corrs=1000, queries_a=None,
-                             return_idx=False, force=False, areas=None, init_b=None):
+                             return_idx=False, force=False, return_tasks_only=False, areas=None, init_b=None):
         """``SparseEngine.cotr_corr_multiscale`` (sparse_engine.py:197-233), same arguments and result ([M,4] rows
         (x_a, y_a, x_b, y_b), at most max_corrs, in task order; with return_idx also the task identifiers).
         ``init_b`` (extra): initial estimates for the known-scale path instead of running ``corr_base``."""
+        if return_tasks_only:
+            raise NotImplementedError('return_tasks_only: there are no RefinementTask objects here (the state machine runs on '
+                                      'arrays); use refine(), whose RefineResult carries loc_history / good / steps per task')
         img_a, img_b = np.ascontiguousarray(img_a), np.ascontiguousarray(img_b)
         if areas is not None:                                      # gen_tasks_w_known_scale :100-114
             assert queries_a is not None and max_corrs >= len(queries_a)   # the reference also insists on force=True
