@@ -190,6 +190,7 @@ def main():
     ap.add_argument('--xcd-mapping', type=int, default=None, help='cotr_set_xcd_mapping policy (experiments)')
     ap.add_argument('--fused-stem', type=int, default=None, help='cotr_set_fused_stem (experiments)')
     ap.add_argument('--ffn-tail', type=int, default=None, help='cotr_set_ffn_tail (experiments)')
+    ap.add_argument('--ffn-preln', type=int, default=None, help='cotr_set_ffn_preln (experiments)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -214,6 +215,9 @@ def main():
     if args.xcd_mapping is not None:
         from cotr_amd import _lib
         _lib.load_library().cotr_set_xcd_mapping(args.xcd_mapping)
+    if args.ffn_preln is not None:
+        from cotr_amd import _lib
+        _lib.load_library().cotr_set_ffn_preln(args.ffn_preln)
     if args.ffn_tail is not None:
         from cotr_amd import _lib
         _lib.load_library().cotr_set_ffn_tail(args.ffn_tail)

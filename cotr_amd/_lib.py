@@ -63,6 +63,7 @@ _PROTOS = {
     'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_fused_stem': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_ffn_tail': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_ffn_preln': (ctypes.c_int, [ctypes.c_int]),
     'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     'cotr_bench_conv': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 9 +

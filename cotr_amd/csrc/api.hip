@@ -150,6 +150,7 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
 
 bool g_fused_stem = true;  // cotr_set_fused_stem
 bool g_ffn_tail = false;   // cotr_set_ffn_tail: measured slower, off
+bool g_ffn_preln = false;  // cotr_set_ffn_preln: the norm before the FFN folded into the fused FFN block (measured neutral, off)
 
 GemmParams base_params() {
   GemmParams p;
@@ -204,6 +205,24 @@ int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, c
   if ((r = linear(h, x, nullptr, 0, 1, 0, l1w, l1b, nullptr, 1, 1.f, 0, hid, M, FFN, D, s))) return r;
   if ((r = linear(h, hid, nullptr, 0, 1, 0, l2w, l2b, x, 0, 1.f, 0, tmp, M, D, FFN, s))) return r;
   return layernorm(h, tmp, nw, nb, y, M, s);
+}
+
+// y = LN_post(x1 + FFN(x1)) with x1 = LN_pre(xpre): the norm after the attention sub-layer folded into the fused FFN block
+// (its only consumers are the FFN input and the FFN residual), so that norm never gets its own launch.  x1buf / tmp are
+// scratch for the unfused fallback (more than g_ffn_fuse_max_rows rows).
+int ffn_block_pre(cotr_ctx* h, const float* xpre, const float* pre_w, const float* pre_b, const float* l1w, const float* l1b,
+                  const float* l2w, const float* l2b, const float* nw, const float* nb, float* hid, float* x1buf, float* tmp,
+                  float* y, int M, hipStream_t s) {
+  if (g_ffn_preln && !g_ffn_tail && M <= g_ffn_fuse_max_rows) {
+    const int nch = ffn_fused_chunks(M);
+    KCHK(h, launch_ffn_fused_pre(xpre, pre_w, pre_b, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
+    if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused ln+%d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
+    KCHK(h, launch_ln_reduce_pre(hid, nch, l2b, xpre, pre_w, pre_b, nw, nb, y, M, s), "ln_reduce");
+    prof_mark(h, "ln_reduce", s, 2);
+    return COTR_OK;
+  }
+  if (int r = layernorm(h, xpre, pre_w, pre_b, x1buf, M, s)) return r;
+  return ffn_block(h, x1buf, l1w, l1b, l2w, l2b, nw, nb, hid, tmp, y, M, s);
 }
 
 int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int relu, float* y, int B,
@@ -590,9 +609,9 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
       prof_mark(h, "attention enc", s, 2);
       if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
-      if ((r = layernorm(h, t_tmp, e.n1w, e.n1b, t_x1, M, s))) return r;
       float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
-      if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_tmp, y, M, s))) return r;
+      if ((r = ffn_block_pre(h, t_tmp, e.n1w, e.n1b, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_x1, t_ao, y, M, s)))
+        return r;
       xin = y;
     }
     prof_mark(h, "encoder", s);
@@ -683,8 +702,8 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
          "attention");
     prof_mark(h, "attention dec", s, 2);
     if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
-    if ((r = layernorm(h, d.pre2, w.n2w, w.n2b, d.t2, R, s))) return r;
-    if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, d.tgt, R, s))) return r;
+    if ((r = ffn_block_pre(h, d.pre2, w.n2w, w.n2b, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.t2, d.pre3, d.tgt, R, s)))
+      return r;
   }
   // decoder.norm + corr_embed on the last layer only (the reference computes all 6 and keeps [-1])
   if ((r = layernorm(h, d.tgt, h->dn_w, h->dn_b, d.pre2, R, s))) return r;
@@ -934,6 +953,11 @@ int cotr_set_ffn_fusion_max_rows(int rows) {
 void set_attention_head_major(int v);  // attention.hip
 void set_ffn_chunk_major(int v);       // ffn.hip
 extern "C" {
+int cotr_set_ffn_preln(int enable) {
+  g_ffn_preln = enable != 0;
+  return COTR_OK;
+}
+
 int cotr_set_ffn_tail(int enable) {
   g_ffn_tail = enable != 0;
   return COTR_OK;

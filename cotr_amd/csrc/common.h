@@ -126,3 +126,8 @@ int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const 
                         const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
 int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                      float* y, int rows, hipStream_t s);
+// the same two with the LayerNorm that precedes the FFN folded in: X / residual are the PRE-norm rows
+int launch_ffn_fused_pre(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
+                         const float* W2, float* P, int M, int nch, hipStream_t s);
+int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const float* residual, const float* pre_w,
+                         const float* pre_b, const float* w, const float* b, float* y, int rows, hipStream_t s);

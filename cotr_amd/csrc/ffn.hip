@@ -26,6 +26,10 @@ struct FfnParams {
   const float* W2;   // [256][1024]
   float* P;          // [nch][M][256] partial outputs
   const float* zeros;
+  // optional LayerNorm applied to the X tile after it landed in LDS: X is then the PRE-norm tensor (x + attention output)
+  // and norm1 / norm2 of the layer never needs its own launch (its only consumers are this block and its residual)
+  const float* pre_w;
+  const float* pre_b;
   int M, nch, chunk_major;
   // tail (optional): the LAST of the nch workgroups of a row tile to finish sums the partial outputs in chunk order, adds
   // bias + residual and applies LayerNorm - what ln_reduce_kernel does in a second launch.  No workgroup waits for
@@ -80,6 +84,27 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
     }
   };
   dma_w1(0);
+
+  if (p.pre_w != nullptr) {
+    LDS_DMA_WAIT_ALL();
+    __syncthreads();                                  // X (and the first W1 sub-chunk) have landed
+    // same arithmetic as layernorm_kernel (pointwise.hip): lane holds 4 consecutive channels, two wave reductions
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(p.pre_w + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.pre_b + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* row = Xs + (wave * 4 + i) * FF_LD + lane * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row);
+      const float mean = ffn_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+      const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+      const float var = ffn_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+      const float rstd = 1.f / sqrtf(var + 1e-5f);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = d[e] * rstd * ww[e] + bb[e];
+      *reinterpret_cast<f32x4*>(row) = o;
+    }
+  }
 
   f32x16 acc2;
 #pragma unroll
@@ -168,7 +193,20 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
     const int row = m0 + wave * 4 + i;
     if (row >= p.M) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(p.b2 + lane * 4);
-    v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * FF_D + lane * 4);
+    {
+      f32x4 rr = *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * FF_D + lane * 4);
+      if (p.pre_w != nullptr) {                         // the residual is LayerNorm(pre-norm row)
+        const float mu = ffn_wave_sum(rr[0] + rr[1] + rr[2] + rr[3]) * (1.f / 256.f);
+        const f32x4 dd = {rr[0] - mu, rr[1] - mu, rr[2] - mu, rr[3] - mu};
+        const float va = ffn_wave_sum(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3]) * (1.f / 256.f);
+        const float rs = 1.f / sqrtf(va + 1e-5f);
+        const f32x4 pw = *reinterpret_cast<const f32x4*>(p.pre_w + lane * 4);
+        const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pre_b + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rr[e] = dd[e] * rs * pw[e] + pb[e];
+      }
+      v += rr;
+    }
     for (int c = 0; c < p.nch; ++c) {
       const float* src = p.P + ((size_t)c * p.M + row) * FF_D + lane * 4;
 #pragma unroll
@@ -211,12 +249,25 @@ static int* ffn_counters() {
   return c;
 }
 
+static const float* g_next_pre_w = nullptr;   // set by launch_ffn_fused_pre for the launch that follows (single-threaded host)
+static const float* g_next_pre_b = nullptr;
+
 int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
                         const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
 
 int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
                      hipStream_t s) {
   return launch_ffn_fused_ln(X, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+// X is the pre-norm tensor: LayerNorm(pre_w, pre_b) is applied to the X tile inside the kernel
+int launch_ffn_fused_pre(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
+                         const float* W2, float* P, int M, int nch, hipStream_t s) {
+  g_next_pre_w = pre_w;
+  g_next_pre_b = pre_b;
+  const int r = launch_ffn_fused(X, W1, b1, W2, P, M, nch, s);
+  g_next_pre_w = g_next_pre_b = nullptr;
+  return r;
 }
 
 // with b2 != nullptr the kernel also does  Y = LayerNorm(residual + sum of partials + b2)  (no second launch)
@@ -235,6 +286,7 @@ int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const 
   FfnParams p;
   p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch; p.chunk_major = g_ffn_chunk_major;
   p.counters = nullptr; p.b2 = b2; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y;
+  p.pre_w = g_next_pre_w; p.pre_b = g_next_pre_b;
   if (b2 != nullptr) {
     if (!residual || !ln_w || !ln_b || !Y || (M + 31) / 32 > 1024) return -1;
     p.counters = ffn_counters();

@@ -34,14 +34,28 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // LayerNorm of (sum of `np` partial outputs [np][rows][256] + bias + residual): the tail of the fused FFN block
 // (ffn.hip): y = LN(residual + linear2(...)) with linear2's bias (transformer.py:156-158, 199-201).
+// With pre_w != nullptr the residual is LayerNorm(pre_w, pre_b) of the given (pre-norm) row: the norm after the attention
+// sub-layer, whose only consumers are the FFN (ffn_fused_kernel normalises its X tile itself) and this residual.
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ parts, int np, const float* __restrict__ bias,
-                                                        const float* __restrict__ residual, const float* __restrict__ w,
+                                                        const float* __restrict__ residual, const float* __restrict__ pre_w,
+                                                        const float* __restrict__ pre_b, const float* __restrict__ w,
                                                         const float* __restrict__ b, float* __restrict__ y, int rows) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 v = *reinterpret_cast<const f32x4*>(bias + lane * 4);
-  v += *reinterpret_cast<const f32x4*>(residual + (size_t)row * 256 + lane * 4);
+  f32x4 rr = *reinterpret_cast<const f32x4*>(residual + (size_t)row * 256 + lane * 4);
+  if (pre_w != nullptr) {
+    const float mu = wave_sum(rr[0] + rr[1] + rr[2] + rr[3]) * (1.f / 256.f);
+    const f32x4 dd = {rr[0] - mu, rr[1] - mu, rr[2] - mu, rr[3] - mu};
+    const float va = wave_sum(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3]) * (1.f / 256.f);
+    const float rs = 1.f / sqrtf(va + 1e-5f);
+    const f32x4 pw = *reinterpret_cast<const f32x4*>(pre_w + lane * 4);
+    const f32x4 pb = *reinterpret_cast<const f32x4*>(pre_b + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rr[i] = dd[i] * rs * pw[i] + pb[i];
+  }
+  v += rr;
   for (int c = 0; c < np; ++c) v += *reinterpret_cast<const f32x4*>(parts + ((size_t)c * rows + row) * 256 + lane * 4);
   const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
   const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
@@ -55,11 +69,17 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
   *reinterpret_cast<f32x4*>(y + (size_t)row * 256 + lane * 4) = out;
 }
 
+int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const float* residual, const float* pre_w,
+                         const float* pre_b, const float* w, const float* b, float* y, int rows, hipStream_t s) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, pre_w, pre_b, w, b, y,
+                     rows);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                      float* y, int rows, hipStream_t s) {
-  if (rows <= 0) return 0;
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, w, b, y, rows);
-  return hipGetLastError() == hipSuccess ? 0 : -2;
+  return launch_ln_reduce_pre(parts, np, bias, residual, nullptr, nullptr, w, b, y, rows, s);
 }
 
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s) {

@@ -181,6 +181,11 @@ int cotr_gemm_num_configs(void);
 int cotr_set_encode_chunk(int pairs);
 /* the fused FFN block (ffn.hip) is used for GEMMs with at most this many rows (default 1024); 0 = never */
 int cotr_set_ffn_fusion_max_rows(int rows);
+/* 1: where the fused FFN block is used, the LayerNorm that precedes it (norm1 of an encoder layer, norm2 of a decoder
+ * layer: transformer.py:155,198) is applied inside it - to the X tile in LDS and to the residual row in ln_reduce - instead of
+ * in a launch of its own (bit-identical, 12 launches fewer at one pair, but measured time-neutral: 1.041 vs 1.036 ms);
+ * 0 (default): separate layernorm launch */
+int cotr_set_ffn_preln(int enable);
 /* 1: the fused FFN kernel also sums its partial outputs and applies bias + residual + LayerNorm (last-arriving workgroup
  * of each row tile; same bits as the separate ln_reduce launch); 0 (default): two launches - the single-launch form
  * measured SLOWER (one CU has to pull the 512 KB of partials of its row tile), see DESIGN.md 4b */

@@ -216,3 +216,26 @@ def test_config3_256_pairs_x_1000_queries():
         assert cotr_oracle.px_err(alone, out[b:b + 1].cpu()) < SHAPE_NOISE_PX
     ref = cotr_oracle.cotr_forward(sd, img[100:101], qs[100:101, :64])
     assert cotr_oracle.px_err(out[100:101, :64].cpu(), ref) < PX_BAR
+
+
+def test_norm_folded_into_the_ffn_block_is_bit_identical():
+    """cotr_set_ffn_preln: the LayerNorm after the attention sub-layer applied inside the fused FFN block (to the X tile in LDS
+    and to the residual row in ln_reduce) instead of in its own launch - same arithmetic, same bits, 12 launches fewer."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    img, qs = synth_inputs(1, 1000, seed=31)
+    m = hip_model()
+    try:
+        outs = []
+        for on in (0, 1):
+            assert lib.cotr_set_ffn_preln(on) == 0
+            outs.append(m(img.cuda(), qs.cuda())['pred_corrs'].clone())
+            m.set_profiling(2)
+            m(img.cuda(), qs.cuda())
+            torch.cuda.synchronize()
+            outs.append(len(m.get_profile()))
+            m.set_profiling(0)
+    finally:
+        lib.cotr_set_ffn_preln(0)
+    assert torch.equal(outs[0], outs[2])
+    assert outs[1] - outs[3] == 12, (outs[1], outs[3])
