@@ -249,31 +249,31 @@ static int* ffn_counters() {
   return c;
 }
 
-static const float* g_next_pre_w = nullptr;   // set by launch_ffn_fused_pre for the launch that follows (single-threaded host)
-static const float* g_next_pre_b = nullptr;
-
-int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
-                        const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
+static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
+                           const float* W2, float* P, int M, int nch, const float* b2, const float* residual,
+                           const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
 
 int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
                      hipStream_t s) {
-  return launch_ffn_fused_ln(X, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+  return launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
 // X is the pre-norm tensor: LayerNorm(pre_w, pre_b) is applied to the X tile inside the kernel
 int launch_ffn_fused_pre(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
                          const float* W2, float* P, int M, int nch, hipStream_t s) {
-  g_next_pre_w = pre_w;
-  g_next_pre_b = pre_b;
-  const int r = launch_ffn_fused(X, W1, b1, W2, P, M, nch, s);
-  g_next_pre_w = g_next_pre_b = nullptr;
-  return r;
+  return launch_ffn_impl(X, pre_w, pre_b, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
 // with b2 != nullptr the kernel also does  Y = LayerNorm(residual + sum of partials + b2)  (no second launch)
 int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
                         const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y,
                         hipStream_t s) {
+  return launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, b2, residual, ln_w, ln_b, Y, s);
+}
+
+static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
+                           const float* W2, float* P, int M, int nch, const float* b2, const float* residual,
+                           const float* ln_w, const float* ln_b, float* Y, hipStream_t s) {
   if (M <= 0) return 0;
   if (nch < 1 || nch > 16 || FF_H % (nch * 64) != 0) return -1;
   static bool attr_set = false;
@@ -286,7 +286,7 @@ int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const 
   FfnParams p;
   p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch; p.chunk_major = g_ffn_chunk_major;
   p.counters = nullptr; p.b2 = b2; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y;
-  p.pre_w = g_next_pre_w; p.pre_b = g_next_pre_b;
+  p.pre_w = pre_w; p.pre_b = pre_b;
   if (b2 != nullptr) {
     if (!residual || !ln_w || !ln_b || !Y || (M + 31) / 32 > 1024) return -1;
     p.counters = ffn_counters();
