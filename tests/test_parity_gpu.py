@@ -239,3 +239,33 @@ def test_norm_folded_into_the_ffn_block_is_bit_identical():
         lib.cotr_set_ffn_preln(0)
     assert torch.equal(outs[0], outs[2])
     assert outs[1] - outs[3] == 12, (outs[1], outs[3])
+
+
+def test_backbone_entry_points_match_the_stage_taps():
+    """cotr_backbone / cotr_backbone_upto (the frozen part of the backbone in the training step) return exactly the layer1 /
+    layer2 / layer3 activations the full encode produces (debug taps), in NHWC over the side-by-side pair."""
+    import ctypes
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    img, qs = synth_inputs(3, 4, seed=41)
+    m = hip_model()
+    img_d = img.cuda()
+    m.set_debug_taps(True)
+    m(img_d, qs.cuda())
+    taps = {k: m.debug_tap(k).clone() for k in ('layer1', 'layer2', 'layer3')}
+    m.set_debug_taps(False)
+    shapes = {1: (3, 64, 128, 256), 2: (3, 32, 64, 512), 3: (3, 16, 32, 1024)}
+    for stage, shape in shapes.items():
+        out = torch.full(shape, float('nan'), device='cuda')
+        _lib.check(lib.cotr_backbone_upto(m._handle, img_d.data_ptr(), 3, stage, out.data_ptr(), _lib.current_stream_ptr()),
+                   m._handle, 'cotr_backbone_upto')
+        torch.cuda.synchronize()
+        ref = taps[f'layer{stage}'].view(shape)
+        # the taps run uses the unfused stem (it keeps the 'stem' tap): same math, different MFMA shape in conv1
+        assert (out - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), stage
+    full = torch.empty(3 * 512, 1024, device='cuda')
+    _lib.check(lib.cotr_backbone(m._handle, img_d.data_ptr(), 3, full.data_ptr(), _lib.current_stream_ptr()), m._handle,
+               'cotr_backbone')
+    torch.cuda.synchronize()
+    assert torch.equal(full.view(3, 16, 32, 1024), out)
+    assert lib.cotr_backbone_upto(m._handle, img_d.data_ptr(), 3, 4, out.data_ptr(), _lib.current_stream_ptr()) != 0
