@@ -952,6 +952,7 @@ int cotr_set_ffn_fusion_max_rows(int rows) {
 }  // extern "C"
 void set_attention_head_major(int v);  // attention.hip
 void set_ffn_chunk_major(int v);       // ffn.hip
+void set_ffn_write_through(int v);     // ffn.hip
 extern "C" {
 int cotr_set_ffn_preln(int enable) {
   g_ffn_preln = enable != 0;
@@ -969,10 +970,11 @@ int cotr_set_fused_stem(int enable) {
 }
 
 int cotr_set_xcd_mapping(int policy) {
-  if (policy < 0 || policy > 15 || (policy & 3) == 3) return COTR_ERR_ARG;
+  if (policy < 0 || policy > 31 || (policy & 3) == 3) return COTR_ERR_ARG;
   gemm_set_xcd_policy(policy & 3);
   set_ffn_chunk_major((policy >> 2) & 1);
   set_attention_head_major((policy >> 3) & 1);
+  set_ffn_write_through(((policy >> 4) & 1) == 0);   // bit 4 set = plain (write-back) stores for the FFN partial outputs
   return COTR_OK;
 }
 

@@ -31,6 +31,7 @@ struct FfnParams {
   const float* pre_w;
   const float* pre_b;
   int M, nch, chunk_major;
+  int wt_partials;   // partial outputs with write-through stores
   // tail (optional): the LAST of the nch workgroups of a row tile to finish sums the partial outputs in chunk order, adds
   // bias + residual and applies LayerNorm - what ln_reduce_kernel does in a second launch.  No workgroup waits for
   // another (arrival counter per row tile, reset by the last arriver), the sum order is fixed: same bits as ln_reduce.
@@ -172,7 +173,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
       // with the tail, partials are exchanged between workgroups of different XCDs inside this launch: agent-scope
       // (sc1) stores / loads go to the memory side and bypass the per-XCD L2s, so no L2 write-back / invalidate is needed
       // (a __threadfence() pair here cost ~50 us per launch)
-      if (p.counters != nullptr)
+      // write-through (sc1) stores: the 8-16 MB of partial outputs are read once, by ln_reduce on all XCDs; left dirty in
+      // L2 they are written back at the kernel boundary (MI355X_MICROARCH.md price table: + dirty bytes / 6 TB/s per
+      // boundary).  Measured 1.037 -> 1.025 ms per forward; the same on GEMM / LayerNorm / attention outputs measured
+      // slower (1.057 vs 1.048 ms), so only here.  The in-kernel tail needs them as well (cross-XCD visibility).
+      if (p.counters != nullptr || p.wt_partials)
         __hip_atomic_store(&out[(size_t)m * FF_D + 32 * wave + l31], acc2[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else
         out[(size_t)m * FF_D + 32 * wave + l31] = acc2[r];
@@ -228,6 +233,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
 
 static const size_t kFfnSmem = (size_t)(32 * FF_LD + 64 * FF_LD + 8 * 16 * 64 + 32 * FF_HLD) * sizeof(float);
 
+static int g_ffn_wt = 1;  // cotr_set_xcd_mapping bit 4 clears it
+void set_ffn_write_through(int v) { g_ffn_wt = v; }
 static int g_ffn_chunk_major = 0;  // measured: -112 MB of fabric traffic per forward but +2 % time -> off (cotr_set_xcd_mapping bit 2)
 void set_ffn_chunk_major(int v) { g_ffn_chunk_major = v; }
 
@@ -287,6 +294,7 @@ static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_
   p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch; p.chunk_major = g_ffn_chunk_major;
   p.counters = nullptr; p.b2 = b2; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y;
   p.pre_w = pre_w; p.pre_b = pre_b;
+  p.wt_partials = g_ffn_wt;
   if (b2 != nullptr) {
     if (!residual || !ln_w || !ln_b || !Y || (M + 31) / 32 > 1024) return -1;
     p.counters = ffn_counters();

@@ -198,6 +198,7 @@ int cotr_set_fused_stem(int enable);
  *             2 = row tiles spread over the XCDs (the other way round), 1 = per launch by operand size
  *   bit 2     fused FFN: hidden-unit chunks spread over the XCDs (W1/W2 once) instead of row tiles
  *   bit 3     attention: heads spread over the XCDs (K_h/V_h once) instead of query tiles
+ *   bit 4     fused FFN: plain write-back stores for the partial outputs instead of the default write-through (sc1) ones
  * Experiments / profiling only; see DESIGN.md for the measured trade-off. */
 int cotr_set_xcd_mapping(int policy);
 /* key splits (wavefronts per workgroup) of the attention kernel: 1, 2, 4, 8, 16, or 0 = automatic */
