@@ -90,7 +90,8 @@ def hip_linear(x, w, b=None):
 # ----------------------------------------------------------------------------------------------------------------------
 def lin_sine(x, depth=64):
     """NerfPositionalEncoding 'lin_sine' (COTR/models/position_encoding.py:30-45): cat([sin(k pi x)]_k, [cos(k pi x)]_k)
-    over a last dimension of size 2, k = 1..depth; differentiable (the cycle pass feeds predictions back as queries)."""
+    over a last dimension of size 2, k = 1..depth.  The reference evaluates it under ``torch.no_grad()``; callers here
+    do the same (``forward_train``)."""
     kpi = torch.tensor([(i + 1) * math.pi for i in range(depth)], dtype=x.dtype, device=x.device)
     arg = x.unsqueeze(-2) * kpi.view(-1, 1)                       # [..., depth, 2]
     return torch.cat([torch.sin(arg).flatten(-2), torch.cos(arg).flatten(-2)], dim=-1)
@@ -180,9 +181,15 @@ def _backbone_trains(model):
     return any(p.requires_grad for p in model.backbone.parameters())
 
 
-def forward_train(model, img, queries, features=None):
+def forward_train(model, img, queries, features=None, _query_grad=False):
     """``COTR.forward`` in training mode -> pred_corrs [B,Q,2] with an autograd graph over the trainable part.
-    Row layout is batch-major: row b*L + l is token / query l of pair b."""
+    Row layout is batch-major: row b*L + l is token / query l of pair b.
+
+    The query encoding carries NO gradient: ``NerfPositionalEncoding.forward`` is ``@torch.no_grad()``
+    (COTR/models/position_encoding.py:40-45), so in the cycle pass ``model(img, pred)`` of the trainer
+    (cotr_trainer.py:129) nothing flows back through ``pred`` into the first pass - the cycle term only trains the
+    second pass.  ``_query_grad=True`` re-enables that (non-reference) path; it exists so that the test which pins
+    this behaviour can show that the golden tells the two apart."""
     tr = model.transformer
     nheads, d = tr.nhead, tr.d_model
     scale = float(d // nheads) ** -0.5
@@ -207,7 +214,11 @@ def forward_train(model, img, queries, features=None):
         src = _ln(src + F.dropout(_ffn(src, layer, p, training), p, training), layer.norm2)
     memory, mem_pos = src, add_pos(src)
 
-    query_pos = lin_sine(queries.reshape(-1, 2).float(), d // 4)                                       # cotr_model.py:34-36
+    if _query_grad:
+        query_pos = lin_sine(queries.reshape(-1, 2).float(), d // 4)
+    else:
+        with torch.no_grad():                                                                          # position_encoding.py:40
+            query_pos = lin_sine(queries.detach().reshape(-1, 2).float(), d // 4)                      # cotr_model.py:34-36
     tgt = torch.zeros_like(query_pos)                                                                  # transformer.py:54
     for layer in tr.decoder.layers:                                                                    # transformer.py:185-201
         p = layer.multihead_attn.dropout
@@ -251,17 +262,29 @@ def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=Tru
 
 
 def train_batch(model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None):
-    """One optimisation step, ``COTRTrainer.train_batch`` (cotr_trainer.py:118-150); with ``group`` the gradients are
-    averaged over the process group (one rank per GPU, RCCL) before the optimiser step.  -> (loss value, pred)."""
+    """One optimisation step, ``COTRTrainer.train_batch`` (cotr_trainer.py:118-150); with ``group`` (or an initialised
+    default process group) the gradients are averaged over the ranks (one rank per GPU, RCCL) before the optimiser
+    step.  -> (loss value, pred).
+
+    Rank symmetry: the reference skips backward when the loss is NaN (:145-147).  With several ranks that decision has
+    to be COMMON - a rank that skipped would leave the others alone in the gradient collective - so the NaN flag is
+    max-reduced first and every rank skips (or steps) together."""
+    import torch.distributed as dist
     assert model.training
+    distributed = group is not None or (dist.is_available() and dist.is_initialized())
     optim.zero_grad()
     loss, pred = compute_loss(model, img, query, target, cycle_consis, bidirectional)
     value = loss.item()
-    if math.isnan(value):
+    bad = math.isnan(value)
+    if distributed and dist.get_world_size(group) > 1:
+        flag = torch.tensor([1.0 if bad else 0.0], device=loss.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        bad = bool(flag.item() > 0)
+    if bad:
         optim.zero_grad()
     else:
         loss.backward()
-        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        if distributed:
             sync_gradients([p for g in optim.param_groups for p in g['params']], group)
     optim.step()
     return value, pred.detach()
@@ -292,12 +315,13 @@ def sync_gradients(params, group=None, bucket_elems=1 << 24):
 
 
 def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0):
-    """``torch.optim.Adam(optim_list)`` of train_cotr.py:49-57."""
-    groups = [{'params': model.transformer.parameters(), 'lr': learning_rate},
-              {'params': model.corr_embed.parameters(), 'lr': learning_rate},
-              {'params': model.query_proj.parameters(), 'lr': learning_rate},
-              {'params': model.input_proj.parameters(), 'lr': learning_rate}]
-    groups = [g for g in ({**g, 'params': list(g['params'])} for g in groups) if g['params']]
+    """``torch.optim.Adam(optim_list)`` of train_cotr.py:49-57 - group for group, including the EMPTY ``query_proj``
+    group (the encoding has no parameters), so that ``optim_state_dict`` of a reference checkpoint loads here and the
+    other way round (Adam requires the same number of param groups)."""
+    groups = [{'params': list(model.transformer.parameters()), 'lr': learning_rate},
+              {'params': list(model.corr_embed.parameters()), 'lr': learning_rate},
+              {'params': list(model.query_proj.parameters()), 'lr': learning_rate},
+              {'params': list(model.input_proj.parameters()), 'lr': learning_rate}]
     if lr_backbone > 0:
         groups.append({'params': list(model.backbone.parameters()), 'lr': lr_backbone})
     return torch.optim.Adam(groups)

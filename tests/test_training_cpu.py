@@ -47,12 +47,58 @@ def test_gradient_sync_world_size_2(tmp_path):
     assert all(torch.load(os.path.join(str(tmp_path), f'r{r}.pt')) for r in range(2))
 
 
+def _nan_worker(rank, world, port, out_dir):
+    """rank 0 sees a NaN loss, rank 1 a finite one: both must skip the step together (no collective mismatch)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(3)                                  # identical replicas
+    lin = torch.nn.Linear(4, 2)
+    lin.training = True
+    before = [p.detach().clone() for p in lin.parameters()]
+    opt = torch.optim.Adam(lin.parameters(), lr=0.1)
+    x = torch.ones(3, 4)
+    results = []
+    for step, nan_rank in enumerate((0, None)):            # step 0: rank 0 is NaN -> nobody steps; step 1: everybody steps
+        def fake_loss(model, img, query, target, *a):
+            out = model(x)
+            loss = out.sum() * (float('nan') if rank == nan_rank else 1.0 + rank)
+            return loss, out
+        training.compute_loss, saved = fake_loss, training.compute_loss
+        try:
+            value, _ = training.train_batch(lin, opt, None, None, None)
+        finally:
+            training.compute_loss = saved
+        results.append([p.detach().clone() for p in lin.parameters()])
+    unchanged = all(torch.equal(a, b) for a, b in zip(before, results[0]))
+    moved = not all(torch.equal(a, b) for a, b in zip(results[0], results[1]))
+    torch.save((unchanged, moved, results[1]), os.path.join(out_dir, f'n{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_nan_loss_is_skipped_by_all_ranks_together(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_nan_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), f'n{r}.pt')) for r in range(2))
+    assert r0[0] and r1[0] and r0[1] and r1[1]
+    assert all(torch.allclose(a, b) for a, b in zip(r0[2], r1[2]))          # averaged gradients: replicas stay identical
+
+
 def test_optimizer_groups_and_checkpoint_format(tmp_path):
     m = build_model(cotr_amd.default_args())
     opt = training.optimizer_for(m, learning_rate=1e-4)
     n_trainable = sum(p.numel() for p in m.parameters() if p.requires_grad)
     assert sum(p.numel() for g in opt.param_groups for p in g['params']) == n_trainable      # train_cotr.py:49-53
     assert all(g['lr'] == 1e-4 for g in opt.param_groups)
+    # train_cotr.py:49-53 builds FOUR groups (the query_proj one is empty): a reference optim_state_dict must load
+    assert [len(g['params']) > 0 for g in opt.param_groups] == [True, True, False, True]
+    ref_like = torch.optim.Adam([{'params': list(m.transformer.parameters()), 'lr': 1e-4},
+                                 {'params': list(m.corr_embed.parameters()), 'lr': 1e-4},
+                                 {'params': list(m.query_proj.parameters()), 'lr': 1e-4},
+                                 {'params': list(m.input_proj.parameters()), 'lr': 1e-4}])
+    opt.load_state_dict(ref_like.state_dict())
+    assert len(training.optimizer_for(m, 1e-4, lr_backbone=1e-5).param_groups) == 5                  # :54-55
     path = os.path.join(str(tmp_path), 'checkpoint.pth.tar')
     training.save_checkpoint(path, m, opt, epoch=3, iteration=1234)
     ck = torch.load(path, map_location='cpu')
