@@ -102,26 +102,34 @@ class _DeviceDensePost:
         return out[..., 0] if a.ndim == 2 else out
 
 
-RefineResult = namedtuple('RefineResult', ['loc_from', 'loc_to', 'good', 'loc_history', 'model_calls', 'crops', 'steps'])
+RefineResult = namedtuple('RefineResult', ['loc_from', 'loc_to', 'good', 'loc_history', 'model_calls', 'crops', 'steps',
+                                           'last_iters'], defaults=(None,))
 
 
-def _reference_schedule(steps, good, batch_size, max_corrs, total):
-    """Which tasks has the reference's loop finished when it exits?  (sparse_engine.py:208-218: every iteration steps
-    the first ``batch_size`` unfinished tasks of the list once; it stops when none is left or when ``max_corrs``
-    finished tasks are 'good'.)  ``steps``/``good`` cover the first len(steps) of ``total`` tasks.
-    -> finished mask over the known prefix, or None if the answer depends on tasks beyond the prefix."""
-    remaining = np.array(steps, dtype=np.int64)
+def _reference_schedule_steps(steps, good, batch_size, max_corrs, total):
+    """How many steps has the reference's loop given each task when it exits?  (sparse_engine.py:208-218: every
+    iteration steps the first ``batch_size`` unfinished tasks of the list once; it stops when none is left or when
+    ``max_corrs`` finished tasks are 'good'.)  ``steps``/``good`` cover the first len(steps) of ``total`` tasks.
+    -> executed step count per task of the known prefix, or None if the answer depends on tasks beyond the prefix."""
+    steps = np.asarray(steps, dtype=np.int64)
+    remaining = steps.copy()
     n_good = 0
     while True:
         window = np.flatnonzero(remaining > 0)[:batch_size]
         if n_good >= max_corrs:
-            return remaining == 0               # stops here whatever follows in the list
+            return steps - remaining            # stops here whatever follows in the list
         if window.size < batch_size and len(remaining) < total:
             return None                         # the next batch would reach into tasks not refined yet
         if window.size == 0:
-            return remaining == 0
+            return steps - remaining
         remaining[window] -= 1
         n_good += int(np.asarray(good)[window[remaining[window] == 0]].sum())
+
+
+def _reference_schedule(steps, good, batch_size, max_corrs, total):
+    """-> mask of the tasks the reference's loop has FINISHED when it exits (None: needs more of the list)."""
+    executed = _reference_schedule_steps(steps, good, batch_size, max_corrs, total)
+    return None if executed is None else executed == np.asarray(steps, dtype=np.int64)
 
 
 def patch_boxes(img_shape, pos, scale):
@@ -175,6 +183,107 @@ class _DeviceCropper:
         if rc != 0:
             raise self._lib.CotrHipError(f'cotr_crop_resize_pairs failed (code {rc})')
         return out[:n]
+
+
+class ZoomTask:
+    """State of ONE query's recursive zoom - the fields and methods of the reference's ``RefinementTask``
+    (COTR/inference/refinement_task.py:15-188) that the engines and their callers read: ``loc_from, best_loc_to,
+    cur_loc_to, loc_history, status, result, submitted, identifier, total_iter, cur_zoom, conclude(force)``.  Crops are
+    boxes (x, y, size) - the pixels are cut by the device kernel for a whole batch at once - so there is no image
+    content in here.  ``ZoomEngine`` keeps this state in arrays and only materialises ZoomTask objects for
+    ``return_tasks_only``; ``FasterSparseEngine`` (whose grouping couples tasks) steps them one by one like the reference."""
+
+    def __init__(self, shape_from, shape_to, loc_from, loc_to, area_from, area_to, converge_iters, zoom_ins, identifier=None):
+        self.identifier = identifier
+        self.shape_from, self.shape_to = tuple(shape_from), tuple(shape_to)
+        self.loc_from = np.asarray(loc_from, dtype=np.float64)
+        self.best_loc_to = self.cur_loc_to = np.asarray(loc_to, dtype=np.float64)
+        if area_from < area_to:                                     # refinement_task.py:25-30
+            self.s_from, self.s_to = BASE_ZOOM, BASE_ZOOM * np.sqrt(area_to / area_from)
+        else:
+            self.s_to, self.s_from = BASE_ZOOM, BASE_ZOOM * np.sqrt(area_from / area_to)
+        self.status, self.result, self.submitted = 'unfinished', 'unknown', False
+        self.converge_iters, self.zoom_ins = converge_iters, list(zoom_ins)
+        self.cur_zoom_idx = self.cur_iter = self.total_iter = 0
+        self.loc_to_at_zoom = []
+        self.loc_history = [self.cur_loc_to]
+        self.job = None             # (xa, ya, sa, xb, yb, sb) of the crop pair the pending answer refers to
+
+    @property
+    def cur_zoom(self):
+        return self.zoom_ins[self.cur_zoom_idx]
+
+    def peek(self):
+        """Boxes this task would crop now (``peek`` :58-67): (xa, ya, sa, xb, yb, sb)."""
+        assert self.status == 'unfinished'
+        xa, ya, sa = patch_boxes(self.shape_from, self.loc_from[None], self.s_from * self.cur_zoom)
+        xb, yb, sb = patch_boxes(self.shape_to, self.cur_loc_to[None], self.s_to * self.cur_zoom)
+        return (int(xa[0]), int(ya[0]), sa, int(xb[0]), int(yb[0]), sb)
+
+    def submit(self, boxes=None):
+        """``get_task`` (own crops, :105-132) / ``get_task_pilot`` (somebody else's crops, :69-85) -> (boxes, query):
+        the query in the frame of the left crop, float64 math then float32 (:110)."""
+        assert self.status == 'unfinished' and not self.submitted
+        self.job = self.peek() if boxes is None else tuple(boxes)
+        xa, ya, sa = self.job[:3]
+        query = ((self.loc_from - np.array([xa, ya])) / np.array([sa * 2, sa])).astype(np.float32)
+        self.submitted = True
+        return self.job, query
+
+    def step(self, raw):
+        """``step`` (:153-182) with ``scale_to_loc`` (:145-151): float32 answer, (x - 0.5) * 2 in float32, patch scaling
+        and offset in float64."""
+        assert self.submitted
+        self.submitted = False
+        raw = np.array(raw, dtype=np.float32)
+        raw[0] = (raw[0] - np.float32(0.5)) * np.float32(2)
+        xb, yb, sb = self.job[3:]
+        loc_to = raw.astype(np.float64) * np.array([sb, sb]) + np.array([xb, yb])
+        self.total_iter += 1
+        self.loc_to_at_zoom.append(loc_to)
+        self.cur_loc_to = loc_to
+        finished = True                                             # every level but the last takes one step
+        if self.cur_zoom_idx == len(self.zoom_ins) - 1:
+            prev = np.array(self.loc_to_at_zoom[:-1]).reshape(-1, 2)
+            finished = bool(len(prev) and (prev == loc_to).all(axis=1).any()) or self.cur_iter >= self.converge_iters - 1
+            self.cur_iter += 1
+        if finished:
+            arr = np.array(self.loc_to_at_zoom)
+            if len(arr) >= 2 and (arr[:-1] == arr[-1]).all(axis=1).any():       # find_prediction_loop
+                start = np.where((arr[:-1] == arr[-1]).all(axis=1))[0][0]
+                loc_to = arr[start:-1].mean(axis=0)
+            self.loc_history.append(loc_to)
+            self.best_loc_to = self.cur_loc_to = loc_to
+            if self.cur_zoom_idx >= len(self.zoom_ins) - 1:                     # next_zoom :134-143
+                self.status = 'finished'
+                self.result = 'bad' if self.conclude() is None else 'good'
+            self.cur_zoom_idx += 1
+            self.cur_iter = 0
+            self.loc_to_at_zoom = []
+
+    def conclude(self, force=False):
+        """:184-188 -> [x_a, y_a, x_b, y_b] or None when the levels disagree by more than 2 % of the image."""
+        hist = np.array(self.loc_history)
+        if not force and max(hist.std(axis=0)) >= THRESHOLD_PIXELS_RELATIVE * max(*self.shape_to):
+            return None
+        return np.concatenate([self.loc_from, self.best_loc_to])
+
+
+def conclude_tasks(tasks, return_idx=False, force=False, img_a_shape=None, img_b_shape=None):
+    """``SparseEngine.conclude_tasks`` (sparse_engine.py:58-84) for a list of ZoomTask."""
+    corrs, idx = [], []
+    for t in tasks:
+        if t.status == 'finished':
+            out = t.conclude(force)
+            if out is not None:
+                corrs.append(np.array(out))
+                idx.append(t.identifier)
+    corrs, idx = np.array(corrs), np.array(idx)
+    if corrs.shape[0] > 0 and img_a_shape is not None and img_b_shape is not None and not force:
+        lim = np.concatenate([np.array(img_a_shape[:2])[::-1], np.array(img_b_shape[:2])[::-1]])
+        keep = (corrs < lim).all(axis=1) & (corrs > 0).all(axis=1)
+        corrs, idx = corrs[keep], idx[keep]
+    return (corrs, idx) if return_idx else corrs
 
 
 class ZoomEngine:
@@ -236,6 +345,7 @@ class ZoomEngine:
         cropper = self.make_cropper(img_a, img_b, device)
         buf = torch.empty((min(n, self.max_pairs), 3, 256, 512), dtype=torch.float32, device=device) if n else None
         history = [cur.copy()]
+        last_iters = [[] for _ in range(n)]
         steps = np.zeros(n, dtype=np.int64)
         calls0, crops0 = 0, self.total_tasks
         for zi, zoom in enumerate(zoom_ins):
@@ -263,6 +373,7 @@ class ZoomEngine:
                         prev = at_zoom[t]
                         repeat = len(prev) >= 1 and any((p == loc[j]).all() for p in prev)
                         at_zoom[t].append(loc[j].copy())
+                        last_iters[t].append(loc[j].copy())
                         done[j] = repeat or it >= converge_iters - 1
                 else:
                     for j, t in enumerate(active):
@@ -283,7 +394,7 @@ class ZoomEngine:
             good = np.ones(n, dtype=bool)
         else:                                                      # conclude :184-188
             good = hist.std(axis=0).max(axis=1) < THRESHOLD_PIXELS_RELATIVE * max(*img_b.shape)
-        return RefineResult(loc_from, cur.copy(), good, hist, calls0, self.total_tasks - crops0, steps)
+        return RefineResult(loc_from, cur.copy(), good, hist, calls0, self.total_tasks - crops0, steps, last_iters)
 
     # ------------------------------------------------------------------------------------------------
     @staticmethod
@@ -451,13 +562,13 @@ class ZoomEngine:
                              return_idx=False, force=False, return_tasks_only=False, areas=None, init_b=None):
         """``SparseEngine.cotr_corr_multiscale`` (sparse_engine.py:197-233), same arguments and result ([M,4] rows
         (x_a, y_a, x_b, y_b), at most max_corrs, in task order; with return_idx also the task identifiers).
-        ``init_b`` (extra): initial estimates for the known-scale path instead of running ``corr_base``."""
-        if return_tasks_only:
-            raise NotImplementedError('return_tasks_only: there are no RefinementTask objects here (the state machine runs on '
-                                      'arrays); use refine(), whose RefineResult carries loc_history / good / steps per task')
+        ``init_b`` (extra): initial estimates for the known-scale path instead of running ``corr_base``.
+        ``return_tasks_only``: a list of ``ZoomTask`` (the reference returns its RefinementTask objects)."""
         img_a, img_b = np.ascontiguousarray(img_a), np.ascontiguousarray(img_b)
-        if areas is not None:                                      # gen_tasks_w_known_scale :100-114
-            assert queries_a is not None and max_corrs >= len(queries_a)   # the reference also insists on force=True
+        if areas is not None:                                      # gen_tasks / gen_tasks_w_known_scale :100-114
+            assert queries_a is not None
+            assert force == True                                   # noqa: E712  (sparse_engine.py:110)
+            assert max_corrs >= len(queries_a)
             if init_b is None:
                 base = self.corr_base(img_a, img_b, queries_a)
                 loc_from, loc_to = base[:, :2], base[:, 2:]
@@ -474,17 +585,21 @@ class ZoomEngine:
         final = np.zeros((n, 2))
         good = np.zeros(n, dtype=bool)
         steps = np.zeros(n, dtype=np.int64)
+        results = []
         done = 0
-        finished = np.zeros(0, dtype=bool)
         while True:
-            sched = _reference_schedule(steps[:done], good[:done], self.batch_size, max_corrs, n)
-            if sched is not None:
-                finished = sched
+            executed = _reference_schedule_steps(steps[:done], good[:done], self.batch_size, max_corrs, n)
+            if executed is not None:
                 break
             hi = min(n, done + chunk)
             res = self.refine(img_a, img_b, loc_from[done:hi], loc_to[done:hi], area_a, area_b, zoom_ins, converge_iters, False)
             final[done:hi], good[done:hi], steps[done:hi] = res.loc_to, res.good, res.steps
+            results.append((done, res))
             done = hi
+        finished = executed == steps[:done]
+        if return_tasks_only:                                          # :218-219: the task objects, finished or not
+            return self._task_objects(img_a.shape, img_b.shape, loc_from, loc_to, ident, area_a, area_b, zoom_ins,
+                                      converge_iters, results, executed, areas is None)
         keep = np.zeros(n, dtype=bool)
         keep[:done] = finished if force else (finished & good[:done])  # status == 'finished' and conclude(force) :67-72
         corrs = np.concatenate([loc_from, final], axis=1)
@@ -492,7 +607,32 @@ class ZoomEngine:
             lim = np.concatenate([np.array(img_a.shape[:2])[::-1], np.array(img_b.shape[:2])[::-1]])
             keep &= (corrs < lim).all(axis=1) & (corrs > 0).all(axis=1)
         corrs, idx = corrs[keep][:max_corrs], ident[keep][:max_corrs]
+        if (idx < 0).any():     # tasks made without an identifier carry None in the reference (:63-69 -> array of None)
+            idx = np.array([None if i < 0 else int(i) for i in idx], dtype=object)
         return (corrs, idx) if return_idx else corrs
+
+    @staticmethod
+    def _task_objects(shape_a, shape_b, loc_from, loc_to, ident, area_a, area_b, zoom_ins, converge_iters, results, executed,
+                      with_ident):
+        """``return_tasks_only``: the per-task state the reference's loop leaves behind, rebuilt from the array state
+        (level results of ``refine`` + the number of steps the reference's schedule gave each task before it stopped)."""
+        levels = len(zoom_ins)
+        tasks = [ZoomTask(shape_a, shape_b, loc_from[i], loc_to[i], area_a, area_b, converge_iters, zoom_ins,
+                          int(ident[i]) if with_ident and ident[i] >= 0 else None) for i in range(len(loc_from))]
+        for lo, res in results:
+            for j in range(len(res.steps)):
+                t, k, total = tasks[lo + j], int(executed[lo + j]), int(res.steps[j])
+                done_levels = levels if k == total else min(k, levels - 1)
+                t.loc_history = [t.loc_history[0]] + [res.loc_history[lv + 1, j].copy() for lv in range(done_levels)]
+                t.best_loc_to = t.cur_loc_to = t.loc_history[-1]
+                t.total_iter, t.cur_zoom_idx = k, done_levels
+                if k == total:
+                    t.status = 'finished'
+                    t.result = 'bad' if t.conclude() is None else 'good'
+                elif k > levels - 1 and res.last_iters is not None:     # stopped between iterations of the last level
+                    t.loc_to_at_zoom = [p.copy() for p in res.last_iters[j][:k - (levels - 1)]]
+                    t.cur_loc_to, t.cur_iter = t.loc_to_at_zoom[-1], k - (levels - 1)
+        return tasks
 
     def cotr_corr_multiscale_with_cycle_consistency(self, img_a, img_b, zoom_ins=(1.0,), converge_iters=1, max_corrs=1000,
                                                     queries_a=None, return_idx=False, return_cycle_error=False):
@@ -528,11 +668,143 @@ class SparseEngine(ZoomEngine):
 
 
 class FasterSparseEngine(SparseEngine):
-    """Constructor of ``COTR.inference.sparse_engine.FasterSparseEngine`` (:273-276).  The reference's version merges
-    nearby tasks into shared crops to save model calls ("it will make spatial accuracy slightly worse", :268-271); here
-    every task keeps its own crop - whole zoom levels are batched instead - so results are those of ``SparseEngine``.
-    ``max_load`` is accepted for signature compatibility and ignored."""
+    """``COTR.inference.sparse_engine.FasterSparseEngine`` (:267-427): "search and merge nearby tasks to accelerate
+    inference speed.  It will make spatial accuracy slightly worse."  A *pilot* task cuts its crop pair; every other
+    task of the same zoom level whose query AND current estimate fall into the central half of the pilot's two crops
+    (``form_squad`` :295-337, at most ``max_load`` of them) is answered from the pilot's crops in the same forward, so a
+    model call is img[<=batch_size, 3, 256, 512] x q[<=batch_size, <=max_load+1, 2] (zero-padded queries, :363-366).
+
+    Grouping couples the tasks (who rides with whom depends on ``np.random.permutation`` and on every earlier answer), so
+    unlike ``ZoomEngine`` this engine keeps the reference's control flow call for call - same pilots in the same order,
+    same squads, same RNG draws (:339-427) - and therefore the same correspondences.  What is MI355X-specific: all crop
+    pairs of a model call are cut, resized (Pillow-exact), laid side by side and normalised by ONE launch of the device
+    crop kernel instead of 2 PIL resizes + an H2D copy per pilot, and the forward is the HIP library's batched
+    encode + decode (queries of a squad share their pilot's encode)."""
 
     def __init__(self, model, batch_size, mode='stretching', max_load=256):
         super().__init__(model, batch_size, mode)
-        self.max_load = max_load
+        self.max_load = int(max_load)
+
+    # -- task list --------------------------------------------------------------------------------------------
+    def _make_tasks(self, img_a, img_b, zoom_ins, converge_iters, max_corrs, queries_a, force, areas):
+        """``gen_tasks`` (:108-195) -> [ZoomTask]."""
+        if areas is not None:
+            assert queries_a is not None
+            assert force == True                                    # noqa: E712  (:110)
+            assert max_corrs >= queries_a.shape[0]
+            base = self.corr_base(img_a, img_b, queries_a)
+            loc_from, loc_to, ident = base[:, :2], base[:, 2:], None
+            area_a, area_b = areas
+        else:
+            loc_from, loc_to, ident, area_a, area_b = self.gen_tasks(img_a, img_b, max_corrs, queries_a, force)
+        return [ZoomTask(img_a.shape, img_b.shape, loc_from[i], loc_to[i], area_a, area_b, converge_iters, zoom_ins,
+                         None if ident is None or ident[i] < 0 else int(ident[i])) for i in range(len(loc_from))]
+
+    def _form_grouped_batch(self, zoom, tasks):
+        """``form_grouped_batch`` (:339-369) + ``form_squad`` (:295-337) -> ([members], boxes [P,6], queries [P,Qmax,2])."""
+        cand = [i for i, t in enumerate(tasks) if t.status == 'unfinished' and not t.submitted and t.cur_zoom == zoom]
+        tasks_map = np.array([np.concatenate([tasks[i].loc_from, tasks[i].cur_loc_to]) for i in cand]).reshape(-1, 4)
+        task_ids = np.array(cand, dtype=np.int64)
+        shuffle = np.random.permutation(tasks_map.shape[0])          # the reference's draw from numpy's global RNG
+        tasks_map, task_ids = np.take(tasks_map, shuffle, axis=0), np.take(task_ids, shuffle, axis=0)
+        free = np.ones(len(task_ids), dtype=bool)
+        squads, boxes, queries = [], [], []
+        for i, ti in enumerate(task_ids):
+            pilot = tasks[ti]
+            if not (pilot.status == 'unfinished' and not pilot.submitted and pilot.cur_zoom == zoom):
+                continue                                             # already riding with an earlier pilot
+            xa, ya, sa, xb, yb, sb = pilot.peek()
+            safe = 0.5                                               # SAFE_AREA: the central half of both crops
+            ca = (xa + sa / 2, ya + sa / 2)
+            cb = (xb + sb / 2, yb + sb / 2)
+            job, q = pilot.submit()
+            members, qs = [pilot], [q]
+            free[i] = False
+            inside = ((tasks_map[:, 0] > ca[0] - sa / 2 * safe) & (tasks_map[:, 0] < ca[0] + sa / 2 * safe) &
+                      (tasks_map[:, 1] > ca[1] - sa / 2 * safe) & (tasks_map[:, 1] < ca[1] + sa / 2 * safe) &
+                      (tasks_map[:, 2] > cb[0] - sb / 2 * safe) & (tasks_map[:, 2] < cb[0] + sb / 2 * safe) &
+                      (tasks_map[:, 3] > cb[1] - sb / 2 * safe) & (tasks_map[:, 3] < cb[1] + sb / 2 * safe))
+            loads = np.where(inside * free)[0][: self.max_load]
+            for tj in task_ids[loads]:
+                _, q = tasks[tj].submit(job)                         # get_task_pilot: the pilot's crops, own query
+                members.append(tasks[tj])
+                qs.append(q)
+            free[loads] = False
+            squads.append(members)
+            boxes.append(job)
+            queries.append(np.stack(qs))
+            if len(squads) >= self.batch_size:
+                break
+        if not squads:
+            return [], None, None
+        qmax = max(len(q) for q in queries)
+        qpad = np.zeros((len(squads), qmax, 2), dtype=np.float32)    # zero-padded like torch.zeros (:363-366)
+        for k, q in enumerate(queries):
+            qpad[k, :len(q)] = q
+        return squads, np.array(boxes, dtype=np.int32), qpad
+
+    def _form_batch(self, tasks, zoom):
+        """``form_batch`` (:23-45): the first ``batch_size`` open tasks of this zoom level, each with its own crops."""
+        ref, boxes, queries = [], [], []
+        for t in tasks:
+            if t.status == 'unfinished' and not t.submitted and (zoom is None or t.cur_zoom == zoom):
+                job, q = t.submit()
+                ref.append(t)
+                boxes.append(job)
+                queries.append(q[None])
+                if len(ref) >= self.batch_size:
+                    break
+        if not ref:
+            return [], None, None
+        return ref, np.array(boxes, dtype=np.int32), np.stack(queries)
+
+    def _forward(self, cropper, boxes, queries, device, count):
+        """One model call on the crop pairs ``boxes`` [P,6] with ``queries`` [P,Q,2] -> float32 [P,Q,2]."""
+        buf = torch.empty((len(boxes), 3, 256, 512), dtype=torch.float32, device=device)
+        img = cropper(boxes, buf)
+        pred = self.model(img, torch.from_numpy(queries).to(device))['pred_corrs']
+        if count:
+            self.total_tasks += len(boxes)                           # only infer_batch counts (:48), infer_batch_grouped not
+        return pred.detach().cpu().numpy()
+
+    def cotr_corr_multiscale(self, img_a, img_b, zoom_ins=(1.0,), converge_iters=1, max_corrs=1000, queries_a=None,
+                             return_idx=False, force=False, return_tasks_only=False, areas=None):
+        """``FasterSparseEngine.cotr_corr_multiscale`` (:371-427)."""
+        img_a, img_b = np.ascontiguousarray(img_a), np.ascontiguousarray(img_b)
+        if queries_a is not None:
+            queries_a = np.array(queries_a, dtype=np.float64)
+        zoom_ins = list(zoom_ins)
+        tasks = self._make_tasks(img_a, img_b, zoom_ins, converge_iters, max_corrs, queries_a, force, areas)
+        device = next(self.model.parameters()).device
+        cropper = self.make_cropper(img_a, img_b, device)
+        num_good = lambda: sum(t.result == 'good' for t in tasks)    # noqa: E731
+        zm = None
+        for zm in zoom_ins:
+            while True:
+                num_g = num_good()
+                squads, boxes, queries = self._form_grouped_batch(zm, tasks)
+                if not squads or num_g >= max_corrs:                 # (a batch formed before the exit test stays submitted,
+                    break                                            #  exactly as in the reference)
+                out = self._forward(cropper, boxes, queries, device, count=False)
+                num_steps = 0
+                for i, members in enumerate(squads):
+                    for j, t in enumerate(members):
+                        t.step(out[i, j])
+                        num_steps += 1
+                if num_steps <= self.batch_size:                     # too few tasks group together: next level
+                    break
+        while True:                                                  # "rollback to default inference" (:400-411), last level only
+            num_g = num_good()
+            ref, boxes, queries = self._form_batch(tasks, zm)
+            if not ref or num_g >= max_corrs:
+                break
+            out = self._forward(cropper, boxes, queries, device, count=True)[:, 0, :]
+            if np.isnan(out).any():
+                raise ValueError('NaN in prediction')                # infer_batch (:54-55)
+            for t, o in zip(ref, out):
+                t.step(o)
+        if return_tasks_only:
+            return tasks
+        corrs, idx = conclude_tasks(tasks, True, force, img_a.shape[:2], img_b.shape[:2])
+        corrs, idx = corrs[:max_corrs], idx[:max_corrs]
+        return (corrs, idx) if return_idx else corrs

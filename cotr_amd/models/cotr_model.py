@@ -240,6 +240,12 @@ class COTR(nn.Module):
     @staticmethod
     def _as_batch(samples):
         if isinstance(samples, NestedTensor):
+            # the reference turns a NestedTensor mask into a key-padding mask (transformer.py:49-55); every caller of
+            # the reference feeds exactly 256x512 pixels, i.e. an all-False mask, and the HIP path has no masked
+            # attention - refuse a real mask instead of silently ignoring it
+            if samples.mask is not None and bool(samples.mask.any()):
+                raise NotImplementedError('libcotr_hip has no key-padding mask: NestedTensor.mask must be all False '
+                                          '(the reference always feeds full 256x512 inputs, backbone.py:80)')
             samples = samples.tensors
         elif isinstance(samples, (list, tuple)):
             samples = torch.stack(list(samples))

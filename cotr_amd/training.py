@@ -290,28 +290,10 @@ def train_batch(model, optim, img, query, target, cycle_consis=True, bidirection
     return value, pred.detach()
 
 
-def sync_gradients(params, group=None, bucket_elems=1 << 24):
-    """Average the gradients over the ranks: flat fp32 buckets (64 MB: the whole trainable part of stage 1 is one bucket;
-    xGMI rings are per-link bound, few large messages beat many small ones), one all-reduce each."""
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    if world == 1:
-        return
-    params = [p for p in params if p.grad is not None]
-    i = 0
-    while i < len(params):
-        j, n = i, 0
-        while j < len(params) and (n == 0 or n + params[j].numel() <= bucket_elems):
-            n += params[j].numel()
-            j += 1
-        flat = torch.cat([p.grad.reshape(-1) for p in params[i:j]])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat /= world
-        off = 0
-        for p in params[i:j]:
-            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
-            off += p.numel()
-        i = j
+def sync_gradients(params, group=None, bucket_elems=1 << 25):
+    """Average the gradients over the ranks: reduce-scatter + all-gather of flat fp32 buckets (cotr_amd/dist.py)."""
+    from .dist import sync_gradients_sharded
+    sync_gradients_sharded(params, group, bucket_elems)
 
 
 def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0):

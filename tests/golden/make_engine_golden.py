@@ -74,17 +74,80 @@ def dense_goldens(SparseEngine, cotr_flow, zoom_ins):
               float((flow[1] < 0.02).mean()), float((flow[4] < 0.02).mean()))
 
 
+# FasterSparseEngine (sparse_engine.py:267-427): name: (seed, model, n_queries | None, max_corrs, converge_iters, force,
+#                                                       known scale, batch_size, max_load)
+FASTER_CASES = {
+    'engine_faster_known': (11, 'fake', 150, 150, 2, True, True, 8, 6),          # squads of <= 7 on 8 pilots per call
+    'engine_faster_dense': (12, 'cyclic', None, 60, 1, False, False, 32, 256),   # demo settings (max_load 256)
+    'engine_faster_dense_q': (13, 'cyclic', 90, 70, 3, False, False, 16, 4),     # filtered queries, converge_iters 3
+    'engine_faster_force_q': (14, 'cyclic', 64, 64, 1, True, False, 4, 256),     # tiny batch: grouped loop gives up early
+}
+
+
+def faster_case_inputs(name):
+    seed, kind, nq = FASTER_CASES[name][:3]
+    img_a, img_b = synthetic_pair(seed)
+    rng = np.random.default_rng(seed + 100)
+    queries = None
+    if nq is not None:
+        if FASTER_CASES[name][6]:      # known scale: clustered queries inside the image (several tasks per crop centre)
+            centres = np.stack([rng.uniform(40, img_a.shape[1] - 40, 12), rng.uniform(40, img_a.shape[0] - 40, 12)], 1)
+            queries = centres[rng.integers(0, 12, nq)] + rng.normal(0, 6.0, (nq, 2))
+            queries = np.clip(queries, 5, [img_a.shape[1] - 5, img_a.shape[0] - 5])
+        else:
+            queries = np.stack([rng.uniform(-8, img_a.shape[1] + 8, nq), rng.uniform(-8, img_a.shape[0] + 8, nq)], 1)
+    return img_a, img_b, queries
+
+
+def faster_goldens(FasterSparseEngine, zoom_ins):
+    for name, (seed, kind, nq, max_corrs, conv, force, known, bs, load) in FASTER_CASES.items():
+        img_a, img_b, queries = faster_case_inputs(name)
+        out = {}
+        for tasks_only in (False, True):
+            model = FakeModel() if kind == 'fake' else CyclicFakeModel()
+            engine = FasterSparseEngine(model, bs, mode='tile', max_load=load)
+            np.random.seed(seed)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                res = engine.cotr_corr_multiscale(img_a, img_b, zoom_ins, conv, max_corrs=max_corrs,
+                                                  queries_a=None if queries is None else queries.copy(), return_idx=True,
+                                                  force=force, areas=[1.0, 1.0] if known else None,
+                                                  return_tasks_only=tasks_only)
+            if tasks_only:
+                out['task_status'] = np.array([t.status == 'finished' for t in res])
+                out['task_submitted'] = np.array([bool(t.submitted) for t in res])
+                out['task_iters'] = np.array([t.total_iter for t in res])
+                out['task_levels'] = np.array([len(t.loc_history) for t in res])
+                out['task_best'] = np.array([np.asarray(t.best_loc_to, dtype=np.float64) for t in res])
+                out['task_from'] = np.array([np.asarray(t.loc_from, dtype=np.float64) for t in res])
+            else:
+                corrs, idx = res
+                out['corrs'] = np.asarray(corrs, dtype=np.float64).reshape(-1, 4)
+                out['idx'] = np.array([-1 if i is None else i for i in idx], dtype=np.int64)
+                out['total_tasks'] = np.array(engine.total_tasks)
+                out['calls'] = np.array([list(a) + list(b) for a, b in model.calls], dtype=np.int64)   # [B,3,256,512,B,Q,2]
+        np.savez_compressed(os.path.join(HERE, name + '.npz'),
+                            queries=np.zeros((0, 2)) if queries is None else queries, **out)
+        q_sizes = out['calls'][:, 5]
+        print(name, 'tasks', len(out['task_status']), 'finished', int(out['task_status'].sum()), 'kept', len(out['corrs']),
+              'model calls', len(out['calls']), 'grouped (Q>1)', int((q_sizes > 1).sum() - (q_sizes > 1000).sum()),
+              'largest squad', int(q_sizes[q_sizes < 1000].max()), 'crops counted', int(out['total_tasks']))
+
+
 def main():
     torch.set_num_threads(1)
     ref_import.import_reference_models()                 # installs the stubs, puts the reference on sys.path
     cwd = os.getcwd()
     os.chdir(ref_import.REFERENCE_ROOT)                  # COTR/global_configs asserts ./out and ./tb_out exist
     try:
-        from COTR.inference.sparse_engine import SparseEngine
+        from COTR.inference.sparse_engine import FasterSparseEngine, SparseEngine
         from COTR.inference.inference_helper import cotr_corr_base, cotr_flow
     finally:
         os.chdir(cwd)
     zoom_ins = np.linspace(0.5, 0.0625, 4)               # demo_single_pair.py:37
+    if '--faster-only' in sys.argv or ('--sparse-only' not in sys.argv and '--dense-only' not in sys.argv):
+        faster_goldens(FasterSparseEngine, zoom_ins)
+        if '--faster-only' in sys.argv:
+            return
     if '--sparse-only' not in sys.argv:
         dense_goldens(SparseEngine, cotr_flow, zoom_ins)
     if '--dense-only' in sys.argv:

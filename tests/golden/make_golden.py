@@ -8,7 +8,7 @@ fp32 and fp64 on CPU and stores the outputs (plus the encoder memory the
 reference's ``Transformer.forward`` returns, sub-sampled) in
 ``tests/golden/<case>.npz``.
 
-    python tests/golden/make_golden.py            # rewrites every case
+    python tests/golden/make_golden.py [case ...]  # rewrites every (or the named) case
 
 The inputs/weights are NOT stored (74 MB): they are regenerated from the seeds
 in the file by the numpy PCG64 generator; ``weights_checksum`` guards against
@@ -34,6 +34,11 @@ CASES = {
     'engine_b4_q1': (0, 1.0, 4, 1, 4, (0.0, 1.0)),          # SparseEngine.infer_batch shape (sparse_engine.py:47-56)
     'peaky_b1_q64': (7, 4.0, 1, 64, 5, (0.0, 1.0)),         # sharp softmax
     'outside_b1_q96': (0, 1.0, 1, 96, 6, (-0.5, 1.5)),      # cycle pass feeds unbounded predictions back as queries
+    # softmax extremes for the exp2-domain attention kernel: logits x16^2 / x32^2 (near one-hot rows, large negative
+    # exponents after the running-max subtraction) and q = k = bias only (every score of a row equal: uniform softmax)
+    'peaky16_b1_q64': (7, 16.0, 1, 64, 7, (0.0, 1.0)),
+    'peaky32_b1_q64': (7, 32.0, 1, 64, 8, (0.0, 1.0)),
+    'flat_b1_q64': (7, 0.0, 1, 64, 9, (0.0, 1.0)),
 }
 
 
@@ -49,7 +54,8 @@ def main():
     torch.set_grad_enabled(False)
     torch.set_num_threads(os.cpu_count())
     model = ref_import.build_reference_model()
-    for name in CASES:
+    only = [a for a in sys.argv[1:] if a in CASES]
+    for name in (only or CASES):
         sd, img, qs = case_inputs(name)
         out = {}
         for dt, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):

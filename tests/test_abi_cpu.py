@@ -82,3 +82,11 @@ def test_no_cpu_fallback_and_shape_contract():
     with pytest.raises(NotImplementedError):
         build_model(cotr_amd.default_args(layer='layer2', dim_feedforward=512))
     assert isinstance(NestedTensor(torch.zeros(1, 3, 256, 512), None).decompose()[0], torch.Tensor)
+    # a real key-padding mask is refused (no masked attention in the HIP path), an all-False one is what the reference feeds
+    from cotr_amd.models.cotr_model import COTR
+    img = torch.zeros(1, 3, 256, 512)
+    assert COTR._as_batch(NestedTensor(img, torch.zeros(1, 256, 512, dtype=torch.bool))) is img
+    mask = torch.zeros(1, 256, 512, dtype=torch.bool)
+    mask[0, 0, 0] = True
+    with pytest.raises(NotImplementedError):
+        COTR._as_batch(NestedTensor(img, mask))

@@ -62,6 +62,45 @@ def test_sharded_equals_single_process(tmp_path, B, Q):
         assert r0['calls'] == [(1, 4, 2)] and r1['calls'] == [(1, 3, 2)]     # queries sharded 4 + 3
 
 
+def _local_shard_worker(rank, world, port, out_dir):
+    """Every rank holds only ITS pairs (configs[3] style) and its own numpy RNG state; after the calls all ranks hold
+    the full prediction and rank 0's RNG stream."""
+    import numpy as np
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cotr_amd.dist import broadcast_numpy_rng, shard_range
+    B, Q = 5, 3
+    g = torch.Generator().manual_seed(4)
+    img, qs = torch.randn(B, 3, 4, 4, generator=g), torch.rand(B, Q, 2, generator=g)
+
+    def model(samples, queries):                                  # any per-pair function
+        return {'pred_corrs': queries * 2 + samples.mean(dim=(1, 2, 3))[:, None, None]}
+
+    lo, hi = shard_range(B, world, rank)
+    out = PairShardedModel(model, local_shard=True)(img[lo:hi], qs[lo:hi], B=B)['pred_corrs']
+    np.random.seed(100 + rank)                                    # ranks disagree ...
+    np.random.standard_normal(3)                                  # ... including the cached-gaussian part of the state
+    broadcast_numpy_rng()
+    draws = np.concatenate([np.random.permutation(10).astype(np.float64), np.random.standard_normal(2)])
+    torch.save({'out': out, 'want': model(img, qs)['pred_corrs'], 'draws': draws}, os.path.join(out_dir, f's{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_local_shards_and_rng_broadcast(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_local_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f's{r}.pt', weights_only=False) for r in range(2))
+    assert torch.equal(r0['out'], r0['want']) and torch.equal(r1['out'], r0['want'])
+    import numpy as np
+    assert np.array_equal(r0['draws'], r1['draws'])
+    np.random.seed(100)
+    np.random.standard_normal(3)
+    want = np.concatenate([np.random.permutation(10).astype(np.float64), np.random.standard_normal(2)])
+    assert np.array_equal(r0['draws'], want)                      # rank 0's stream, unperturbed
+
+
 # ---- zoom-in tasks sharded over ranks (cotr_amd.dist.sharded_zoom_engine) ------------------------------------------
 def _engine_worker(rank, world, port, golden_dir, out_dir):
     import numpy as np
@@ -70,7 +109,7 @@ def _engine_worker(rank, world, port, golden_dir, out_dir):
     torch.set_num_threads(2)
     from cotr_amd.dist import sharded_zoom_engine
     from oracle.dense_post import host_dense_post_factory
-    from tests.engine_fixtures import CyclicFakeModel, FakeModel, pil_cropper_factory, synthetic_pair
+    from tests.engine_fixtures import CyclicFakeModel, FakeModel, ids, pil_cropper_factory, synthetic_pair
     from tests.test_zoom_engine_cpu import ZOOMS, run_dense_case
     ok = True
     g = np.load(os.path.join(golden_dir, 'engine_c3_filter.npz'))          # known-scale path, converge_iters = 3
@@ -85,7 +124,7 @@ def _engine_worker(rank, world, port, golden_dir, out_dir):
         eng = sharded_zoom_engine(CyclicFakeModel(), max_pairs=40, make_cropper=pil_cropper_factory,
                                   make_dense_post=host_dense_post_factory)
         out = run_dense_case(g, eng)
-        ok &= np.array_equal(out[0], g['corrs']) and np.array_equal(out[1], g['idx'])
+        ok &= np.array_equal(out[0], g['corrs']) and np.array_equal(ids(out[1]), g['idx'])
     torch.save(bool(ok), os.path.join(out_dir, f'e{rank}.pt'))
     dist.destroy_process_group()
 

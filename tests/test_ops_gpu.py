@@ -110,6 +110,54 @@ def test_attention(nb, nq, gain):
     assert e < 2e-5, e
 
 
+@pytest.mark.parametrize('case', ['gain64', 'gain256', 'constant', 'spike_late', 'spike_every_block', 'huge_negative'])
+def test_attention_softmax_extremes(case):
+    """The attention kernel keeps scores in the log2 domain with an online (running-max) softmax split over 4 key
+    ranges: inputs that FORCE the rescale branch at chosen key blocks, one-hot rows, rows of equal scores and scores
+    far below the running maximum (exp2 underflow), each against an fp64 reference of the whole tensor."""
+    from cotr_amd import _lib
+    nb, nq = 2, 77
+    g = _g(hash(case) % 1000)
+    q = torch.randn(nb * nq, 256, generator=g) / math.sqrt(32)
+    k = torch.randn(nb * 512, 256, generator=g)
+    v = torch.randn(nb * 512, 256, generator=g)
+    if case == 'gain64':
+        q *= 64.0
+    elif case == 'gain256':
+        q *= 256.0                                     # |logit| ~ 1e3: rows are one-hot, every other exponent underflows
+    elif case == 'constant':
+        k[:] = k[:1]                                   # every key identical: all scores of a row equal -> plain mean of v
+    elif case == 'spike_late':                         # the row maximum jumps at the LAST key block of the last key split
+        k[500::512] = 40.0 * q[:nb] / q[:nb].norm(dim=1, keepdim=True)     # key 500 of each pair: a huge score for some rows
+    elif case == 'spike_every_block':                  # a larger maximum in every successive 32-key block: rescale each time
+        for blk in range(16):
+            k[blk * 32 + 5::512] *= (1.0 + blk)
+        q *= 8.0
+    elif case == 'huge_negative':
+        q *= 32.0
+        k[:, :] = -k.abs()                             # keeps a wide spread of very negative scores
+    qh = q.double().view(nb, nq, 8, 32).permute(0, 2, 1, 3)
+    kh = k.double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    vh = v.double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).permute(0, 2, 1, 3).reshape(nb * nq, 256)
+    d = G.dev()
+    kv = torch.cat([k, v], 1).to(d)
+    o = torch.full((nb * nq, 256), float('nan'), device=d)
+    lib = _lib.load_library()
+    for ns in (0, 1, 2, 8):                            # automatic (4 key splits) and explicit split counts
+        assert lib.cotr_set_attention_splits(ns) == 0
+        try:
+            rc = lib.cotr_op_attention(G.P(q.to(d)), 256, G.P(kv), G.P(kv[:, 256:]), 512, G.P(o), 256, nb, nq, G.sptr())
+        finally:
+            lib.cotr_set_attention_splits(0)
+        assert rc == 0
+        assert torch.isfinite(o).all(), (case, ns)
+        # one-hot rows amplify the fp32 rounding of the logits (|logit| * 2^-24 absolute) into the weights
+        tol = 2e-5 if case in ('constant', 'spike_late') else 2e-3 if case == 'gain256' else 3e-4
+        e = G.rel_err(o, ref)
+        assert e < tol, (case, ns, e)
+
+
 def test_layernorm():
     from cotr_amd import _lib
     g = _g(3)

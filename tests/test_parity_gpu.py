@@ -46,9 +46,16 @@ def test_golden_vectors_from_the_reference(name, golden_dir):
     assert not torch.isnan(out).any()
     e64 = cotr_oracle.px_err(out, torch.from_numpy(g['pred_f64']))
     e32 = cotr_oracle.px_err(out, torch.from_numpy(g['pred_f32']))
-    assert e64 < PX_BAR and e32 < PX_BAR, (e64, e32)
-    mem = m.debug_tap('memory').cpu().view(img.shape[0], 512, 256)[:, ::8]
-    assert float((mem - torch.from_numpy(g['memory'])).abs().max()) < 1e-4
+    # ill-conditioned cases (near one-hot softmax in all 12 layers): the reference's OWN fp32 run is off its fp64 run by
+    # more than the bar (peaky16: 1.7e-2 px, peaky32: 3.2 px - printed by make_golden.py); nothing in fp32 can do better,
+    # so there the bar is "no further from the fp64 truth than 3x the reference's fp32 run"
+    ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), torch.from_numpy(g['pred_f64']))
+    bar = max(PX_BAR, 3 * ref_gap)
+    assert e64 < bar, (e64, ref_gap)
+    if ref_gap < PX_BAR / 3:
+        assert e32 < PX_BAR, (e64, e32)
+        mem = m.debug_tap('memory').cpu().view(img.shape[0], 512, 256)[:, ::8]
+        assert float((mem - torch.from_numpy(g['memory'])).abs().max()) < 1e-4
 
 
 def test_stage_taps_against_oracle():

@@ -9,7 +9,7 @@ import torch
 
 from cotr_amd.inference import ZoomEngine, patch_boxes
 from oracle.dense_post import host_dense_post_factory
-from tests.engine_fixtures import FakeModel, synthetic_pair, pil_cropper_factory
+from tests.engine_fixtures import FakeModel, ids, synthetic_pair, pil_cropper_factory
 
 CASES = ['engine_c1_force', 'engine_c3_force', 'engine_c3_filter']
 ZOOMS = np.linspace(0.5, 0.0625, 4)
@@ -28,9 +28,10 @@ def test_trajectories_match_reference_engine(name, max_pairs, golden_dir):
     assert np.array_equal(res.loc_history.transpose(1, 0, 2), g['loc_history'])      # every level, every task
     assert np.array_equal(res.loc_to, g['best'])
     assert res.crops == int(g['total_tasks'])                                         # same number of network inputs
-    corrs = eng.cotr_corr_multiscale(img_a, img_b, ZOOMS, conv, max_corrs=n, queries_a=g['init'][:, :2],
-                                     force=bool(force), areas=[1.0, 1.0], init_b=g['init'][:, 2:])
-    assert np.array_equal(corrs, g['corrs'])
+    if force:      # known areas demand force=True (sparse_engine.py:110); the filtered conclusion of the same tasks is
+        corrs = eng.cotr_corr_multiscale(img_a, img_b, ZOOMS, conv, max_corrs=n, queries_a=g['init'][:, :2],   # checked in
+                                         force=True, areas=[1.0, 1.0], init_b=g['init'][:, 2:])   # test_return_tasks_only_*
+        assert np.array_equal(corrs, g['corrs'])
     # one model call per chunk per iteration instead of one per 32 tasks per task-iteration
     assert all(shape_q[1] == 1 for _, shape_q in model.calls)
 
@@ -114,7 +115,7 @@ def test_default_path_matches_reference_engine(name, max_pairs, golden_dir):
                      make_dense_post=host_dense_post_factory, mode=mode)
     out = run_dense_case(g, eng)
     assert np.array_equal(out[0], g['corrs'])
-    assert np.array_equal(out[1], g['idx'])
+    assert np.array_equal(ids(out[1]), g['idx'])
     if len(out) == 3:
         assert np.array_equal(out[2], g['cycle_error'])
 
@@ -145,16 +146,111 @@ def test_reference_schedule_emulation():
 
 
 def test_reference_constructor_signatures(golden_dir):
-    """SparseEngine(model, 32, mode='tile') / FasterSparseEngine(model, 32, 'tile', max_load=256) as the demos build them
-    (demo_single_pair.py:35, demo_reconstruction.py) give the reference SparseEngine's golden result."""
+    """SparseEngine(model, 32, mode='tile') as the demos build it (demo_single_pair.py:35) gives the reference
+    SparseEngine's golden result; FasterSparseEngine has its own goldens below."""
     from cotr_amd.inference import FasterSparseEngine, SparseEngine
     from tests.engine_fixtures import CyclicFakeModel
     g = np.load(os.path.join(golden_dir, 'engine_cycle_default.npz'))
-    for eng in (SparseEngine(CyclicFakeModel(), 32, mode='tile'), FasterSparseEngine(CyclicFakeModel(), 32, 'tile', max_load=256)):
-        eng.make_cropper, eng.make_dense_post = pil_cropper_factory, host_dense_post_factory
-        out = run_dense_case(g, eng)
-        assert np.array_equal(out[0], g['corrs']) and np.array_equal(out[2], g['cycle_error'])
+    eng = SparseEngine(CyclicFakeModel(), 32, mode='tile')
+    eng.make_cropper, eng.make_dense_post = pil_cropper_factory, host_dense_post_factory
+    out = run_dense_case(g, eng)
+    assert np.array_equal(out[0], g['corrs']) and np.array_equal(out[2], g['cycle_error'])
     assert SparseEngine(CyclicFakeModel(), 32).mode == 'stretching'        # the reference's default (sparse_engine.py:18)
+    assert FasterSparseEngine(CyclicFakeModel(), 32, 'tile', max_load=256).max_load == 256       # demo_reconstruction.py
+
+
+FASTER_CASES = {   # tests/golden/make_engine_golden.py FASTER_CASES: (seed, model, nq, max_corrs, conv, force, known, batch, load)
+    'engine_faster_known': (11, 'fake', 150, 150, 2, True, True, 8, 6),
+    'engine_faster_dense': (12, 'cyclic', None, 60, 1, False, False, 32, 256),
+    'engine_faster_dense_q': (13, 'cyclic', 90, 70, 3, False, False, 16, 4),
+    'engine_faster_force_q': (14, 'cyclic', 64, 64, 1, True, False, 4, 256),
+}
+
+
+def run_faster_case(name, g, tasks_only, **engine_kw):
+    from cotr_amd.inference import FasterSparseEngine
+    from tests.engine_fixtures import CyclicFakeModel
+    seed, kind, nq, max_corrs, conv, force, known, bs, load = FASTER_CASES[name]
+    img_a, img_b = synthetic_pair(seed)
+    model = FakeModel() if kind == 'fake' else CyclicFakeModel()
+    eng = FasterSparseEngine(model, bs, mode='tile', max_load=load)
+    for k, v in engine_kw.items():
+        setattr(eng, k, v)
+    np.random.seed(seed)
+    res = eng.cotr_corr_multiscale(img_a, img_b, ZOOMS, conv, max_corrs=max_corrs, queries_a=None if nq is None else g['queries'],
+                                   return_idx=True, force=force, areas=[1.0, 1.0] if known else None,
+                                   return_tasks_only=tasks_only)
+    return res, eng, model
+
+
+@pytest.mark.parametrize('name', list(FASTER_CASES))
+def test_faster_sparse_engine_matches_the_reference_class(name, golden_dir):
+    """FasterSparseEngine (sparse_engine.py:267-427: pilots, squads of nearby tasks answered from the pilot's crops,
+    np.random.permutation pilot order, zero-padded query batches, early give-up per level, fallback loop on the last
+    level) against goldens of the reference's own class with the same fake model: same correspondences, identifiers,
+    crop bookkeeping, the same sequence of model-call shapes, and the same state of EVERY task at the end (including the
+    tasks the reference's loop leaves unfinished at an earlier level)."""
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    kw = dict(make_cropper=pil_cropper_factory, make_dense_post=host_dense_post_factory)
+    (corrs, idx), eng, model = run_faster_case(name, g, False, **kw)
+    assert np.array_equal(np.asarray(corrs, dtype=np.float64).reshape(-1, 4), g['corrs'])
+    assert np.array_equal(ids(idx), g['idx'])
+    assert eng.total_tasks - (4 if FASTER_CASES[name][6] else 4) == int(g['total_tasks'])   # + our 4 patch pairs of the init pass
+    # model calls of the zoom loops (after the initial pass, which is batched differently here): [pairs, queries per pair]
+    ref_calls = [(int(r[0]), int(r[5])) for r in g['calls']][8 if FASTER_CASES[name][6] else 4:]
+    own_calls = [(a[0], b[1]) for a, b in model.calls][2 if FASTER_CASES[name][6] else 1:]
+    assert own_calls == ref_calls
+    tasks, _, _ = run_faster_case(name, g, True, **kw)
+    assert np.array_equal(np.array([t.status == 'finished' for t in tasks]), g['task_status'])
+    assert np.array_equal(np.array([t.submitted for t in tasks]), g['task_submitted'])
+    assert np.array_equal(np.array([t.total_iter for t in tasks]), g['task_iters'])
+    assert np.array_equal(np.array([len(t.loc_history) for t in tasks]), g['task_levels'])
+    assert np.array_equal(np.array([t.best_loc_to for t in tasks], dtype=np.float64), g['task_best'])
+    assert np.array_equal(np.array([t.loc_from for t in tasks], dtype=np.float64), g['task_from'])
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_return_tasks_only_gives_the_reference_task_states(name, golden_dir):
+    """cotr_corr_multiscale(..., return_tasks_only=True) (sparse_engine.py:218-219): ZoomTask objects carrying the
+    reference RefinementTask's loc_history / best_loc_to / status, concluded like SparseEngine.conclude_tasks."""
+    from cotr_amd.inference.zoom_engine import conclude_tasks
+    torch.set_num_threads(1)
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    seed, n, conv, force = (int(v) for v in g['meta'])
+    img_a, img_b = synthetic_pair(seed)
+    eng = ZoomEngine(FakeModel(), max_pairs=16, make_cropper=pil_cropper_factory)
+    tasks = eng.cotr_corr_multiscale(img_a, img_b, ZOOMS, conv, max_corrs=n, queries_a=g['init'][:, :2], force=True,
+                                     areas=[1.0, 1.0], init_b=g['init'][:, 2:], return_tasks_only=True)
+    assert len(tasks) == n and all(t.status == 'finished' and t.identifier is None for t in tasks)
+    assert np.array_equal(np.array([np.array(t.loc_history) for t in tasks]), g['loc_history'])
+    assert np.array_equal(np.array([t.best_loc_to for t in tasks]), g['best'])
+    corrs, _ = conclude_tasks(tasks, return_idx=True, force=bool(force), img_a_shape=img_a.shape[:2], img_b_shape=img_b.shape[:2])
+    assert np.array_equal(corrs, g['corrs'])
+    with pytest.raises(AssertionError):                      # the reference insists on force=True with known areas (:110)
+        eng.cotr_corr_multiscale(img_a, img_b, ZOOMS, conv, max_corrs=n, queries_a=g['init'][:, :2], force=False,
+                                 areas=[1.0, 1.0], init_b=g['init'][:, 2:])
+
+
+def test_return_tasks_only_after_an_early_exit(golden_dir):
+    """Default path stopping early (max_corrs good tasks reached): the task list holds finished, partially stepped and
+    untouched tasks exactly where the reference's group-of-32 loop leaves them; concluding it gives the golden rows."""
+    from cotr_amd.inference.zoom_engine import conclude_tasks
+    from tests.engine_fixtures import CyclicFakeModel
+    torch.set_num_threads(1)
+    for name in ('engine_dense_default', 'engine_dense_default_c3'):
+        g = np.load(os.path.join(golden_dir, name + '.npz'))
+        seed, max_corrs, conv = (int(v) for v in g['meta'][:3])
+        img_a, img_b = synthetic_pair(seed)
+        eng = ZoomEngine(CyclicFakeModel(), max_pairs=64, make_cropper=pil_cropper_factory, make_dense_post=host_dense_post_factory)
+        np.random.seed(seed)
+        tasks = eng.cotr_corr_multiscale(img_a, img_b, ZOOMS, conv, max_corrs=max_corrs, return_tasks_only=True)
+        corrs, idx = conclude_tasks(tasks, True, False, img_a.shape[:2], img_b.shape[:2])
+        assert np.array_equal(corrs[:max_corrs], g['corrs'])
+        states = {t.status for t in tasks}
+        assert 'finished' in states and 'unfinished' in states
+        for t in tasks:                                      # internal consistency of the partially stepped ones
+            assert len(t.loc_history) == (5 if t.status == 'finished' else min(t.total_iter, 3) + 1)
 
 
 def test_default_cropper_fails_loudly_without_gpu_or_with_wrong_images():

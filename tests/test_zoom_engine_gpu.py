@@ -12,7 +12,7 @@ from cotr_amd.inference import ZoomEngine
 from cotr_amd.models import build_model
 from cotr_amd.utils.synth import synth_state_dict
 from oracle import cotr_oracle, dense_post
-from tests.engine_fixtures import FakeModel, synthetic_pair, pil_cropper_factory
+from tests.engine_fixtures import FakeModel, ids, synthetic_pair, pil_cropper_factory
 
 pytestmark = pytest.mark.gpu
 ZOOMS = np.linspace(0.5, 0.0625, 4)
@@ -109,7 +109,7 @@ def test_default_path_device_crops_equal_host_crops(name, golden_dir):
     for d, h in zip(out_d, out_h):
         assert np.array_equal(d, h)
     if exact:
-        assert np.array_equal(out_d[0], g['corrs']) and np.array_equal(out_d[1], g['idx'])
+        assert np.array_equal(out_d[0], g['corrs']) and np.array_equal(ids(out_d[1]), g['idx'])
 
 
 def _dense_inputs(seed, rough):
