@@ -112,6 +112,35 @@ namespace {
     }                                                                                    \
   } while (0)
 
+// Makes the handle's device current for the duration of an ABI call and puts the caller's device back afterwards (a
+// destroy running from a Python finaliser must not change the thread's current device behind the caller's back).
+struct DeviceScope {
+  int prev = -1, prev_tls = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceScope(int dev) {
+    prev_tls = cotr_tls_device;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+    if (err == hipSuccess) cotr_tls_device = dev;
+  }
+  ~DeviceScope() {
+    cotr_tls_device = prev_tls;
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define DEVICE_SCOPE(h)                                                                  \
+  DeviceScope dev_scope_((h)->device);                                                   \
+  do {                                                                                   \
+    if (dev_scope_.err != hipSuccess) {                                                  \
+      (h)->err = std::string("hipSetDevice: ") + hipGetErrorString(dev_scope_.err);      \
+      return COTR_ERR_HIP;                                                               \
+    }                                                                                    \
+  } while (0)
+
 int ensure(cotr_ctx* h, Arena& a, size_t floats) {
   if (a.cap >= floats) return COTR_OK;
   if (a.ptr) HIPCHK(h, hipFree(a.ptr));
@@ -264,7 +293,12 @@ const char* cotr_last_error(cotr_handle h) { return h ? h->err.c_str() : g_creat
 int cotr_create(cotr_handle* out, int device) {
   if (!out) return COTR_ERR_ARG;
   *out = nullptr;
-  hipError_t e = hipSetDevice(device);
+  if (device < 0 || device >= COTR_MAX_DEVICES) {
+    g_create_error = "cotr_create: device index out of range";
+    return COTR_ERR_ARG;
+  }
+  DeviceScope scope(device);
+  hipError_t e = scope.err;
   if (e != hipSuccess) {
     g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
     return COTR_ERR_HIP;
@@ -297,7 +331,7 @@ int cotr_create(cotr_handle* out, int device) {
 
 void cotr_destroy(cotr_handle h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  DeviceScope scope(h->device);
   (void)hipDeviceSynchronize();
   prof_reset(h);
   if (h->wbuf) (void)hipFree(h->wbuf);
@@ -313,7 +347,7 @@ void cotr_destroy(cotr_handle h) {
 int cotr_load_weights(cotr_handle h, const char* const* names, const float* const* ptrs,
                       const int64_t* numels, int n) {
   if (!h || !names || !ptrs || !numels || n <= 0) return COTR_ERR_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   std::map<std::string, int> idx;
   for (int i = 0; i < n; ++i) idx[names[i]] = i;
 
@@ -499,7 +533,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   if (!h->loaded) { h->err = "cotr_encode before cotr_load_weights"; return COTR_ERR_STATE; }
   if (!img || B <= 0) { h->err = "cotr_encode: null image or B <= 0"; return COTR_ERR_ARG; }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   const int L = (int)h->dec.size();
   const size_t KVLD = (size_t)L * 2 * D;
   h->enc_B = 0;
@@ -756,7 +790,7 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
     return COTR_ERR_STATE;
   }
   if (Q == 0) return COTR_OK;
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   DecPlan d;
   if (int r = dec_plan(h, B, Q, d)) return r;
   return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
@@ -769,7 +803,7 @@ int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, i
   int r = cotr_encode(h, img, B, stream);
   if (r) return r;
   if (Q == 0) return COTR_OK;
-  HIPCHK(h, hipSetDevice(h->device));
+  DEVICE_SCOPE(h);
   DecPlan d;
   if ((r = dec_plan(h, B, Q, d))) return r;
   return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
@@ -798,6 +832,7 @@ int cotr_debug_tap(cotr_handle h, const char* name, float* dst, size_t max_elems
   if (n_elems) *n_elems = it->second.second;
   if (!dst) return COTR_OK;
   if (max_elems < it->second.second) { h->err = "tap buffer too small"; return COTR_ERR_ARG; }
+  DEVICE_SCOPE(h);
   HIPCHK(h, hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   HIPCHK(h, hipMemcpy(dst, it->second.first, it->second.second * sizeof(float), hipMemcpyDefault));
   return COTR_OK;

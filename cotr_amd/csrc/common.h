@@ -12,6 +12,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDS_DMA_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 // ---------------------------------------------------------------------------------------------
+// Per-device one-time state.  A process may hold handles on several GPUs (cotr_create(&h, device)): function attributes
+// (the > 64 KB dynamic-LDS opt-in is per device), the zero buffer of the LDS-DMA kernels and the arrival counters of the
+// fused FFN tail live on ONE device each, so they are keyed by the device that is current when a launch helper runs.
+// The ABI entry points make the handle's device current (DeviceScope, api.hip) and record it here so that the launch
+// helpers do not have to ask the runtime on every launch.
+// ---------------------------------------------------------------------------------------------
+#define COTR_MAX_DEVICES 64
+extern thread_local int cotr_tls_device;   // device made current by the innermost DeviceScope of this thread, or -1
+static inline int cotr_current_device() {
+  if (cotr_tls_device >= 0) return cotr_tls_device;
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= COTR_MAX_DEVICES) d = 0;
+  return d;
+}
+struct PerDeviceFlag {
+  bool done[COTR_MAX_DEVICES] = {};
+  bool get() const { return done[cotr_current_device()]; }
+  void set() { done[cotr_current_device()] = true; }
+};
+
+// ---------------------------------------------------------------------------------------------
 // C[M,N] = epilogue( A'[M,K] . W[N,K]^T )
 //   A' row m, column k:
 //     mode DENSE : A[m*lda + k]  (+ A2[(m % a2_row_mod)*lda2 + k] when the tile's first column n0
@@ -88,7 +109,7 @@ int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s); 
 int gemm_num_configs();
 void gemm_set_xcd_policy(int v);  // 0 column tiles over XCDs, 1 by operand size (default), 2 row tiles over XCDs
 bool gemm_cfg_supports_ln(int cfg);
-const float* gemm_zero_buffer();  // per-process device buffer of zeros (LDS-DMA padding source)
+const float* gemm_zero_buffer();  // per-DEVICE buffer of zeros (LDS-DMA padding source), on the current device
 
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]
 int launch_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,

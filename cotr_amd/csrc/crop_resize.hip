@@ -163,12 +163,12 @@ int launch_crop_resize(const uint8_t* img_a, int ha, int wa, const uint8_t* img_
     if (bytes <= 160 * 1024) break;
   }
   if (R < 1) return -1;
-  static size_t attr_bytes = 0;
-  if (bytes > attr_bytes) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(crop_resize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(160 * 1024)) != hipSuccess)
       return -2;
-    attr_bytes = 160 * 1024;
+    attr_set.set();
   }
   CropParams p;
   p.img[0] = img_a; p.img[1] = img_b;

@@ -246,14 +246,17 @@ int ffn_fused_chunks(int M) {
   return nch;
 }
 
-// per-process arrival counters of the tail (1024 rows / 32 = at most 32 row tiles are ever fused)
+// per-device arrival counters of the tail (1024 rows / 32 = at most 32 row tiles are ever fused)
 static int* ffn_counters() {
-  static int* c = nullptr;
-  if (c == nullptr) {
-    if (hipMalloc(reinterpret_cast<void**>(&c), 4096) != hipSuccess) return nullptr;
-    if (hipMemset(c, 0, 4096) != hipSuccess) return nullptr;
+  static int* c[COTR_MAX_DEVICES] = {};
+  int*& cd = c[cotr_current_device()];
+  if (cd == nullptr) {
+    int* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    cd = p;
   }
-  return c;
+  return cd;
 }
 
 static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
@@ -283,12 +286,12 @@ static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_
                            const float* ln_w, const float* ln_b, float* Y, hipStream_t s) {
   if (M <= 0) return 0;
   if (nch < 1 || nch > 16 || FF_H % (nch * 64) != 0) return -1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)kFfnSmem) != hipSuccess)
       return -2;
-    attr_set = true;
+    attr_set.set();
   }
   FfnParams p;
   p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch; p.chunk_major = g_ffn_chunk_major;

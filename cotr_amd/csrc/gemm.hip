@@ -601,13 +601,13 @@ template <int NWK, int TM, int TN, int MODE, int DB>
 static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
   constexpr int BM = TM * 32, BN = TN == 0 ? 16 : TN * 32;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
-  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  static PerDeviceFlag attr_set;  // > 64 KB of dynamic LDS needs the opt-in once per kernel and device
   constexpr size_t smem = ks_smem<NWK, TM, TN, DB>();
-  if (!attr_set) {
+  if (!attr_set.get()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_kernel<NWK, TM, TN, MODE, DB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
-    attr_set = true;
+    attr_set.set();
   }
   const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles), dim3(NWK * 64), smem, s, p);
@@ -779,13 +779,18 @@ int launch_gemm_cfg(int mode, int cfg, const GemmParams& p0, hipStream_t s) {
   }
 }
 
+thread_local int cotr_tls_device = -1;
+
 const float* gemm_zero_buffer() {
-  static float* z = nullptr;  // one device per process (one process per GPU)
-  if (z == nullptr) {
-    if (hipMalloc(reinterpret_cast<void**>(&z), 4096) != hipSuccess) return nullptr;
-    if (hipMemset(z, 0, 4096) != hipSuccess) return nullptr;
+  static float* z[COTR_MAX_DEVICES] = {};  // one per device, on that device
+  float*& zd = z[cotr_current_device()];
+  if (zd == nullptr) {
+    float* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    zd = p;
   }
-  return z;
+  return zd;
 }
 
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s) {

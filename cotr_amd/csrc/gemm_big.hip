@@ -226,12 +226,12 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   if (((uintptr_t)p.C & 15) || ((uintptr_t)p.residual & 15)) return -1;
   if (p.zeros == nullptr) p.zeros = gemm_zero_buffer();
   if (p.zeros == nullptr) return -2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
-    attr_set = true;
+    attr_set.set();
   }
   const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST>), dim3(tiles), dim3(256), smem, s, p);

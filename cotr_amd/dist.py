@@ -24,8 +24,16 @@ def shard_range(n, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# A world of ONE rank needs no exchange and the helpers below return early.  The single-GPU box has no second rank to talk
+# to, so tests/test_dist_gpu.py sets this to True: the collectives are then issued even at world size 1 and really go through
+# RCCL on device buffers (communicator initialisation, all_gather_into_tensor, broadcast, reduce_scatter_tensor).
+FORCE_COLLECTIVES = False
+
+
 def _active(group=None):
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or FORCE_COLLECTIVES
 
 
 def comm_device(group=None):

@@ -18,7 +18,10 @@
  *  - `stream` is a hipStream_t (NULL = the default stream).  All work is enqueued on it;
  *    nothing synchronises the device except cotr_load_weights / cotr_destroy / cotr_debug_tap.
  *  - packed weights and scratch live in memory owned by the handle (grow-only arenas).
- *  - one handle per device per caller thread; a handle is not thread-safe.
+ *  - one handle per device per caller thread; a handle is not thread-safe.  Handles on different
+ *    devices may coexist in one process: every call makes its handle's device current for its
+ *    duration and restores the caller's current device before returning; one-time kernel
+ *    attributes and helper buffers are kept per device.
  *  - a NaN in the inputs/weights yields NaN outputs, never a trap: the reference's engines
  *    raise ValueError('NaN in prediction') themselves (sparse_engine.py:54-55).
  *
@@ -174,7 +177,10 @@ int cotr_dense_merge(const float* maps, const int32_t* boxes, int n_pairs, int s
  * of the squared images back to the image shape (sparse_engine.py:124-129). */
 int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, cotr_stream stream);
 
-/* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
+/* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests -------------------
+ * The cotr_set_* functions WITHOUT a handle argument below are PROCESS-WIDE tuning / experiment switches
+ * (they change which kernels every handle of the process launches); they are not part of the drop-in
+ * boundary and a binding never needs them. */
 int cotr_gemm_num_configs(void);
 /* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB
  * Infinity Cache, larger ones fill the CUs better */
