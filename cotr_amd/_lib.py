@@ -45,6 +45,12 @@ _PROTOS = {
                                        ctypes.c_void_p]),
     'cotr_op_attention': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int, c_float_p,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_attention_fused': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float,
+                                               c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p, c_float_p,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_dec_head': (ctypes.c_int, [c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_ln_reduce': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                         ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_layernorm': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_ffn_block': (ctypes.c_int, [c_float_p] * 9 + [ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_ffn_chunks': (ctypes.c_int, [ctypes.c_int]),
@@ -59,9 +65,16 @@ _PROTOS = {
     'cotr_set_encode_chunk': (ctypes.c_int, [ctypes.c_int]),
     'cotr_gemm_num_configs': (ctypes.c_int, []),
     'cotr_set_ffn_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_attention_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_head_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_splits': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_fused_stem': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_dual_conv': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_op_conv_dual_cfg': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_set_ffn_tail': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_ffn_preln': (ctypes.c_int, [ctypes.c_int]),
     'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,

@@ -57,6 +57,8 @@ struct Arena {
 };
 
 thread_local std::string g_create_error;
+int g_head_fuse_max_rows = 2048;  // decoder.norm + corr_embed as one row-local launch up to this many rows
+int g_attn_fuse_max_rows = 1024;  // attention with the out-projection (and, in the decoder, the q projection) fused in, up to this many rows
 int g_ffn_fuse_max_rows = 1024;  // fused FFN block up to this many rows (forward at B=1,Q=1000: 1.064 vs 1.083 ms; slower from ~1300 rows on)
 }  // namespace
 
@@ -254,8 +256,7 @@ int ffn_block_pre(cotr_ctx* h, const float* xpre, const float* pre_w, const floa
   return ffn_block(h, x1buf, l1w, l1b, l2w, l2b, nw, nb, hid, tmp, y, M, s);
 }
 
-int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int relu, float* y, int B,
-         int Hin, int Win, hipStream_t s) {
+GemmParams conv_params(const ConvW& c, const float* x, const float* residual, int relu, float* y, int B, int Hin, int Win) {
   GemmParams p = base_params();
   const int pad = c.k / 2;
   p.Hin = Hin; p.Win = Win; p.Cin = c.cin;
@@ -266,6 +267,40 @@ int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int
   p.A = x; p.lda = c.cin;
   p.W = c.w; p.C = y; p.ldc = c.cout;
   p.scale = c.scale; p.bias = c.bias; p.residual = residual; p.ldr = c.cout; p.relu = relu;
+  return p;
+}
+
+bool g_dual_conv = true;  // cotr_set_dual_conv
+
+// Entry block of a ResNet stage: the downsample branch and conv1 both read the block input (torchvision Bottleneck.forward)
+// and are independent - in the latency-bound regime (a pair or two per pass) they go out as ONE launch whose grid is the
+// tiles of both problems.  Returns 1 if it launched them, 0 if the caller should launch them one by one, < 0 on error.
+int conv_pair(cotr_ctx* h, const ConvW& cd, const ConvW& c1, const float* x, float* yd, float* y1, int B, int Hin, int Win,
+              hipStream_t s) {
+  if (!g_dual_conv) return 0;
+  const GemmParams pd = conv_params(cd, x, nullptr, 0, yd, B, Hin, Win), p1 = conv_params(c1, x, nullptr, 1, y1, B, Hin, Win);
+  if (p1.M > 16384) return 0;   // batched: throughput-bound, each problem keeps its own best configuration
+  const int cfd = gemm_pick_config(GEMM_CONV, pd), cf1 = gemm_pick_config(GEMM_CONV, p1);
+  const bool d_larger = (double)pd.M * pd.N >= (double)p1.M * p1.N;
+  const int order[2] = {d_larger ? cfd : cf1, d_larger ? cf1 : cfd};   // the larger problem's configuration first
+  for (int cfg : order) {
+    if (cfg < 0 || !gemm_cfg_supports_dual(cfg)) continue;
+    const int r = launch_gemm_dual_cfg(GEMM_CONV, cfg, pd, p1, s);
+    if (r == -1) continue;                                              // does not fit one of the two shapes
+    if (r != 0) { h->err = "launch failed: dual conv (hip error)"; return COTR_ERR_HIP; }
+    if (h->prof >= 2) {
+      char nm[128];
+      snprintf(nm, sizeof nm, "conv1x1/%d+conv1x1/1 %dx%dx%d+%dx%dx%d cfg%d", cd.stride, pd.M, pd.N, pd.K, p1.M, p1.N, p1.K, cfg);
+      prof_mark(h, nm, s, 2);
+    }
+    return 1;
+  }
+  return 0;
+}
+
+int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int relu, float* y, int B,
+         int Hin, int Win, hipStream_t s) {
+  const GemmParams p = conv_params(c, x, residual, relu, y, B, Hin, Win);
   KCHK(h, launch_gemm(GEMM_CONV, p, s), "conv");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "conv%dx%d/%d %dx%dx%d cfg%d", c.k, c.k, c.stride, p.M, p.N, p.K, gemm_pick_config(GEMM_CONV, p)); prof_mark(h, nm, s, 2); }
   return COTR_OK;
@@ -605,12 +640,16 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
         flip ^= 1;
         int r;
         const float* idt = x;
+        bool c1_done = false;
         if (b == 0) {  // downsample branch (1x1, strided)
           const ConvW& cd = h->convs[ci++];
-          if ((r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
+          const int pr = conv_pair(h, cd, c1, x, b_d, b_t1, Bc, H, W, s);
+          if (pr < 0) return pr;
+          c1_done = pr == 1;
+          if (!c1_done && (r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
           idt = b_d;
         }
-        if ((r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
+        if (!c1_done && (r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
         if ((r = conv(h, c2, b_t1, nullptr, 1, b_t2, Bc, H, W, s))) return r;
         if ((r = conv(h, c3, b_t2, idt, 1, y, Bc, Ho, Wo, s))) return r;
         x = y;
@@ -640,12 +679,22 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       const EncW& e = h->enc[li];
       // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
       if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
-      KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
-      prof_mark(h, "attention enc", s, 2);
-      if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
       float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
-      if ((r = ffn_block_pre(h, t_tmp, e.n1w, e.n1b, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_x1, t_ao, y, M, s)))
-        return r;
+      if (M <= g_attn_fuse_max_rows && M <= g_ffn_fuse_max_rows && !g_ffn_preln) {
+        // out_proj inside the attention kernel (8 per-head partial outputs), summed + bias + residual + norm1 by ln_reduce
+        KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
+                                       nullptr, 0, e.out_w, t_hid, Bc, TOK, s), "attention+out_proj");
+        prof_mark(h, "attention+oproj enc", s, 2);
+        KCHK(h, launch_ln_reduce(t_hid, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
+        prof_mark(h, "ln_reduce heads", s, 2);
+        if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_tmp, y, M, s))) return r;
+      } else {
+        KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
+        prof_mark(h, "attention enc", s, 2);
+        if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
+        if ((r = ffn_block_pre(h, t_tmp, e.n1w, e.n1b, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_x1, t_ao, y, M, s)))
+          return r;
+      }
       xin = y;
     }
     prof_mark(h, "encoder", s);
@@ -709,9 +758,10 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
 
 // query-side prologue of one chunk: lin_sine encoding of the queries (cotr_model.py:34-36) and layer 0's
 // q = Wq(0 + query_pos) * 32^-0.5 (tgt == 0 at layer 0, transformer.py:54).  Depends on the queries only.
-int dec_prologue(cotr_ctx* h, const DecPlan& d, const float* qsrc, int nb, int nq, int Q, hipStream_t s) {
+int dec_prologue(cotr_ctx* h, const DecPlan& d, const float* qsrc, int nb, int nq, int Q, hipStream_t s, bool fused) {
   KCHK(h, launch_posenc(qsrc, d.qpos, nb, nq, Q, s), "posenc");
   prof_mark(h, "posenc", s, 2);
+  if (fused) return COTR_OK;   // the attention kernel projects its own queries
   const DecW& w = h->dec[0];
   return linear(h, d.qpos, nullptr, 0, 1, 0, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, nb * nq, D, D, s);
 }
@@ -726,10 +776,23 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   const int KVLD = L * 2 * D;
   const int R = nb * nq;
   int r;
-  if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s))) return r;
+  const bool fused = R <= g_attn_fuse_max_rows && R <= g_ffn_fuse_max_rows && !g_ffn_preln;
+  if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s, fused))) return r;
   // transformer.py:185-201 per layer (cross-attention only, post-norm)
   for (int li = 0; li < L; ++li) {
     const DecW& w = h->dec[li];
+    if (fused) {
+      // q = Wq(tgt + query_pos) * 32^-0.5 in the attention kernel's prologue (tgt == 0 at layer 0, transformer.py:54), out_proj
+      // in its epilogue (8 per-head partials), then ln_reduce: sum + bias + residual + norm2; FFN block; 4 launches per layer
+      KCHK(h, launch_attention_fused(nullptr, 0, li == 0 ? nullptr : d.tgt, d.qpos, w.q_w, w.q_b, QSCALE,
+                                     kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, nullptr, 0, w.out_w, d.hid,
+                                     nb, nq, s), "q_proj+attention+out_proj");
+      prof_mark(h, "qproj+attention+oproj dec", s, 2);
+      KCHK(h, launch_ln_reduce(d.hid, 8, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
+      prof_mark(h, "ln_reduce heads", s, 2);
+      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, d.tgt, R, s))) return r;
+      continue;
+    }
     // q = Wq(tgt + query_pos) * 32^-0.5 ; tgt == 0 at layer 0 (transformer.py:54): computed by dec_prologue
     if (li > 0 && (r = linear(h, d.tgt, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s))) return r;
     KCHK(h, launch_attention(d.q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d.ao, D, nb, nq, s),
@@ -740,6 +803,12 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       return r;
   }
   // decoder.norm + corr_embed on the last layer only (the reference computes all 6 and keeps [-1])
+  if (R <= g_head_fuse_max_rows) {   // one row-local launch (head.hip); 'hs' is only written for the debug tap
+    KCHK(h, launch_dec_head(d.tgt, h->dn_w, h->dn_b, h->mlp_w[0], h->mlp_b[0], h->mlp_w[1], h->mlp_b[1], h->mlp_w[2], h->mlp_b[2],
+                            h->keep_taps ? d.pre2 : nullptr, odst, nb, nq, Q, s), "dec_head");
+    prof_mark(h, "dec_head norm+mlp", s, 2);
+    return COTR_OK;
+  }
   if ((r = layernorm(h, d.tgt, h->dn_w, h->dn_b, d.pre2, R, s))) return r;
   if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s))) return r;
   if ((r = linear(h, d.ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d.q, R, D, D, s))) return r;
@@ -920,6 +989,26 @@ int cotr_op_attention(const float* q, int ldq, const float* k, const float* v, i
   return op_ret(launch_attention(q, ldq, k, v, ldkv, o, ldo, nb, nq, static_cast<hipStream_t>(stream)));
 }
 
+int cotr_op_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                            float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                            float* part, int nb, int nq, cotr_stream stream) {
+  return op_ret(launch_attention_fused(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, o, ldo, wo, part, nb, nq,
+                                       static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
+                     const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
+                     cotr_stream stream) {
+  if (!x || !nw || !nb || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out) return COTR_ERR_ARG;
+  return op_ret(launch_dec_head(x, nw, nb, w0, b0, w1, b1, w2, b2, hs, out, nb_pairs, nq, q_total, static_cast<hipStream_t>(stream)));
+}
+
+int cotr_op_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
+                      float* y, int rows, cotr_stream stream) {
+  if (!parts || np < 1 || !bias || !w || !b || !y) return COTR_ERR_ARG;
+  return op_ret(launch_ln_reduce(parts, np, bias, residual, w, b, y, rows, static_cast<hipStream_t>(stream)));
+}
+
 int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, int rows, cotr_stream stream) {
   return op_ret(launch_layernorm(x, w, b, y, rows, static_cast<hipStream_t>(stream)));
 }
@@ -979,6 +1068,16 @@ int cotr_set_encode_chunk(int pairs) {
   return COTR_OK;
 }
 
+int cotr_set_head_fusion_max_rows(int rows) {
+  g_head_fuse_max_rows = rows < 0 ? 0 : rows;
+  return COTR_OK;
+}
+
+int cotr_set_attention_fusion_max_rows(int rows) {
+  g_attn_fuse_max_rows = rows < 0 ? 0 : rows;
+  return COTR_OK;
+}
+
 int cotr_set_ffn_fusion_max_rows(int rows) {
   g_ffn_fuse_max_rows = rows < 0 ? 0 : rows;
   return COTR_OK;
@@ -996,6 +1095,11 @@ int cotr_set_ffn_preln(int enable) {
 
 int cotr_set_ffn_tail(int enable) {
   g_ffn_tail = enable != 0;
+  return COTR_OK;
+}
+
+int cotr_set_dual_conv(int enable) {
+  g_dual_conv = enable != 0;
   return COTR_OK;
 }
 
@@ -1063,6 +1167,15 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
   p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout;
   p.scale = scale; p.bias = bias; p.residual = residual; p.ldr = Cout; p.relu = relu;
   return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
+}
+
+// two independent convolutions of the same block input in one launch (tests): both outputs, explicit config
+int cotr_op_conv_dual_cfg(const float* x, const float* w0, const float* scale0, const float* bias0, int relu0, float* y0, int Cout0,
+                          int ksize0, int stride0, const float* w1, const float* scale1, const float* bias1, int relu1, float* y1,
+                          int Cout1, int ksize1, int stride1, int B, int Hin, int Win, int Cin, int cfg, cotr_stream stream) {
+  ConvW c0 = {w0, scale0, bias0, Cin, Cout0, ksize0, stride0}, c1 = {w1, scale1, bias1, Cin, Cout1, ksize1, stride1};
+  const GemmParams p0 = conv_params(c0, x, nullptr, relu0, y0, B, Hin, Win), p1 = conv_params(c1, x, nullptr, relu1, y1, B, Hin, Win);
+  return op_ret(launch_gemm_dual_cfg(GEMM_CONV, cfg, p0, p1, static_cast<hipStream_t>(stream)));
 }
 
 // ---- engine-side input construction --------------------------------------------------

@@ -24,11 +24,34 @@
 #define ATT_KEYS 512
 #define ATT_HD 32
 
-template <int NS>
+// Optional fusions for the small-row regime (one pair / ~1000 query rows, where every launch costs ~4 us of latency):
+//   QP  q-projection prologue: q_h = ((x + x2) . Wq_h^T + bq_h) * qscale computed by the workgroup itself for its 32 queries
+//       and its head (COTR/models/transformer.py:192 with nn.MultiheadAttention's packed in_proj): Q^T = Wq_h . X^T lands in
+//       the MFMA D layout, which IS the B-operand layout of S^T = K . Q^T below (lane = query, register r = head dim
+//       (r&3) + 8*(r>>2) + 4*half) - no transpose, no launch of its own.  The 4 wavefronts split the 256-deep contraction
+//       and sum through LDS in a fixed order.
+//   OP  out-projection epilogue: the workgroup multiplies its merged 32 x 32 O tile by the head's 32 columns of W_out
+//       (transformer.py:153,195: out_proj) and writes a partial [32 x 256] row block; the 8 per-head partials are summed, biased,
+//       added to the residual and normalised by ln_reduce_kernel - the launch that followed the projection anyway.
+struct AttnFuse {
+  const float* x;      // QP: [rows][256] decoder state (nullptr with x2 only: layer 0, tgt == 0)
+  const float* x2;     // QP: [rows][256] query encoding added to x (may be nullptr)
+  const float* wq;     // QP: [256][256] q rows of in_proj_weight
+  const float* bq;     // QP: [256]
+  float qscale;        // QP: head_dim^-0.5
+  const float* wo;     // OP: out_proj.weight [256][256]
+  float* part;         // OP: [8][rows_total][256]
+  int rows_total;      // OP: rows of one partial
+  int wt;              // OP: write-through (sc1) stores for the partials (read once, by every XCD)
+};
+
+template <int NS, bool QP, bool OP>
 __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restrict__ q, int ldq,
                                                             const float* __restrict__ k,
                                                             const float* __restrict__ v, int ldkv,
-                                                            float* __restrict__ o, int ldo, int nq, int head_major) {
+                                                            float* __restrict__ o, int ldo, int nq, int head_major,
+                                                            const AttnFuse fz) {
+  static_assert(!(QP || OP) || NS == 4, "the fused variants are written for 4 key splits");
   constexpr int NBLK = ATT_KEYS / NS / 32;  // key blocks per wavefront
   constexpr int RPW = 16 / NS;              // accumulator rows finished per wavefront in the merge
   __shared__ float lds_o[NS][16][64];
@@ -51,13 +74,54 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
 
   // Q^T fragment (B operand): lane holds q[qi][j*8 + hh*4 + e]
   f32x4 qf[4];
+  if constexpr (QP) {
+    // wave w contracts over model channels [64w, 64w + 64): A = Wq_h (lane: head dim l31, k half hh), B = X^T (lane: query l31)
+    f32x16 qacc;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    qf[j] = q_ok ? *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4) : z;
-    // scores in the log2 domain: softmax(s) = 2^(s*log2e - max) / sum, so every exponential below is ONE v_exp_f32
-    // (expf's range reduction is 13 VALU instructions per element: 8.1 instead of 9.6 us per call at one pair)
-    qf[j] *= 1.44269504088896340736f;
+    for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
+    const float* wrow = fz.wq + (size_t)(head * ATT_HD + l31) * 256 + wave * 64 + hh * 4;
+    const float* xrow = fz.x ? fz.x + qrow * 256 + wave * 64 + hh * 4 : nullptr;
+    const float* x2row = fz.x2 ? fz.x2 + qrow * 256 + wave * 64 + hh * 4 : nullptr;
+    f32x4 wa[8], xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      wa[j] = *reinterpret_cast<const f32x4*>(wrow + j * 8);
+      f32x4 b = {0.f, 0.f, 0.f, 0.f};
+      if (q_ok) {
+        if (xrow) b = *reinterpret_cast<const f32x4*>(xrow + j * 8);
+        if (x2row) b += *reinterpret_cast<const f32x4*>(x2row + j * 8);
+      }
+      xb[j] = b;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][e], xb[j][e], qacc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds_o[wave][r][lane] = qacc[r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = j * 4 + e;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NS; ++w) sum += lds_o[w][r][lane];
+        // D row r of this lane = head dim (r&3) + 8*(r>>2) + 4*hh = j*8 + hh*4 + e
+        sum += fz.bq[head * ATT_HD + j * 8 + hh * 4 + e];
+        qf[j][e] = sum * fz.qscale * 1.44269504088896340736f;
+      }
+    __syncthreads();   // lds_o is reused by the key-split merge below
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      qf[j] = q_ok ? *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4) : z;
+      // scores in the log2 domain: softmax(s) = 2^(s*log2e - max) / sum, so every exponential below is ONE v_exp_f32
+      // (expf's range reduction is 13 VALU instructions per element: 8.1 instead of 9.6 us per call at one pair)
+      qf[j] *= 1.44269504088896340736f;
+    }
   }
   const size_t key0 = (size_t)pair * ATT_KEYS + (size_t)wave * (ATT_KEYS / NS);
   // K fragment (A operand of S^T): lane (key l31, half hh) reads k[key][j*8 + hh*4 .. +3]
@@ -147,6 +211,35 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
     lds_out[l31][(r & 3) + 8 * (r >> 2) + 4 * hh] = acc * inv;
   }
   __syncthreads();
+  if constexpr (OP) {
+    // partial[head][row][n] = sum_d O[row][d] * Wo[n][head*32 + d]: wave w -> output columns [64w, 64w + 64)
+    float* pbase = fz.part + ((size_t)head * fz.rows_total + (size_t)pair * nq) * 256;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int n = (wave * 2 + nb) * 32 + l31;
+      const float* worow = fz.wo + (size_t)n * 256 + head * ATT_HD + hh * 4;
+      f32x16 pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(&lds_out[l31][j * 8 + hh * 4]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(worow + j * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], pacc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qo = qtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (qo < nq) {
+          float* dst = pbase + (size_t)qo * 256 + n;
+          if (fz.wt) __hip_atomic_store(dst, pacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *dst = pacc[r];
+        }
+      }
+    }
+    if (o == nullptr) return;
+  }
   for (int i = t; i < 256; i += NS * 64) {  // 32 rows x 128 B, one float4 per thread: coalesced row stores
     const int row = i >> 3, c4 = (i & 7) * 4;
     const int qo = qtile * 32 + row;
@@ -157,6 +250,8 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
 }
 
 static int g_att_splits = 0;  // 0 = automatic
+static int g_att_part_wt = 1;  // write-through stores for the out-projection partials (set_attention_part_wt)
+void set_attention_part_wt(int v) { g_att_part_wt = v; }
 static int g_att_head_major = 0;  // measured: -88 MB of fabric traffic per forward, +0.4 % time -> off (cotr_set_xcd_mapping bit 3)
 void set_attention_head_major(int v) { g_att_head_major = v; }
 void set_attention_splits(int ns) { g_att_splits = ns; }
@@ -168,26 +263,53 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
   if (nb <= 0 || nq <= 0) return 0;
   if (ldq % 4 || ldkv % 4 || ldo % 4) return -1;
   dim3 grid(((nq + 31) / 32) * 8, 1, nb);
+  AttnFuse fz = {};
   int ns = g_att_splits;
   if (ns == 0) ns = 4;
   switch (ns) {
     case 1:
-      hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(64), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
+      hipLaunchKernelGGL((attention_kernel<1, false, false>), grid, dim3(64), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     case 2:
-      hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(128), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
+      hipLaunchKernelGGL((attention_kernel<2, false, false>), grid, dim3(128), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     case 4:
-      hipLaunchKernelGGL(attention_kernel<4>, grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
+      hipLaunchKernelGGL((attention_kernel<4, false, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     case 8:
-      hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(512), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
+      hipLaunchKernelGGL((attention_kernel<8, false, false>), grid, dim3(512), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     case 16:
-      hipLaunchKernelGGL(attention_kernel<16>, grid, dim3(1024), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major);
+      hipLaunchKernelGGL((attention_kernel<16, false, false>), grid, dim3(1024), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     default:
       return -1;
   }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// Attention with the q projection in the prologue (qp: x/x2/wq/bq/qscale, q unused) and / or the output projection in the
+// epilogue (op: partial outputs [8][nb*nq][256] to `part`, o may be nullptr).  4 key splits.
+int launch_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                           float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                           float* part, int nb, int nq, hipStream_t s) {
+  if (nb <= 0 || nq <= 0) return 0;
+  const bool qp = wq != nullptr, op = wo != nullptr;
+  if (ldkv % 4 || (o && ldo % 4) || (!qp && (q == nullptr || ldq % 4))) return -1;
+  if (qp && (bq == nullptr || (x == nullptr && x2 == nullptr))) return -1;
+  if (op && part == nullptr) return -1;
+  if (!op && o == nullptr) return -1;
+  dim3 grid(((nq + 31) / 32) * 8, 1, nb);
+  AttnFuse fz = {};
+  fz.x = x; fz.x2 = x2; fz.wq = wq; fz.bq = bq; fz.qscale = qscale;
+  fz.wo = wo; fz.part = part; fz.rows_total = nb * nq; fz.wt = g_att_part_wt;
+  if (qp && op)
+    hipLaunchKernelGGL((attention_kernel<4, true, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+  else if (qp)
+    hipLaunchKernelGGL((attention_kernel<4, true, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+  else if (op)
+    hipLaunchKernelGGL((attention_kernel<4, false, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+  else
+    hipLaunchKernelGGL((attention_kernel<4, false, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

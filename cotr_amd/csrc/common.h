@@ -82,9 +82,8 @@ struct GemmParams {
 //   M-split  an XCD owns every 8th ROW tile and walks all column tiles: activations once chip-wide, W once per XCD
 //            (right when the activation operand is the larger one: layer1/layer2 at any batch, everything when batched)
 // Time-neutral at one pair (the path is latency-bound there); it is what the L2<->fabric byte counters see.
-__device__ __forceinline__ bool gemm_tile_coords(const GemmParams& p, int bm, int bn, int& m0, int& n0) {
+__device__ __forceinline__ bool gemm_tile_coords(const GemmParams& p, int bm, int bn, int bid, int& m0, int& n0) {
   const int tiles_n = p.N / bn;
-  const int bid = blockIdx.x;
   if (p.xcd_msplit) {
     const int tiles_m = (p.M + bm - 1) / bm;
     const int mt = (bid / (8 * tiles_n)) * 8 + (bid & 7);
@@ -106,6 +105,12 @@ int launch_gemm(int mode, const GemmParams& p, hipStream_t s);            // tun
 int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s);  // explicit config (tuning, tests)
 int gemm_pick_config(int mode, const GemmParams& p);
 int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s);  // gemm_big.hip: 0 = 128x128, 1 = 128x64
+// Two INDEPENDENT problems of the same mode in ONE launch (grid = tiles of p0 followed by tiles of p1, same kernel
+// configuration): the downsample branch of a bottleneck next to its conv1 (torchvision Bottleneck.forward: both read the block
+// input).  Supported configurations: the k-split ones without LDS-DMA (kinds 1, 2) and the large tiles (kind 4).
+int launch_gemm_dual_cfg(int mode, int cfg, const GemmParams& p0, const GemmParams& p1, hipStream_t s);
+int launch_gemm_big_dual(int mode, int variant, const GemmParams& p0, const GemmParams& p1, hipStream_t s);
+bool gemm_cfg_supports_dual(int cfg);
 int gemm_num_configs();
 void gemm_set_xcd_policy(int v);  // 0 column tiles over XCDs, 1 by operand size (default), 2 row tiles over XCDs
 bool gemm_cfg_supports_ln(int cfg);
@@ -115,6 +120,12 @@ const float* gemm_zero_buffer();  // per-DEVICE buffer of zeros (LDS-DMA padding
 int launch_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
                      int nb, int nq, hipStream_t s);
 
+// the same with the q projection as prologue (wq != nullptr: q = ((x + x2) . wq_h^T + bq_h) * qscale, `q` unused) and / or the
+// output projection as epilogue (wo != nullptr: per-head partial outputs [8][nb*nq][256] to `part`; `o` may be nullptr)
+int launch_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                           float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                           float* part, int nb, int nq, hipStream_t s);
+
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s);
 // lin_sine encoding; point (bi, qi) read from pts[((bi*q_total) + qi)*2], written to row bi*nq+qi
 int launch_posenc(const float* pts, float* y, int nb, int nq, int q_total, hipStream_t s);
@@ -123,6 +134,11 @@ int launch_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, hip
 // y[(bi*q_total + qi)*2 + j] = x[bi*nq+qi, :] . w[j, :] + b[j]   (last corr_embed layer, 256 -> 2)
 int launch_head2(const float* x, const float* w, const float* b, float* y, int nb, int nq, int q_total,
                  hipStream_t s);
+
+// decoder.norm + corr_embed (256 -> 256 -> 256 -> 2) in one row-local launch (head.hip); hs (normalised rows) optional
+int launch_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
+                    const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
+                    hipStream_t s);
 
 // conv1 7x7/2 + FrozenBN + ReLU + maxpool 3x3/2 in one launch (stem_pool.hip): img NCHW [B,3,256,512] -> [B,64,128,64]
 int launch_stem_pool(const float* img, const float* w, int wk, const float* scale, const float* bias, float* out, int B,

@@ -15,6 +15,7 @@
 // rows those R output rows need goes to LDS (uchar4 per pixel), the vertical pass reads it back.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.h"
 
 #define OUT 256
 #define PRECISION_BITS 22

@@ -25,6 +25,7 @@
 
 template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  const int bid = blockIdx.x;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RA = BM / 32, RW = BN / 32;
   __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDSLD];
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 
   const int t = threadIdx.x;
   int m0, n0;
-  if (!gemm_tile_coords(p, BM, BN, m0, n0)) return;
+  if (!gemm_tile_coords(p, BM, BN, bid, m0, n0)) return;
   const int lr = t >> 3, lc = (t & 7) * 4;
   const int KT = p.K / BK;
 
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 // launch) and the same fused epilogue is applied.
 // ---------------------------------------------------------------------------------------------
 template <int NWK, int TM, int TN, int MODE, int DB>
-__global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid) {
   constexpr int NT = NWK * 64;
   // TN == 0 selects the 32 x 16 tile built from v_mfma_f32_16x16x4_f32 (two 16-row blocks x one 16-column block):
   // twice the workgroups of the 32 x 32 tile for the M <= 512, N = 256 shapes that otherwise fill half the CUs
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
 
   const int t = threadIdx.x;
   int m0, n0;
-  if (!gemm_tile_coords(p, BM, BN, m0, n0)) return;
+  if (!gemm_tile_coords(p, BM, BN, bid, m0, n0)) return;
   const int lr = t / C4, lc4 = t % C4;
   const int ktl = lc4 >> 3;            // which 32-wide k-tile of the step this thread loads
   const int lcc = (lc4 & 7) * 4;       // column inside that k-tile
@@ -536,6 +537,18 @@ __global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
     }
 }
 
+template <int NWK, int TM, int TN, int MODE, int DB>
+__global__ __launch_bounds__(NWK * 64) void gemm_ks_kernel(const GemmParams p) {
+  gemm_ks_body<NWK, TM, TN, MODE, DB>(p, blockIdx.x);
+}
+
+// two independent problems, one grid: workgroups [0, tiles0) work on p0, the rest on p1 (workgroup-uniform branch)
+template <int NWK, int TM, int TN, int MODE, int DB>
+__global__ __launch_bounds__(NWK * 64) void gemm_ks_dual_kernel(const GemmParams p0, const GemmParams p1, const int tiles0) {
+  if ((int)blockIdx.x < tiles0) gemm_ks_body<NWK, TM, TN, MODE, DB>(p0, blockIdx.x);
+  else gemm_ks_body<NWK, TM, TN, MODE, DB>(p1, (int)blockIdx.x - tiles0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // launch configurations; the per-shape choice comes from a table measured on the MI355X
 // (tools/tune_gemm.py -> gemm_tuned.inc) with a heuristic for shapes not in the table.
@@ -614,6 +627,24 @@ static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+template <int NWK, int TM, int TN, int MODE, int DB>
+static int launch_ks_dual(const GemmParams& p0, const GemmParams& p1, hipStream_t s) {
+  static_assert(DB != 2, "the LDS-DMA variant is not instantiated for dual launches");
+  constexpr int BM = TM * 32, BN = TN == 0 ? 16 : TN * 32;
+  if (p0.N % BN != 0 || p0.K % BK != 0 || p0.M <= 0 || p1.N % BN != 0 || p1.K % BK != 0 || p1.M <= 0) return -1;
+  static PerDeviceFlag attr_set;
+  constexpr size_t smem = ks_smem<NWK, TM, TN, DB>();
+  if (!attr_set.get()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ks_dual_kernel<NWK, TM, TN, MODE, DB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return -2;
+    attr_set.set();
+  }
+  const int tiles0 = gemm_grid_tiles(p0, BM, BN), tiles1 = gemm_grid_tiles(p1, BM, BN);
+  hipLaunchKernelGGL((gemm_ks_dual_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles0 + tiles1), dim3(NWK * 64), smem, s, p0, p1, tiles0);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <int NWK, int TM, int TN, int MODE, int DB = 0>
 static int launch_ks(const GemmParams& p, hipStream_t s) {
   if constexpr (DB == 2) {
@@ -660,6 +691,27 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 27: return launch_gemm_big(MODE, 1, p, s);
     case 28: return launch_gemm_big(MODE, 2, p, s);
     case 29: return launch_gemm_big(MODE, 3, p, s);
+    default: return -1;
+  }
+}
+
+// dual launches are instantiated for the convolution mode only, and only for the configurations the one-pair schedule of
+// the bottleneck entry blocks uses (measured table): k-split 4 waves 32x32 (4), 8 waves 32x64 (10), their double-buffered
+// forms (14, 16), 8 waves 32x32 (3, 13) and the large tiles (26, 27)
+bool gemm_cfg_supports_dual(int cfg) {
+  return cfg == 3 || cfg == 4 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 16 || cfg == 26 || cfg == 27;
+}
+
+static int launch_dual_conv(int cfg, const GemmParams& p0, const GemmParams& p1, hipStream_t s) {
+  switch (cfg) {
+    case 3: return launch_ks_dual<8, 1, 1, GEMM_CONV, 0>(p0, p1, s);
+    case 4: return launch_ks_dual<4, 1, 1, GEMM_CONV, 0>(p0, p1, s);
+    case 10: return launch_ks_dual<8, 1, 2, GEMM_CONV, 0>(p0, p1, s);
+    case 13: return launch_ks_dual<8, 1, 1, GEMM_CONV, 1>(p0, p1, s);
+    case 14: return launch_ks_dual<4, 1, 1, GEMM_CONV, 1>(p0, p1, s);
+    case 16: return launch_ks_dual<8, 1, 2, GEMM_CONV, 1>(p0, p1, s);
+    case 26: return launch_gemm_big_dual(GEMM_CONV, 0, p0, p1, s);
+    case 27: return launch_gemm_big_dual(GEMM_CONV, 1, p0, p1, s);
     default: return -1;
   }
 }
@@ -752,18 +804,31 @@ int gemm_pick_config(int mode, const GemmParams& p) {
 static int g_xcd_policy = 1;  // 0 = column tiles over XCDs always, 1 = by operand size, 2 = row tiles over XCDs always
 void gemm_set_xcd_policy(int v) { g_xcd_policy = v; }
 
+// which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
+static void set_xcd_split(int mode, int cfg, GemmParams& p) {
+  const GemmCfg& c = kCfgs[cfg];
+  const int bm = c.kind >= 4 ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
+  const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
+  const double w_bytes = (double)p.N * p.K * 4.0;
+  const bool fits = (p.M + bm - 1) / bm >= 8;
+  p.xcd_msplit = mode != GEMM_STEM && fits && (g_xcd_policy == 2 || (g_xcd_policy == 1 && a_bytes >= 2.0 * w_bytes));
+}
+
+int launch_gemm_dual_cfg(int mode, int cfg, const GemmParams& a, const GemmParams& b, hipStream_t s) {
+  if (mode != GEMM_CONV || cfg < 0 || cfg >= kNumCfgs || !gemm_cfg_supports_dual(cfg)) return -1;
+  if (!cfg_fits(cfg, a) || !cfg_fits(cfg, b)) return -1;
+  GemmParams p0 = a, p1 = b;
+  for (GemmParams* p : {&p0, &p1}) {
+    if (p->N % 16 != 0 || p->Cin % BK != 0 || p->K != p->ksize * p->ksize * p->Cin) return -1;
+    set_xcd_split(mode, cfg, *p);
+  }
+  return launch_dual_conv(cfg, p0, p1, s);
+}
+
 int launch_gemm_cfg(int mode, int cfg, const GemmParams& p0, hipStream_t s) {
   if (p0.N % 16 != 0 || cfg < 0 || cfg >= kNumCfgs || !cfg_fits(cfg, p0)) return -1;
   GemmParams p = p0;
-  {
-    // which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
-    const GemmCfg& c = kCfgs[cfg];
-    const int bm = c.kind >= 4 ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
-    const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
-    const double w_bytes = (double)p.N * p.K * 4.0;
-    const bool fits = (p.M + bm - 1) / bm >= 8;
-    p.xcd_msplit = mode != GEMM_STEM && fits && (g_xcd_policy == 2 || (g_xcd_policy == 1 && a_bytes >= 2.0 * w_bytes));
-  }
+  set_xcd_split(mode, cfg, p);
   switch (mode) {
     case GEMM_DENSE:
       if (p.lda % 4 != 0 || (p.A2 && p.lda2 % 4 != 0)) return -1;

@@ -23,7 +23,7 @@
 // the barrier of step t is a counted vmcnt that covers tile t only, tile t+1 stays in flight across the barrier (raw s_barrier,
 // no fence: __syncthreads() would drain the queue) and tile t+2 is requested right after it.
 template <int TN, int MODE, int NST>
-__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage
   constexpr int QW = BN / 32;             // W-tile DMA instructions per wavefront
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int m0, n0;
-  if (!gemm_tile_coords(p, BM, BN, m0, n0)) return;
+  if (!gemm_tile_coords(p, BM, BN, bid, m0, n0)) return;
   const int KT = p.K / BK;
 
   // ---- LDS-DMA bookkeeping: lane -> (row lane>>3 of the instruction's 8 rows, physical 16-B chunk lane&7) ----
@@ -213,6 +213,47 @@ __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
       }
     }
   }
+}
+
+template <int TN, int MODE, int NST>
+__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
+  gemm_big_body<TN, MODE, NST>(p, blockIdx.x);
+}
+
+// two independent problems in one grid (common.h: launch_gemm_dual_cfg)
+template <int TN, int MODE, int NST>
+__global__ __launch_bounds__(256, 2) void gemm_big_dual_kernel(const GemmParams p0, const GemmParams p1, const int tiles0) {
+  if ((int)blockIdx.x < tiles0) gemm_big_body<TN, MODE, NST>(p0, blockIdx.x);
+  else gemm_big_body<TN, MODE, NST>(p1, (int)blockIdx.x - tiles0);
+}
+
+template <int TN>
+static int launch_big_dual_t(const GemmParams& a, const GemmParams& b, hipStream_t s) {
+  constexpr int BM = 128, BN = 64 * TN;
+  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  GemmParams p0 = a, p1 = b;
+  for (GemmParams* p : {&p0, &p1}) {
+    if (p->N % BN != 0 || p->K % BK != 0 || p->M <= 0 || p->A2 != nullptr) return -1;
+    if (p->ldc % 4 != 0 || (p->residual && p->ldr % 4 != 0)) return -1;
+    if (((uintptr_t)p->C & 15) || ((uintptr_t)p->residual & 15)) return -1;
+    if (p->zeros == nullptr) p->zeros = gemm_zero_buffer();
+    if (p->zeros == nullptr) return -2;
+  }
+  static PerDeviceFlag attr_set;
+  if (!attr_set.get()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_dual_kernel<TN, GEMM_CONV, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return -2;
+    attr_set.set();
+  }
+  const int tiles0 = gemm_grid_tiles(p0, BM, BN), tiles1 = gemm_grid_tiles(p1, BM, BN);
+  hipLaunchKernelGGL((gemm_big_dual_kernel<TN, GEMM_CONV, 2>), dim3(tiles0 + tiles1), dim3(256), smem, s, p0, p1, tiles0);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int launch_gemm_big_dual(int mode, int variant, const GemmParams& p0, const GemmParams& p1, hipStream_t s) {
+  if (mode != GEMM_CONV) return -1;
+  return variant == 0 ? launch_big_dual_t<2>(p0, p1, s) : variant == 1 ? launch_big_dual_t<1>(p0, p1, s) : -1;
 }
 
 template <int TN, int MODE, int NST>

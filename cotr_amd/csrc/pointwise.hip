@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   f32x4 v = *reinterpret_cast<const f32x4*>(bias + lane * 4);
-  f32x4 rr = *reinterpret_cast<const f32x4*>(residual + (size_t)row * 256 + lane * 4);
+  f32x4 rr = {0.f, 0.f, 0.f, 0.f};
+  if (residual != nullptr) rr = *reinterpret_cast<const f32x4*>(residual + (size_t)row * 256 + lane * 4);
   if (pre_w != nullptr) {
     const float mu = wave_sum(rr[0] + rr[1] + rr[2] + rr[3]) * (1.f / 256.f);
     const f32x4 dd = {rr[0] - mu, rr[1] - mu, rr[2] - mu, rr[3] - mu};

@@ -136,6 +136,19 @@ int cotr_op_stem_pool(const float* img, const float* w, const float* scale, cons
 /* q [nb*nq, ldq] (pre-scaled), k/v [nb*512, ldkv]; 8 heads x 32; o [nb*nq, ldo] */
 int cotr_op_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
                       int nb, int nq, cotr_stream stream);
+/* the same kernel with the q projection as prologue (wq != NULL: q = ((x + x2) . wq_h^T + bq_h) * qscale per head, `q`
+ * unused; x or x2 may be NULL) and / or the output projection as epilogue (wo != NULL: per-head partial outputs
+ * part[8][nb*nq][256], part[h] = O_h . wo[:, 32h:32h+32]^T; `o` may then be NULL) */
+int cotr_op_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                            float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                            float* part, int nb, int nq, cotr_stream stream);
+/* decoder tail: out[b][q][0..1] = corr_embed(LayerNorm(x)) for x [nb_pairs*nq, 256]; hs (optional) receives the normalised rows */
+int cotr_op_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
+                     const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
+                     cotr_stream stream);
+/* y = LayerNorm(sum_c parts[c] + bias + residual) over rows of 256; parts [np][rows][256]; residual may be NULL */
+int cotr_op_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
+                      float* y, int rows, cotr_stream stream);
 int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, int rows, cotr_stream stream);
 /* fused FFN block y = LN(x + W2 relu(W1 x + b1) + b2) in two launches (ffn.hip + ln_reduce); scratch holds
  * cotr_op_ffn_chunks(M) * M * 256 floats */
@@ -185,6 +198,13 @@ int cotr_gemm_num_configs(void);
 /* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB
  * Infinity Cache, larger ones fill the CUs better */
 int cotr_set_encode_chunk(int pairs);
+/* up to this many rows (default 2048; 0 = never) decoder.norm + corr_embed run as ONE row-local launch (head.hip) instead
+ * of layernorm + two linears + the 256 -> 2 head */
+int cotr_set_head_fusion_max_rows(int rows);
+/* up to this many rows (default 1024; 0 = never) the attention kernel also does the output projection (per-head partial
+ * outputs summed + bias + residual + LayerNorm by one ln_reduce launch) and, in the decoder, the q projection of its own
+ * queries: 5 (encoder) / 4 (decoder) launches per transformer layer instead of 6 */
+int cotr_set_attention_fusion_max_rows(int rows);
 /* the fused FFN block (ffn.hip) is used for GEMMs with at most this many rows (default 1024); 0 = never */
 int cotr_set_ffn_fusion_max_rows(int rows);
 /* 1: where the fused FFN block is used, the LayerNorm that precedes it (norm1 of an encoder layer, norm2 of a decoder
@@ -196,6 +216,9 @@ int cotr_set_ffn_preln(int enable);
  * of each row tile; same bits as the separate ln_reduce launch); 0 (default): two launches - the single-launch form
  * measured SLOWER (one CU has to pull the 512 KB of partials of its row tile), see DESIGN.md 4b */
 int cotr_set_ffn_tail(int enable);
+/* 1 (default): in the entry block of each ResNet stage the downsample convolution and conv1 (both read the block input) go
+ * out as one launch at up to two pairs per pass; 0: two launches */
+int cotr_set_dual_conv(int enable);
 /* 1 (default): conv1 + bn1 + relu + maxpool of the ResNet stem as one launch (stem_pool.hip); 0: implicit-GEMM stem + separate
  * max-pool kernel (also used whenever debug taps are on: the 'stem' tap is the un-pooled conv output) */
 int cotr_set_fused_stem(int enable);
@@ -220,6 +243,11 @@ int cotr_op_linear_cfg(const float* x, const float* w, const float* bias, const 
 int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const float* bias, const float* residual,
                      int relu, float* y, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int cfg,
                      cotr_stream stream);
+
+/* two independent convolutions of the SAME input in one launch under config `cfg` (the dual-launch path of the entry blocks) */
+int cotr_op_conv_dual_cfg(const float* x, const float* w0, const float* scale0, const float* bias0, int relu0, float* y0, int Cout0,
+                          int ksize0, int stride0, const float* w1, const float* scale1, const float* bias1, int relu1, float* y1,
+                          int Cout1, int ksize1, int stride1, int B, int Hin, int Win, int Cin, int cfg, cotr_stream stream);
 
 #ifdef __cplusplus
 }

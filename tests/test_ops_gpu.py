@@ -158,6 +158,113 @@ def test_attention_softmax_extremes(case):
         assert e < tol, (case, ns, e)
 
 
+@pytest.mark.parametrize('nb,nq', [(1, 1000), (2, 77), (3, 1)])
+def test_attention_with_fused_projections(nb, nq):
+    """attention_kernel<4, QP, OP>: q projection in the prologue (decoder, transformer.py:192 with the packed in_proj of
+    nn.MultiheadAttention: q = Wq(tgt + query_pos) * head_dim^-0.5) and out_proj in the epilogue as 8 per-head partial
+    outputs that ln_reduce sums (+ bias + residual + LayerNorm, transformer.py:195-198), against fp64 torch."""
+    from cotr_amd import _lib
+    import torch.nn.functional as F
+    lib = _lib.load_library()
+    g = _g(nb * 1000 + nq)
+    R = nb * nq
+    x, x2 = torch.randn(R, 256, generator=g), torch.randn(R, 256, generator=g)
+    wq, bq = torch.randn(256, 256, generator=g) / 16, 0.1 * torch.randn(256, generator=g)
+    wo, bo = torch.randn(256, 256, generator=g) / 16, 0.1 * torch.randn(256, generator=g)
+    kv = torch.randn(nb * 512, 512, generator=g)
+    res = torch.randn(R, 256, generator=g)
+    lw, lb = torch.rand(256, generator=g) + 0.5, 0.1 * torch.randn(256, generator=g)
+    scale = 32 ** -0.5
+    qd = ((x + x2).double() @ wq.double().t() + bq.double()) * scale
+    qh = qd.view(nb, nq, 8, 32).permute(0, 2, 1, 3)
+    kh = kv[:, :256].double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    vh = kv[:, 256:].double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    o_ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).permute(0, 2, 1, 3).reshape(R, 256)
+    proj_ref = o_ref @ wo.double().t()
+    y_ref = F.layer_norm(res.double() + proj_ref + bo.double(), (256,), lw.double(), lb.double())
+    d = G.dev()
+    xd, x2d, wqd, bqd, wod, bod, kvd, resd, lwd, lbd = (t.to(d) for t in (x, x2, wq, bq, wo, bo, kv, res, lw, lb))
+    o = torch.full((R, 256), float('nan'), device=d)
+    part = torch.full((8, R, 256), float('nan'), device=d)
+    y = torch.full((R, 256), float('nan'), device=d)
+    none = None
+    # (a) q projection only: o against the reference attention
+    rc = lib.cotr_op_attention_fused(none, 0, G.P(xd), G.P(x2d), G.P(wqd), G.P(bqd), scale, G.P(kvd), G.P(kvd[:, 256:]), 512,
+                                     G.P(o), 256, none, none, nb, nq, G.sptr())
+    assert rc == 0
+    assert G.rel_err(o, o_ref) < 2e-5
+    # x alone / x2 alone (layer 0 of the decoder: tgt == 0)
+    o1 = torch.full((R, 256), float('nan'), device=d)
+    xs = (xd + x2d).contiguous()
+    for xa, xb in ((xs, None), (None, xs)):
+        assert lib.cotr_op_attention_fused(none, 0, G.P(xa), G.P(xb), G.P(wqd), G.P(bqd), scale, G.P(kvd), G.P(kvd[:, 256:]),
+                                           512, G.P(o1), 256, none, none, nb, nq, G.sptr()) == 0
+        assert torch.equal(o1, o)
+    # (b) out projection only, q given: the partials sum to O . Wo^T; o is still written when asked for
+    qf = qd.float().to(d)
+    o2 = torch.full((R, 256), float('nan'), device=d)
+    rc = lib.cotr_op_attention_fused(G.P(qf), 256, none, none, none, none, 0.0, G.P(kvd), G.P(kvd[:, 256:]), 512, G.P(o2), 256,
+                                     G.P(wod), G.P(part), nb, nq, G.sptr())
+    assert rc == 0
+    assert G.rel_err(o2, o_ref) < 2e-5
+    assert G.rel_err(part.double().sum(0), proj_ref) < 3e-5
+    # (c) both + ln_reduce: the decoder's cross-attention sub-layer in two launches
+    part.fill_(float('nan'))
+    rc = lib.cotr_op_attention_fused(none, 0, G.P(xd), G.P(x2d), G.P(wqd), G.P(bqd), scale, G.P(kvd), G.P(kvd[:, 256:]), 512,
+                                     none, 0, G.P(wod), G.P(part), nb, nq, G.sptr())
+    assert rc == 0
+    assert lib.cotr_op_ln_reduce(G.P(part), 8, G.P(bod), G.P(resd), G.P(lwd), G.P(lbd), G.P(y), R, G.sptr()) == 0
+    assert G.rel_err(y, y_ref) < 3e-5
+    assert lib.cotr_op_ln_reduce(G.P(part), 8, G.P(bod), none, G.P(lwd), G.P(lbd), G.P(y), R, G.sptr()) == 0   # no residual
+    y0 = F.layer_norm(proj_ref + bo.double(), (256,), lw.double(), lb.double())
+    assert G.rel_err(y, y0) < 3e-5
+    # a NaN query row stays in its row (the engines test for NaN themselves, sparse_engine.py:54-55)
+    if nq > 2:
+        x2n = x2d.clone()
+        x2n[1] = float('nan')
+        assert lib.cotr_op_attention_fused(none, 0, G.P(xd), G.P(x2n), G.P(wqd), G.P(bqd), scale, G.P(kvd), G.P(kvd[:, 256:]), 512,
+                                           G.P(o1), 256, G.P(wod), G.P(part), nb, nq, G.sptr()) == 0
+        assert torch.isnan(o1[1]).all() and torch.isnan(part[:, 1]).all()
+        keep = torch.arange(R, device=d) != 1
+        assert torch.equal(o1[keep], o[keep]) and not torch.isnan(part[:, keep]).any()
+
+
+@pytest.mark.parametrize('nb,nq,q_total', [(1, 1000, 1000), (3, 7, 11), (1, 1, 1), (2, 16, 16)])
+def test_decoder_head_in_one_launch(nb, nq, q_total):
+    """dec_head_kernel = decoder.norm + corr_embed (transformer.py:110-111, position_encoding.py:23-26) on 16-row tiles
+    with v_mfma_f32_16x16x4_f32, predictions scattered to out[b][q] of a larger [nb, q_total, 2] tensor; vs fp64 torch."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(nb * 31 + nq)
+    R = nb * nq
+    x = torch.randn(R, 256, generator=g) * 2 + 0.3
+    nw, nbias = torch.rand(256, generator=g) + 0.5, 0.1 * torch.randn(256, generator=g)
+    w0, b0 = torch.randn(256, 256, generator=g) / 16, 0.1 * torch.randn(256, generator=g)
+    w1, b1 = torch.randn(256, 256, generator=g) / 16, 0.1 * torch.randn(256, generator=g)
+    w2, b2 = torch.randn(2, 256, generator=g) / 16, torch.randn(2, generator=g)
+    hs_ref = F.layer_norm(x.double(), (256,), nw.double(), nbias.double())
+    h = F.relu(F.linear(F.relu(F.linear(hs_ref, w0.double(), b0.double())), w1.double(), b1.double()))
+    ref = F.linear(h, w2.double(), b2.double()).view(nb, nq, 2)
+    d = G.dev()
+    t = [v.to(d) for v in (x, nw, nbias, w0, b0, w1, b1, w2, b2)]
+    hs = torch.full((R, 256), float('nan'), device=d)
+    out = torch.full((nb, q_total, 2), float('nan'), device=d)
+    assert lib.cotr_op_dec_head(*[G.P(v) for v in t], G.P(hs), G.P(out), nb, nq, q_total, G.sptr()) == 0
+    assert G.rel_err(hs, hs_ref) < 1e-5
+    assert G.rel_err(out[:, :nq], ref) < 3e-5
+    assert torch.isnan(out[:, nq:]).all()                      # rows of other query chunks are not touched
+    out2 = torch.full((nb, q_total, 2), float('nan'), device=d)
+    assert lib.cotr_op_dec_head(*[G.P(v) for v in t], None, G.P(out2), nb, nq, q_total, G.sptr()) == 0
+    assert torch.equal(out2[:, :nq], out[:, :nq])              # the hs tap is optional
+    if R > 2:                                                  # a NaN row stays in its row
+        xn = t[0].clone()
+        xn[1] = float('nan')
+        assert lib.cotr_op_dec_head(G.P(xn), *[G.P(v) for v in t[1:]], None, G.P(out2), nb, nq, q_total, G.sptr()) == 0
+        flat, flat0 = out2[:, :nq].reshape(R, 2), out[:, :nq].reshape(R, 2)
+        keep = torch.arange(R, device=d) != 1
+        assert torch.isnan(flat[1]).all() and torch.equal(flat[keep], flat0[keep])
+
+
 def test_layernorm():
     from cotr_amd import _lib
     g = _g(3)
@@ -295,6 +402,40 @@ def test_every_gemm_config_conv():
             assert e < 3e-5, (cfg, B, H, cin, cout, k, stride, e)
             ran += 1
     assert ran >= 80
+
+
+@pytest.mark.parametrize('B,H,cin,c_ds,c_1,stride', [(1, 64, 64, 256, 64, 1), (1, 64, 256, 512, 128, 2), (1, 32, 512, 1024, 256, 2),
+                                                     (2, 16, 64, 256, 64, 2)])
+def test_dual_conv_launch(B, H, cin, c_ds, c_1, stride):
+    """Entry block of a ResNet stage: downsample (1x1, stride s, FrozenBN, no ReLU) and conv1 (1x1, stride 1, FrozenBN,
+    ReLU) of the same input as ONE launch, under every configuration that has a dual form; a configuration may decline
+    (rc -1), never return a wrong result.  Each output against torch on CPU."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(B * 100 + H + cin)
+    x = torch.randn(B, cin, H, 2 * H, generator=g)
+    wd, w1 = torch.randn(c_ds, cin, 1, 1, generator=g) / math.sqrt(cin), torch.randn(c_1, cin, 1, 1, generator=g) / math.sqrt(cin)
+    sd, bd = torch.rand(c_ds, generator=g) + 0.5, torch.randn(c_ds, generator=g)
+    s1, b1 = torch.rand(c_1, generator=g) + 0.5, torch.randn(c_1, generator=g)
+    ref_d = G.per_half(lambda t: F.conv2d(t, wd, stride=stride), x) * sd.view(1, -1, 1, 1) + bd.view(1, -1, 1, 1)
+    ref_1 = F.relu(G.per_half(lambda t: F.conv2d(t, w1), x) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    d = G.dev()
+    xd = G.nchw_to_sbs(x).to(d)
+    wdd, w1d = G.pack_conv_weight(wd).to(d), G.pack_conv_weight(w1).to(d)
+    sdd, bdd, s1d, b1d = sd.to(d), bd.to(d), s1.to(d), b1.to(d)
+    ran = 0
+    for cfg in _cfgs():
+        yd = torch.full((B, H // stride, 2 * H // stride, c_ds), float('nan'), device=d)
+        y1 = torch.full((B, H, 2 * H, c_1), float('nan'), device=d)
+        rc = lib.cotr_op_conv_dual_cfg(G.P(xd), G.P(wdd), G.P(sdd), G.P(bdd), 0, G.P(yd), c_ds, 1, stride,
+                                       G.P(w1d), G.P(s1d), G.P(b1d), 1, G.P(y1), c_1, 1, 1, B, H, H, cin, cfg, G.sptr())
+        if rc != 0:
+            assert rc == -1, (cfg, rc)
+            continue
+        assert G.rel_err(G.sbs_to_nchw(yd.cpu()), ref_d) < 3e-5, cfg
+        assert G.rel_err(G.sbs_to_nchw(y1.cpu()), ref_1) < 3e-5, cfg
+        ran += 1
+    assert ran >= 5, ran
 
 
 def test_large_tile_configs_are_repeatable():

@@ -29,14 +29,20 @@ def test_oracle_matches_reference_golden(name, golden_dir):
     taps = {}
     o32 = cotr_oracle.cotr_forward(sd, img, qs, taps=taps)
     assert o32.shape == g['pred_f32'].shape
-    # fp32 restatement vs fp32 reference and vs the fp64 reference: inside the bar
-    assert cotr_oracle.px_err(o32, torch.from_numpy(g['pred_f32'])) < PX_BAR
-    assert cotr_oracle.px_err(o32, torch.from_numpy(g['pred_f64'])) < PX_BAR
-    mem = taps['enc.5'].permute(1, 0, 2)[:, ::8]            # [B,64,256]
-    assert float((mem - torch.from_numpy(g['memory'])).abs().max()) < 5e-5
+    # fp32 restatement vs fp32 reference and vs the fp64 reference: inside the bar.  The ill-conditioned softmax-extreme
+    # cases (peaky16 / peaky32: near one-hot attention in all 12 layers) put the reference's OWN fp32 run 1.7e-2 / 3.2 px
+    # from its fp64 run; there the restatement is held to 3x that gap from the fp64 truth, and the fp64 restatement to
+    # the fp64 reference exactly (test below)
+    ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), torch.from_numpy(g['pred_f64']))
+    bar = max(PX_BAR, 3 * ref_gap)
+    assert cotr_oracle.px_err(o32, torch.from_numpy(g['pred_f64'])) < bar
+    if ref_gap < PX_BAR / 3:
+        assert cotr_oracle.px_err(o32, torch.from_numpy(g['pred_f32'])) < PX_BAR
+        mem = taps['enc.5'].permute(1, 0, 2)[:, ::8]            # [B,64,256]
+        assert float((mem - torch.from_numpy(g['memory'])).abs().max()) < 5e-5
 
 
-@pytest.mark.parametrize('name', ['single_b1_q1', 'peaky_b1_q64'])
+@pytest.mark.parametrize('name', ['single_b1_q1', 'peaky_b1_q64', 'peaky16_b1_q64', 'peaky32_b1_q64', 'flat_b1_q64'])
 def test_oracle_fp64_is_the_reference_fp64(name, golden_dir):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     sd, img, qs = make_golden.case_inputs(name)

@@ -182,6 +182,61 @@ def test_fused_and_unfused_ffn_paths_agree():
     assert cotr_oracle.px_err(plain, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
 
 
+def test_fused_and_unfused_attention_paths_agree():
+    """Default up to 1024 rows: attention with the out projection (and, in the decoder, the q projection) inside the
+    kernel + ln_reduce; cotr_set_attention_fusion_max_rows(0) = the six-launch layer.  Same function, different fp32
+    summation order; both within the bar of the oracle."""
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(2, 300, seed=17)
+    m = hip_model()
+    fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    lib = _lib.load_library()
+    try:
+        assert lib.cotr_set_attention_fusion_max_rows(0) == 0
+        plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    finally:
+        lib.cotr_set_attention_fusion_max_rows(1024)
+    assert not torch.equal(fused, plain)                       # really two different launch sequences
+    assert cotr_oracle.px_err(fused, plain) < SHAPE_NOISE_PX
+    ref = cotr_oracle.cotr_forward(sd, img, qs)
+    assert cotr_oracle.px_err(plain, ref) < PX_BAR and cotr_oracle.px_err(fused, ref) < PX_BAR
+
+
+def test_fused_and_unfused_decoder_head_agree():
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(2, 100, seed=19)
+    m = hip_model()
+    fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    lib = _lib.load_library()
+    try:
+        assert lib.cotr_set_head_fusion_max_rows(0) == 0
+        plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    finally:
+        lib.cotr_set_head_fusion_max_rows(2048)
+    assert cotr_oracle.px_err(fused, plain) < SHAPE_NOISE_PX
+    assert cotr_oracle.px_err(fused, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
+
+
+def test_dual_conv_launch_is_bit_identical_to_two_launches():
+    """The entry blocks' downsample + conv1 in one launch compute exactly what the two launches compute when the
+    configuration is the same; end to end the two schedules agree to launch-configuration rounding."""
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(1, 64, seed=18)
+    m = hip_model()
+    dual = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    lib = _lib.load_library()
+    try:
+        assert lib.cotr_set_dual_conv(0) == 0
+        plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    finally:
+        lib.cotr_set_dual_conv(1)
+    assert cotr_oracle.px_err(dual, plain) < SHAPE_NOISE_PX
+    assert cotr_oracle.px_err(dual, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
+
+
 def test_dense_pass_shape_q131072():
     """cotr_patch_flow_exhaustive feeds q[1,131072,2] (inference_helper.py:116-127): 4 decoder chunks; a strided
     sample of it is checked against the oracle."""
