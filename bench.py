@@ -1,25 +1,36 @@
 #!/usr/bin/env python
 """Headline benchmark: query-correspondences/sec of the COTR forward path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload headline|batch256|train]
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "primary"): one 256x512 side-by-side pair,
-1000 queries, zoom disabled -> one ``model(img[1,3,256,512], q[1,1000,2])`` call per step, per GPU.
-Synthetic data and seeded random weights of the COTR architecture (no checkpoint exists offline).
-Inputs are resident in HBM before the timed region.  N > 1 (launched by torch.distributed.run, one
-rank per GPU, RCCL): every rank runs its own pair(s) (weak scaling), the predicted (x,y) of every
-step are all-gathered over xGMI on RCCL's stream, overlapped with the next step.
+Workloads
+  headline (default)  BASELINE.json configs[1], SURVEY.md 8d "primary": one 256x512 side-by-side pair, 1000 queries, zoom
+                      disabled -> one ``model(img[1,3,256,512], q[1,1000,2])`` call per step PER GPU (weak scaling).
+  batch256            BASELINE.json configs[3]: 256 pairs x 1000 queries per step for the whole job, pairs sharded over the
+                      ranks (32 per GPU on 8 GPUs, 256 on one), every rank holds only its own pairs (strong scaling).
+  train               BASELINE.json configs[4] / SURVEY.md 8f4: one ``COTRTrainer.train_batch`` step (cycle + bidirectional,
+                      Adam, dropout 0.1) at 16 pairs x 200 queries per GPU; value = pairs/s.  Not the headline metric.
+Synthetic data and seeded random weights of the COTR architecture (no checkpoint exists offline).  Inputs are resident in
+HBM before the timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the predicted (x,y) of
+every step are all-gathered over xGMI on RCCL's stream, overlapped with the next step; no collective in the math.
 
-Prints ONE JSON line on rank 0.  ``roofline`` is for the whole forward launch sequence (one "launch"
-= one cotr_forward = the ~150 kernels of one step): achieved = FLOP(B,Q) / mean step time measured
-with HIP events on the launch stream, against the fp32 MFMA peak (parity forces fp32 operands).
-``cpu_baseline`` is the CPU oracle (a torch-CPU restatement of the reference, kind "port") timed on
-this box's host cores on a bounded number of the same forward calls - rank 0, N == 1 only.
+Prints ONE JSON line on rank 0.  ``roofline`` is for the whole forward launch sequence (one "launch" = one cotr_forward =
+the ~100 kernels of one step): achieved = FLOP(B,Q) / mean step time measured with HIP events on the launch stream, against
+the fp32 MFMA peak (parity forces fp32 operands).  ``roofline.traffic`` = bytes crossing L2 <-> fabric per forward, measured
+by this run itself (two rocprofv3 --pmc passes of a child process: FETCH_SIZE x2 on gfx950 + WRITE_SIZE) when rocprofv3 is
+on the box, else taken from the committed profile - ``traffic_source`` says which.  ``cpu_baseline`` is the CPU oracle (a
+torch-CPU restatement of the reference, kind "port"; the reference itself, kind "reference", where /root/reference is
+importable) timed on this box's host cores on a bounded number of the same forward calls - rank 0, N == 1 only.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -29,7 +40,6 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PAIRS_PER_GPU = 1
 QUERIES = 1000
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CUs
 HBM_PEAK_GBS = 8000.0
@@ -64,8 +74,8 @@ def kernel_breakdown(model, img, qs, step_ms, reps=5):
     (cotr_set_profiling level 2).  An event costs ~3 us of stream time per launch, so the raw per-launch times are
     rescaled to sum to the un-instrumented step time measured above."""
     import collections
-    model.set_profiling(2)
     import re
+    model.set_profiling(2)
     fam = collections.OrderedDict()
     n_launch = 0
     for _ in range(reps):
@@ -78,8 +88,7 @@ def kernel_breakdown(model, img, qs, step_ms, reps=5):
             e = fam.setdefault(key, [0, 0.0, 0.0])
             e[0] += 1
             e[1] += ms
-            mnk = re.search(r'(\d+)x(\d+)x(\d+)', name)          # GEMM / conv launches carry their M x N x K
-            if mnk:
+            for mnk in re.finditer(r'(\d+)x(\d+)x(\d+)', name):          # GEMM / conv launches carry their M x N x K
                 e[2] += 2.0 * int(mnk.group(1)) * int(mnk.group(2)) * int(mnk.group(3))
     model.set_profiling(0)
     raw_total = sum(v[1] for v in fam.values()) / reps
@@ -100,9 +109,20 @@ def kernel_breakdown(model, img, qs, step_ms, reps=5):
     return res
 
 
+def time_calls(fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
 def other_regimes(sd, dev):
     """NOT the headline: the same path (a) with three independent calls in flight (three handles, three streams - the
-    one-pair forward leaves CUs idle between its ~120 dependent launches) and (b) at the batched shapes the callers use."""
+    one-pair forward leaves CUs idle between its ~100 dependent launches) and (b) at the batched shapes the callers use."""
     import cotr_amd
     from cotr_amd.models import build_model
     from cotr_amd.utils.synth import synth_inputs
@@ -113,7 +133,7 @@ def other_regimes(sd, dev):
         m.load_state_dict(sd)
         models.append(m)
     streams = [torch.cuda.Stream(device=dev) for _ in models]
-    img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1)
+    img, qs = synth_inputs(1, QUERIES, seed=1)
     img, qs = img.to(dev), qs.to(dev)
 
     def run(n):
@@ -129,69 +149,185 @@ def other_regimes(sd, dev):
     out['three_calls_in_flight'] = {'ms_per_call': dt * 1e3, 'query_corr_per_s': QUERIES / dt,
                                     'tflops': flop(1, QUERIES) / dt / 1e12}
     m = models[0]
-    for tag, b, q, n in (('batch_32_pairs_x_1000_queries', 32, 1000, 5), ('engine_batch_32_pairs_x_1_query', 32, 1, 10)):
+    for tag, b, q, n in (('batch_32_pairs_x_1000_queries', 32, 1000, 5), ('engine_batch_32_pairs_x_1_query', 32, 1, 10),
+                         ('dense_pass_1_pair_x_131072_queries', 1, 131072, 5)):
         img, qs = synth_inputs(b, q, seed=2)
         img, qs = img.to(dev), qs.to(dev)
-        for _ in range(2):
-            m(img, qs)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            m(img, qs)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
+        dt = time_calls(lambda: m(img, qs), n)
         out[tag] = {'ms_per_call': dt * 1e3, 'query_corr_per_s': b * q / dt, 'pairs_per_s': b / dt,
                     'tflops': flop(b, q) / dt / 1e12, 'frac_of_fp32_mfma_peak': flop(b, q) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
     return out
 
 
-def hbm_traffic_bytes():
-    """HBM<->L2 bytes per forward from the committed rocprofv3 PMC passes (profiles/r1_pmc_hbm_traffic.txt:
-    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes), or None."""
-    path = os.path.join(ROOT, 'profiles', 'r1_pmc_hbm_traffic.txt')
-    try:
-        tot = 0.0
-        for line in open(path):
-            if line.startswith(('FETCH_SIZE', 'WRITE_SIZE')):
-                tot += float(line.split('->')[1].split('MB')[0]) * 1e6
-        return tot or None
-    except (OSError, ValueError, IndexError):
-        return None
+# ---- L2 <-> fabric traffic ------------------------------------------------------------------------------------------
+def traffic_child(n_forward):
+    """Child process of measure_traffic (runs under rocprofv3 --pmc): a few warm-up forwards, then n_forward forwards."""
+    import cotr_amd
+    from cotr_amd.models import build_model
+    from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+    dev = torch.device('cuda', 0)
+    model = build_model(cotr_amd.default_args()).to(dev).eval()
+    model.load_state_dict(synth_state_dict(0))
+    img, qs = synth_inputs(1, QUERIES, seed=1)
+    img, qs = img.to(dev), qs.to(dev)
+    for _ in range(3 + n_forward):
+        model(img, qs)
+    torch.cuda.synchronize()
 
 
+def measure_traffic(n_forward=5, timeout_s=240):
+    """bytes per forward crossing L2 <-> fabric (Infinity Cache / HBM): FETCH_SIZE (KB; reports half the bytes of wide
+    coalesced reads on gfx950: doubled, MI355X_MICROARCH.md) and WRITE_SIZE (KB) in SEPARATE rocprofv3 --pmc passes
+    (they do not fit one pass), kernel trace only.  -> (bytes, per-counter dict) or (None, reason)."""
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    per = {}
+    for ctr, corr in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
+        tmp = tempfile.mkdtemp(prefix='cotr_pmc_', dir='/tmp')
+        try:
+            env = dict(os.environ, TMPDIR='/tmp')
+            cmd = [exe, '--kernel-trace', '--pmc', ctr, '--output-format', 'csv', '-d', tmp, '-o', 'pmc', '--',
+                   sys.executable, os.path.abspath(__file__), '--traffic-child', str(n_forward)]
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            files = glob.glob(os.path.join(tmp, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f'rocprofv3 --pmc {ctr} failed (rc {r.returncode})'
+            rows = [row for row in csv.DictReader(open(files[0])) if row.get('Counter_Name') == ctr]
+            rows.sort(key=lambda row: int(row.get('Dispatch_Id', 0)))
+            starts = [i for i, row in enumerate(rows) if 'stem_pool_kernel' in row['Kernel_Name']]   # first kernel of a forward
+            if len(starts) < n_forward + 1:
+                return None, f'{ctr}: expected {n_forward + 3} forwards in the trace, found {len(starts)}'
+            steady = rows[starts[-n_forward]:]
+            per[ctr] = sum(float(row['Counter_Value']) for row in steady) / n_forward * 1024.0 * corr
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+            return None, f'{ctr}: {type(e).__name__}: {e}'
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return per['FETCH_SIZE'] + per['WRITE_SIZE'], per
+
+
+def committed_traffic():
+    """The same quantity from the newest committed rocprofv3 PMC summary under profiles/ (tools/pmc.sh), or None."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_hbm_traffic.txt'))):
+        try:
+            tot = 0.0
+            for line in open(path):
+                if line.startswith(('FETCH_SIZE', 'WRITE_SIZE')):
+                    tot += float(line.split('->')[1].split('MB')[0]) * 1e6
+            if tot:
+                best = (tot, os.path.relpath(path, ROOT))
+        except (OSError, ValueError, IndexError):
+            pass
+    return best
+
+
+# ---- CPU baseline ----------------------------------------------------------------------------------------------------
 def cpu_baseline(budget_s=12.0):
     from cotr_amd.utils.synth import synth_state_dict, synth_inputs
-    from oracle import cotr_oracle
+    from oracle import cotr_oracle, ref_import
     cores = usable_cores()
     torch.set_num_threads(cores)
     sd = synth_state_dict(0)
-    img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1)
-    cotr_oracle.cotr_forward(sd, img, qs)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        cotr_oracle.cotr_forward(sd, img, qs)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 100:
-            break
-    return {'value': PAIRS_PER_GPU * QUERIES * n / dt, 'unit': 'query-correspondences/s', 'cores': cores,
-            'kind': 'port',
-            'sample': f'{n} forward calls of the same workload (1 pair x {QUERIES} queries, fp32) by oracle/cotr_oracle.py '
-                      f'(torch CPU, {cores} threads), {dt:.1f} s'}
+    img, qs = synth_inputs(1, QUERIES, seed=1)
+
+    def timed(fn, budget):
+        fn()  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or n >= 100:
+                return n, dt
+    n, dt = timed(lambda: cotr_oracle.cotr_forward(sd, img, qs), budget_s)
+    out = {'value': QUERIES * n / dt, 'unit': 'query-correspondences/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{n} forward calls of the same workload (1 pair x {QUERIES} queries, fp32) by oracle/cotr_oracle.py '
+                     f'(torch CPU, {cores} threads), {dt:.1f} s',
+           'note': 'the port applies decoder.norm + corr_embed to the LAST decoder layer only and skips the head-averaged '
+                   'attention maps nn.MultiheadAttention also returns; the reference computes both for all 6 layers and '
+                   'discards them (cotr_model.py:37-39), so the port is a FASTER baseline than the reference itself'}
+    if ref_import.reference_available():     # authoring container only: the unmodified reference, same inputs
+        try:
+            model = ref_import.build_reference_model()
+            model.load_state_dict(sd)
+            model.eval()
+            with torch.no_grad():
+                n2, dt2 = timed(lambda: model(img, qs), budget_s)
+            out['reference'] = {'value': QUERIES * n2 / dt2, 'kind': 'reference', 'cores': cores,
+                                'sample': f'{n2} calls of COTR.forward imported unchanged from /root/reference (torch CPU), {dt2:.1f} s'}
+        except Exception as e:   # noqa: BLE001  (a baseline, never fatal)
+            out['reference'] = {'error': f'{type(e).__name__}: {e}'}
+    return out
+
+
+# ---- training step -----------------------------------------------------------------------------------------------------
+def run_train(args, dev, world, rank):
+    import cotr_amd
+    from cotr_amd import training
+    from cotr_amd.models import build_model
+    from cotr_amd.utils.synth import synth_state_dict
+    pairs, nq = 16, 200                       # BASELINE.json configs[4]: bs=16 per GPU, 200 queries, cycle + bidirectional
+    model = build_model(cotr_amd.default_args(dropout=0.1)).to(dev)
+    model.load_state_dict(synth_state_dict(0))
+    model.train()
+    optim = training.optimizer_for(model, learning_rate=1e-4)
+    g = torch.Generator().manual_seed(5 + rank)
+    img = torch.randn(pairs, 3, 256, 512, generator=g).to(dev)
+    query, target = torch.rand(pairs, nq, 2, generator=g).to(dev), torch.rand(pairs, nq, 2, generator=g).to(dev)
+    for _ in range(args.warmup):
+        training.train_batch(model, optim, img, query, target)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        training.train_batch(model, optim, img, query, target)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'training pairs/sec (COTRTrainer.train_batch step, cycle + bidirectional)', 'value': world * pairs * args.steps / elapsed,
+            'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[4]: 16 pairs x 200 queries per GPU, cycle consistency + bidirectional, '
+                                   'dropout 0.1, Adam lr 1e-4, frozen backbone (stage 1 of the reference recipe)',
+                       'pairs_per_gpu': pairs, 'queries_per_pair': nq,
+                       'parallelism': f'data parallel x{world}, reduce-scatter + all-gather of the gradients' if world > 1 else 'single GPU'},
+        }), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--workload', choices=['headline', 'batch256', 'train'], default='headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='only the timed steps (for rocprofv3 runs)')
-    ap.add_argument('--xcd-mapping', type=int, default=None, help='cotr_set_xcd_mapping policy (experiments)')
-    ap.add_argument('--fused-stem', type=int, default=None, help='cotr_set_fused_stem (experiments)')
-    ap.add_argument('--ffn-tail', type=int, default=None, help='cotr_set_ffn_tail (experiments)')
-    ap.add_argument('--ffn-preln', type=int, default=None, help='cotr_set_ffn_preln (experiments)')
+    ap.add_argument('--traffic', choices=['auto', 'measure', 'committed', 'none'], default='auto',
+                    help='roofline.traffic: measured by a rocprofv3 --pmc child of this run (auto: when available, N == 1, extras '
+                         'on), or the committed profile')
+    ap.add_argument('--traffic-child', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--set', action='append', default=[], metavar='KNOB=INT',
+                    help='experiments: call cotr_set_<KNOB>(INT) first, e.g. --set attention_fusion_max_rows=0')
     args = ap.parse_args()
+    if args.traffic_child:
+        return traffic_child(args.traffic_child)
+    if args.steps is None:
+        args.steps = {'headline': 200, 'batch256': 5, 'train': 10}[args.workload]
+    if args.warmup is None:
+        args.warmup = {'headline': 20, 'batch256': 2, 'train': 3}[args.workload]
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -209,31 +345,35 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     import cotr_amd
+    from cotr_amd import _lib
+    from cotr_amd.dist import all_gather_rows, shard_range
     from cotr_amd.models import build_model
     from cotr_amd.utils.synth import synth_state_dict, synth_inputs
 
-    if args.xcd_mapping is not None:
-        from cotr_amd import _lib
-        _lib.load_library().cotr_set_xcd_mapping(args.xcd_mapping)
-    if args.ffn_preln is not None:
-        from cotr_amd import _lib
-        _lib.load_library().cotr_set_ffn_preln(args.ffn_preln)
-    if args.ffn_tail is not None:
-        from cotr_amd import _lib
-        _lib.load_library().cotr_set_ffn_tail(args.ffn_tail)
-    if args.fused_stem is not None:
-        from cotr_amd import _lib
-        _lib.load_library().cotr_set_fused_stem(args.fused_stem)
+    for kv in args.set:
+        name, val = kv.split('=')
+        if getattr(_lib.load_library(), 'cotr_set_' + name)(int(val)) != 0:
+            raise SystemExit(f'cotr_set_{name}({val}) failed')
+    if args.workload == 'train':
+        run_train(args, dev, world, rank)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    batch256 = args.workload == 'batch256'
+    total_pairs = 256 if batch256 else world
+    lo, hi = shard_range(total_pairs, world, rank)
+    pairs = hi - lo                                           # this rank's pairs (batch256: its block of the 256)
     model = build_model(cotr_amd.default_args()).to(dev).eval()
     model.load_state_dict(synth_state_dict(0))
-    img, qs = synth_inputs(PAIRS_PER_GPU, QUERIES, seed=1 + rank)
+    img, qs = synth_inputs(pairs, QUERIES, seed=1 + rank)
     img, qs = img.to(dev), qs.to(dev)
-    gathered = torch.empty((world * PAIRS_PER_GPU, QUERIES, 2), device=dev) if world > 1 else None
+    counts = [shard_range(total_pairs, world, r)[1] - shard_range(total_pairs, world, r)[0] for r in range(world)]
 
     def step():
         out = model(img, qs)['pred_corrs']
         if world > 1:  # RCCL all-gather of the predicted (x,y), asynchronous w.r.t. the next step's kernels
-            return dist.all_gather_into_tensor(gathered, out, async_op=True)
+            return all_gather_rows(out, counts, async_op=True)[1]
         return None
 
     for _ in range(args.warmup):
@@ -267,8 +407,14 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        units = world * PAIRS_PER_GPU * QUERIES * args.steps
-        achieved = flop(PAIRS_PER_GPU, QUERIES) / (kernel_ms * 1e-3) / 1e12
+        units = total_pairs * QUERIES * args.steps
+        achieved = flop(pairs, QUERIES) / (kernel_ms * 1e-3) / 1e12
+        if batch256:
+            workload = ('BASELINE.json configs[3]: 256 pairs 256x512 side-by-side x 1000 queries per step for the whole job, '
+                        f'{pairs} pairs on this GPU, model(img[{pairs},3,256,512], q[{pairs},1000,2]); seeded random COTR weights')
+        else:
+            workload = ('BASELINE.json configs[1]: 1 pair 256x512 side-by-side x 1000 queries per GPU per step, zoom disabled, '
+                        'model(img[1,3,256,512], q[1,1000,2]); seeded random COTR weights')
         line = {
             'metric': 'query-correspondences/sec at 256x512 SBS, 1k queries',
             'value': units / elapsed,
@@ -278,28 +424,45 @@ def main():
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,
             'higher_is_better': True,
-            'scaling': 'weak',
+            'scaling': 'strong' if batch256 else 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: 1 pair 256x512 side-by-side x 1000 queries per GPU per step, '
-                                   'zoom disabled, model(img[1,3,256,512], q[1,1000,2]); seeded random COTR weights',
-                       'pairs_per_gpu': PAIRS_PER_GPU, 'queries_per_pair': QUERIES,
+            'config': {'workload': workload, 'pairs_per_gpu': pairs, 'queries_per_pair': QUERIES,
                        'parallelism': f'pairs sharded x{world}, all-gather of pred_corrs' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                          'launch': 'one cotr_forward (all kernels of a step)', 'launch_ms_hip_events': kernel_ms,
-                         'algorithmic_gflop_per_launch': flop(PAIRS_PER_GPU, QUERIES) / 1e9,
-                         'min_hbm_gbs': min_hbm_bytes(PAIRS_PER_GPU, QUERIES) / (kernel_ms * 1e-3) / 1e9,
+                         'algorithmic_gflop_per_launch': flop(pairs, QUERIES) / 1e9,
+                         'min_hbm_gbs': min_hbm_bytes(pairs, QUERIES) / (kernel_ms * 1e-3) / 1e9,
                          'hbm_peak_gbs': HBM_PEAK_GBS},
         }
-        line['roofline']['traffic'] = hbm_traffic_bytes()
-        line['roofline']['traffic_note'] = ('bytes per forward crossing L2<->fabric (MALL/HBM), rocprofv3 PMC FETCH_SIZE x2 + '
-                                            'WRITE_SIZE from profiles/r1_pmc_hbm_traffic.txt; minimum is 75.4 MB')
-        if world == 1 and not args.no_extras:
-            line['roofline']['kernels'] = kernel_breakdown(model, img, qs, kernel_ms)
+        extras = world == 1 and not args.no_extras and not batch256
+        roof = line['roofline']
+        mode = args.traffic
+        if mode == 'auto':
+            mode = 'measure' if extras else 'committed'
+        if mode == 'measure':
+            tot, detail = measure_traffic()
+            if tot is not None:
+                roof['traffic'], roof['traffic_source'] = tot, 'measured by this run: rocprofv3 --pmc child, 5 forwards'
+                roof['traffic_detail'] = {k: round(v) for k, v in detail.items()}
+            else:
+                roof['traffic_measure_error'] = detail
+                mode = 'committed'
+        if mode == 'committed' and not batch256:
+            c = committed_traffic()
+            if c is not None:
+                roof['traffic'], roof['traffic_source'] = c[0], f'committed profile {c[1]}'
+        roof['traffic_note'] = ('bytes per forward crossing L2<->fabric (Infinity Cache / HBM): rocprofv3 PMC FETCH_SIZE x2 (gfx950) + '
+                                f'WRITE_SIZE, separate passes; algorithmic minimum {min_hbm_bytes(pairs, QUERIES) / 1e6:.1f} MB')
+        if extras:
+            roof['kernels'] = kernel_breakdown(model, img, qs, kernel_ms)
+            roof['launches_per_forward'] = roof['kernels']['launches_per_forward']
             line['also_measured'] = other_regimes(synth_state_dict(0), dev)
-        if world == 1 and not args.no_cpu_baseline:
+            roof['batched_frac'] = line['also_measured']['batch_32_pairs_x_1000_queries']['frac_of_fp32_mfma_peak']
+            roof['batched_frac_note'] = 'same path at 32 pairs x 1000 queries per call (throughput regime)'
+        if world == 1 and not args.no_cpu_baseline and not batch256:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -28,6 +28,8 @@ _PROTOS = {
     'cotr_forward': (ctypes.c_int, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p,
                                     ctypes.c_void_p]),
     'cotr_workspace_bytes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    'cotr_scratch_bytes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    'cotr_set_workspace': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     'cotr_debug_tap': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_float_p, ctypes.c_size_t,
                                       ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]),
     'cotr_set_debug_taps': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
@@ -71,6 +73,7 @@ _PROTOS = {
     'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_fused_stem': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_dual_conv': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_ks3': (ctypes.c_int, [ctypes.c_int]),
     'cotr_op_conv_dual_cfg': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -54,10 +54,11 @@ const StageSpec kStages[3] = {{64, 3, 1}, {128, 4, 2}, {256, 6, 2}};
 struct Arena {
   float* ptr = nullptr;
   size_t cap = 0;  // floats
+  bool external = false;  // carved from the caller's workspace (cotr_set_workspace): never freed here
 };
 
 thread_local std::string g_create_error;
-int g_head_fuse_max_rows = 2048;  // decoder.norm + corr_embed as one row-local launch up to this many rows
+int g_head_fuse_max_rows = 0;     // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower at 1000 rows: 63 workgroups each pull all 512 KB of weights; off)
 int g_attn_fuse_max_rows = 1024;  // attention with the out-projection (and, in the decoder, the q projection) fused in, up to this many rows
 int g_ffn_fuse_max_rows = 1024;  // fused FFN block up to this many rows (forward at B=1,Q=1000: 1.064 vs 1.083 ms; slower from ~1300 rows on)
 }  // namespace
@@ -88,6 +89,9 @@ struct cotr_ctx {
   std::map<std::string, std::pair<const float*, size_t>> taps;
   bool keep_taps = false;
   std::map<std::string, Arena> tap_store;
+  // caller-supplied scratch (cotr_set_workspace): the three arenas are carved from it instead of hipMalloc'ed
+  char* ws = nullptr;
+  size_t ws_bytes = 0, ws_used = 0;
   // profiling
   int prof = 0;  // 0 off, 1 per stage, 2 per kernel launch
   std::vector<std::string> prof_names;
@@ -145,9 +149,28 @@ struct DeviceScope {
 
 int ensure(cotr_ctx* h, Arena& a, size_t floats) {
   if (a.cap >= floats) return COTR_OK;
-  if (a.ptr) HIPCHK(h, hipFree(a.ptr));
+  if (h->ws != nullptr && (&a == &h->memkv || &a == &h->enc_scr || &a == &h->dec_scr)) {
+    // caller-supplied workspace: bump allocation, 256-byte aligned; nothing is freed or allocated on the device (no
+    // synchronisation in the middle of a stream).  A region that has to grow takes a new carve: the caller sizes the
+    // workspace with cotr_scratch_bytes for the largest (B, Q) it will pass.
+    const size_t off = (h->ws_used + 255) & ~size_t(255);
+    if (off + floats * sizeof(float) > h->ws_bytes) {
+      char msg[160];
+      snprintf(msg, sizeof msg, "workspace too small: %zu bytes given, %zu needed so far (size it with cotr_scratch_bytes)",
+               h->ws_bytes, off + floats * sizeof(float));
+      h->err = msg;
+      return COTR_ERR_ARG;
+    }
+    a.ptr = reinterpret_cast<float*>(h->ws + off);
+    a.cap = floats;
+    a.external = true;
+    h->ws_used = off + floats * sizeof(float);
+    return COTR_OK;
+  }
+  if (a.ptr && !a.external) HIPCHK(h, hipFree(a.ptr));
   a.ptr = nullptr;
   a.cap = 0;
+  a.external = false;
   HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&a.ptr), floats * sizeof(float)));
   a.cap = floats;
   return COTR_OK;
@@ -371,9 +394,8 @@ void cotr_destroy(cotr_handle h) {
   prof_reset(h);
   if (h->wbuf) (void)hipFree(h->wbuf);
   if (h->pos) (void)hipFree(h->pos);
-  if (h->memkv.ptr) (void)hipFree(h->memkv.ptr);
-  if (h->enc_scr.ptr) (void)hipFree(h->enc_scr.ptr);
-  if (h->dec_scr.ptr) (void)hipFree(h->dec_scr.ptr);
+  for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr})
+    if (a->ptr && !a->external) (void)hipFree(a->ptr);
   for (auto& kv : h->tap_store)
     if (kv.second.ptr) (void)hipFree(kv.second.ptr);
   delete h;
@@ -586,8 +608,11 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   const size_t n_stem = (size_t)128 * 256 * 64, n_pool = (size_t)64 * 128 * 64, n_act = (size_t)64 * 128 * 256;
   const size_t n_tok = (size_t)TOK * D;
   const size_t per_pair = n_stem + n_pool + 5 * n_act + 6 * n_tok + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
+  // per-head partial outputs of the fused attention + out_proj launch (small-row regime only); a buffer of their own: the
+  // fused FFN's partials (t_hid) are written with write-through stores right after these were read
+  const size_t n_part = (Bc_max * TOK <= g_attn_fuse_max_rows) ? (size_t)8 * Bc_max * n_tok : 0;
   {
-    int r = ensure(h, h->enc_scr, per_pair * Bc_max);
+    int r = ensure(h, h->enc_scr, per_pair * Bc_max + n_part);
     if (r) return r;
   }
   float* p = h->enc_scr.ptr;
@@ -606,6 +631,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   float* t_ao = p; p += n_tok * Bc_max;
   float* t_qkv = p; p += (size_t)TOK * 3 * D * Bc_max;
   float* t_hid = p; p += (size_t)TOK * 4 * FFN * Bc_max;  // hidden activations, or up to 16 partial outputs of the fused FFN
+  float* t_part = p; p += n_part;
 
   if (h->prof) prof_reset(h);
   prof_mark(h, "begin", s);
@@ -680,12 +706,12 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
       if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
       float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
-      if (M <= g_attn_fuse_max_rows && M <= g_ffn_fuse_max_rows && !g_ffn_preln) {
+      if (n_part != 0 && M <= g_attn_fuse_max_rows && M <= g_ffn_fuse_max_rows && !g_ffn_preln) {
         // out_proj inside the attention kernel (8 per-head partial outputs), summed + bias + residual + norm1 by ln_reduce
         KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
-                                       nullptr, 0, e.out_w, t_hid, Bc, TOK, s), "attention+out_proj");
+                                       nullptr, 0, e.out_w, t_part, Bc, TOK, s), "attention+out_proj");
         prof_mark(h, "attention+oproj enc", s, 2);
-        KCHK(h, launch_ln_reduce(t_hid, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
+        KCHK(h, launch_ln_reduce(t_part, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
         prof_mark(h, "ln_reduce heads", s, 2);
         if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_tmp, y, M, s))) return r;
       } else {
@@ -731,7 +757,7 @@ struct DecPlan {
   int q_chunk = 0, nb_max = 0;
   size_t Rmax = 0;
   float *qpos = nullptr, *tgt = nullptr, *q = nullptr, *ao = nullptr, *pre2 = nullptr, *t2 = nullptr, *pre3 = nullptr,
-        *hid = nullptr;
+        *hid = nullptr, *part = nullptr;
   bool single_chunk = false;
 };
 
@@ -742,7 +768,8 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
   d.Rmax = (size_t)d.nb_max * d.q_chunk;
   d.single_chunk = d.nb_max >= B && d.q_chunk >= Q;
   const size_t hid_per_row = d.Rmax <= (size_t)g_ffn_fuse_max_rows ? 4 * FFN : FFN;  // fused FFN: up to 16 partial outputs
-  int r = ensure(h, h->dec_scr, d.Rmax * (7 * D + hid_per_row));
+  const size_t part_per_row = d.Rmax <= (size_t)g_attn_fuse_max_rows ? 8 * D : 0;  // per-head partials of attention + out_proj
+  int r = ensure(h, h->dec_scr, d.Rmax * (7 * D + hid_per_row + part_per_row));
   if (r) return r;
   float* p = h->dec_scr.ptr;
   d.qpos = p; p += d.Rmax * D;
@@ -753,6 +780,7 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
   d.t2 = p; p += d.Rmax * D;
   d.pre3 = p; p += d.Rmax * D;
   d.hid = p; p += d.Rmax * hid_per_row;
+  d.part = part_per_row ? p : nullptr; p += d.Rmax * part_per_row;
   return COTR_OK;
 }
 
@@ -771,12 +799,12 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
                  int Q, hipStream_t s) {
   DecPlan d = d0;
   d.qpos += row0 * D; d.tgt += row0 * D; d.q += row0 * D; d.ao += row0 * D; d.pre2 += row0 * D; d.t2 += row0 * D;
-  d.pre3 += row0 * D; d.hid += row0 * FFN;
+  d.pre3 += row0 * D; d.hid += row0 * FFN;   // (row0 is 0 in every caller; d.part is only valid for row0 == 0)
   const int L = (int)h->dec.size();
   const int KVLD = L * 2 * D;
   const int R = nb * nq;
   int r;
-  const bool fused = R <= g_attn_fuse_max_rows && R <= g_ffn_fuse_max_rows && !g_ffn_preln;
+  const bool fused = d.part != nullptr && R <= g_attn_fuse_max_rows && R <= g_ffn_fuse_max_rows && !g_ffn_preln;
   if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s, fused))) return r;
   // transformer.py:185-201 per layer (cross-attention only, post-norm)
   for (int li = 0; li < L; ++li) {
@@ -785,10 +813,10 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       // q = Wq(tgt + query_pos) * 32^-0.5 in the attention kernel's prologue (tgt == 0 at layer 0, transformer.py:54), out_proj
       // in its epilogue (8 per-head partials), then ln_reduce: sum + bias + residual + norm2; FFN block; 4 launches per layer
       KCHK(h, launch_attention_fused(nullptr, 0, li == 0 ? nullptr : d.tgt, d.qpos, w.q_w, w.q_b, QSCALE,
-                                     kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, nullptr, 0, w.out_w, d.hid,
+                                     kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, nullptr, 0, w.out_w, d.part,
                                      nb, nq, s), "q_proj+attention+out_proj");
       prof_mark(h, "qproj+attention+oproj dec", s, 2);
-      KCHK(h, launch_ln_reduce(d.hid, 8, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
+      KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
       prof_mark(h, "ln_reduce heads", s, 2);
       if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, d.tgt, R, s))) return r;
       continue;
@@ -878,6 +906,71 @@ int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, i
   return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
 }
 
+// bytes of the three arenas a call of that size carves (each rounded up to 256 B): what cotr_set_workspace must be given
+int cotr_scratch_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
+  if (!h || !bytes || B <= 0 || Q < 0) return COTR_ERR_ARG;
+  const size_t L = h->dec.empty() ? 6 : h->dec.size();
+  const size_t Bc = B < g_enc_chunk ? B : g_enc_chunk;
+  const size_t per_pair = (size_t)128 * 256 * 64 + (size_t)64 * 128 * 64 + 5 * (size_t)64 * 128 * 256 +
+                          6 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
+  const size_t q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
+  const size_t pairs_per = (Q > 0 && Q < DEC_ROWS) ? (DEC_ROWS / Q) : 1;
+  const size_t nb = (size_t)B < pairs_per ? B : pairs_per;
+  const size_t R = nb * q_chunk;
+  // (an upper bound over the fusion thresholds' settings: flipping a tuning knob must not make a sized workspace too small)
+  const size_t thr_a = g_attn_fuse_max_rows > 1024 ? g_attn_fuse_max_rows : 1024, thr_f = g_ffn_fuse_max_rows > 1024 ? g_ffn_fuse_max_rows : 1024;
+  const size_t f_memkv = (size_t)B * TOK * (D + L * 2 * D);
+  const size_t f_enc = per_pair * Bc + (Bc * TOK <= thr_a ? 8 * Bc * TOK * D : 0);
+  const size_t f_dec = R * (7 * D + (R <= thr_f ? 4 * FFN : FFN) + (R <= thr_a ? 8 * D : 0));
+  size_t total = 0;
+  for (size_t f : {f_memkv, f_enc, f_dec}) total = ((total + 255) & ~size_t(255)) + f * sizeof(float);
+  *bytes = total + 256;
+  return COTR_OK;
+}
+
+// Scratch from the CALLER's allocator (torch's caching allocator in the Python binding): the handle carves its encode cache
+// and its two scratch arenas from [ws, ws + bytes) instead of owning hipMalloc'ed memory that it would have to hipFree +
+// hipMalloc (a device synchronisation in the middle of the stream) whenever a larger batch arrives.  With keep_encode a cached
+// encode is carried over (copied on `stream`; its region is the first carve, so the workspace should be sized for the same
+// number of pairs); ws == NULL returns to handle-owned memory and drops it.  The memory must stay valid until the next cotr_set_workspace /
+// cotr_destroy and all work enqueued on it has finished.
+int cotr_set_workspace(cotr_handle h, void* ws, size_t bytes, int keep_encode, cotr_stream stream) {
+  if (!h || (ws != nullptr && (bytes == 0 || ((uintptr_t)ws & 255)))) return COTR_ERR_ARG;
+  DEVICE_SCOPE(h);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // a cached encode moves with the workspace (copied on `stream`, ordered after the work that produced it): a caller that
+  // encodes once and then decodes a larger query set than ever before keeps its encode
+  const size_t L = h->dec.size();
+  const size_t keep = (ws != nullptr && keep_encode && h->enc_B > 0 && h->memkv.ptr) ? (size_t)h->enc_B * TOK * (D + L * 2 * D) : 0;
+  if (keep * sizeof(float) > bytes) { h->err = "cotr_set_workspace: smaller than the cached encode"; return COTR_ERR_ARG; }
+  if (keep) HIPCHK(h, hipMemcpyAsync(ws, h->memkv.ptr, keep * sizeof(float), hipMemcpyDeviceToDevice, s));
+  bool synced = false;
+  for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr}) {
+    if (a->ptr && !a->external) {
+      if (!synced) HIPCHK(h, hipDeviceSynchronize());
+      synced = true;
+      HIPCHK(h, hipFree(a->ptr));
+    }
+    *a = Arena();
+  }
+  h->ws = static_cast<char*>(ws);
+  h->ws_bytes = ws ? bytes : 0;
+  h->ws_used = 0;
+  h->taps.clear();
+  if (keep) {   // first carve = the encode cache, already filled
+    h->memkv.ptr = static_cast<float*>(ws);
+    h->memkv.cap = keep;
+    h->memkv.external = true;
+    h->ws_used = keep * sizeof(float);
+    h->taps["memory"] = {h->memkv.ptr, (size_t)h->enc_B * TOK * D};
+    h->taps["kv"] = {h->memkv.ptr + (size_t)h->enc_B * TOK * D, (size_t)h->enc_B * TOK * L * 2 * D};
+    h->taps["pos"] = {h->pos, (size_t)TOK * D};
+  } else {
+    h->enc_B = 0;
+  }
+  return COTR_OK;
+}
+
 int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   if (!h || !bytes || B <= 0 || Q < 0) return COTR_ERR_ARG;
   const size_t L = h->dec.empty() ? 6 : h->dec.size();
@@ -888,7 +981,9 @@ int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   const size_t pairs_per = (Q > 0 && Q < DEC_ROWS) ? (DEC_ROWS / Q) : 1;
   const size_t nb = (size_t)B < pairs_per ? B : pairs_per;
   size_t fl = h->wfloats + (size_t)TOK * D + (size_t)B * TOK * (D + L * 2 * D) + per_pair * Bc +
-              nb * q_chunk * (7 * D + (nb * q_chunk <= (size_t)g_ffn_fuse_max_rows ? 4 * FFN : FFN));
+              (Bc * TOK <= (size_t)g_attn_fuse_max_rows ? 8 * Bc * TOK * D : 0) +
+              nb * q_chunk * (7 * D + (nb * q_chunk <= (size_t)g_ffn_fuse_max_rows ? 4 * FFN : FFN) +
+                              (nb * q_chunk <= (size_t)g_attn_fuse_max_rows ? 8 * D : 0));
   *bytes = fl * sizeof(float);
   return COTR_OK;
 }
@@ -1095,6 +1190,11 @@ int cotr_set_ffn_preln(int enable) {
 
 int cotr_set_ffn_tail(int enable) {
   g_ffn_tail = enable != 0;
+  return COTR_OK;
+}
+
+int cotr_set_ks3(int enable) {
+  gemm_set_ks3(enable != 0);
   return COTR_OK;
 }
 

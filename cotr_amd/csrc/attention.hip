@@ -34,8 +34,8 @@
 //       (transformer.py:153,195: out_proj) and writes a partial [32 x 256] row block; the 8 per-head partials are summed, biased,
 //       added to the residual and normalised by ln_reduce_kernel - the launch that followed the projection anyway.
 struct AttnFuse {
-  const float* x;      // QP: [rows][256] decoder state (nullptr with x2 only: layer 0, tgt == 0)
-  const float* x2;     // QP: [rows][256] query encoding added to x (may be nullptr)
+  const float* x;      // QP: [rows][256] rows to project
+  const float* x2;     // QP == 2: [rows][256] added to x first (decoder: tgt + query_pos; layer 0 has tgt == 0 -> x = query_pos)
   const float* wq;     // QP: [256][256] q rows of in_proj_weight
   const float* bq;     // QP: [256]
   float qscale;        // QP: head_dim^-0.5
@@ -45,7 +45,7 @@ struct AttnFuse {
   int wt;              // OP: write-through (sc1) stores for the partials (read once, by every XCD)
 };
 
-template <int NS, bool QP, bool OP>
+template <int NS, int QP, bool OP>   // QP: 0 = q given, 1 = project x, 2 = project x + x2
 __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restrict__ q, int ldq,
                                                             const float* __restrict__ k,
                                                             const float* __restrict__ v, int ldkv,
@@ -54,7 +54,10 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
   static_assert(!(QP || OP) || NS == 4, "the fused variants are written for 4 key splits");
   constexpr int NBLK = ATT_KEYS / NS / 32;  // key blocks per wavefront
   constexpr int RPW = 16 / NS;              // accumulator rows finished per wavefront in the merge
-  __shared__ float lds_o[NS][16][64];
+  // key-split merge buffer [NS][16][64]; the out-projection epilogue reuses it as 4 wave-private staging tiles [32][68]
+  constexpr int LDS_BUF = OP ? (4 * 32 * 68 > NS * 16 * 64 ? 4 * 32 * 68 : NS * 16 * 64) : NS * 16 * 64;
+  __shared__ __attribute__((aligned(16))) float lds_buf[LDS_BUF];
+  float (*lds_o)[16][64] = reinterpret_cast<float (*)[16][64]>(lds_buf);
   __shared__ float lds_m[NS][32];
   __shared__ float lds_l[NS][32];
   __shared__ __attribute__((aligned(16))) float lds_out[32][36];  // merged O tile [query][d], rows 16-B aligned
@@ -72,26 +75,51 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
   const bool q_ok = qi < nq;
   const size_t qrow = (size_t)pair * nq + (q_ok ? qi : 0);
 
+  const size_t key0 = (size_t)pair * ATT_KEYS + (size_t)wave * (ATT_KEYS / NS);
+  // K fragment (A operand of S^T): lane (key l31, half hh) reads k[key][j*8 + hh*4 .. +3]
+  const float* kg = k + (key0 + l31) * ldkv + head * ATT_HD + hh * 4;
+  // V fragment (A operand of O^T): lane (d l31, half hh) reads v[key(r, hh)][d]
+  const float* vg = v + (key0 + 4 * hh) * ldkv + head * ATT_HD + l31;
+  // everything that does not depend on the queries is requested first: its latency hides under the q projection
+  f32x4 kf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kg + j * 8);
+  f32x4 wof[2][4];   // OP: W_out fragment of this wave's two 32-column blocks (B operand: lane n = l31, k = head dims)
+  if constexpr (OP) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float* worow = fz.wo + (size_t)((wave * 2 + nb) * 32 + l31) * 256 + head * ATT_HD + hh * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wof[nb][j] = *reinterpret_cast<const f32x4*>(worow + j * 8);
+    }
+  }
+
   // Q^T fragment (B operand): lane holds q[qi][j*8 + hh*4 + e]
   f32x4 qf[4];
   if constexpr (QP) {
+    f32x4 bq4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bq4[j] = *reinterpret_cast<const f32x4*>(fz.bq + head * ATT_HD + j * 8 + hh * 4);
     // wave w contracts over model channels [64w, 64w + 64): A = Wq_h (lane: head dim l31, k half hh), B = X^T (lane: query l31)
     f32x16 qacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
+    // every load is unconditional (rows past nq re-read row 0 of the pair and are never stored): a per-element
+    // "load or zero" select would make the compiler branch around each load and wait for it - 16 dependent L2 round trips
     const float* wrow = fz.wq + (size_t)(head * ATT_HD + l31) * 256 + wave * 64 + hh * 4;
-    const float* xrow = fz.x ? fz.x + qrow * 256 + wave * 64 + hh * 4 : nullptr;
-    const float* x2row = fz.x2 ? fz.x2 + qrow * 256 + wave * 64 + hh * 4 : nullptr;
+    const float* xrow = fz.x + qrow * 256 + wave * 64 + hh * 4;
     f32x4 wa[8], xb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      wa[j] = *reinterpret_cast<const f32x4*>(wrow + j * 8);
-      f32x4 b = {0.f, 0.f, 0.f, 0.f};
-      if (q_ok) {
-        if (xrow) b = *reinterpret_cast<const f32x4*>(xrow + j * 8);
-        if (x2row) b += *reinterpret_cast<const f32x4*>(x2row + j * 8);
-      }
-      xb[j] = b;
+    for (int j = 0; j < 8; ++j) wa[j] = *reinterpret_cast<const f32x4*>(wrow + j * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8);
+    if constexpr (QP == 2) {
+      const float* x2row = fz.x2 + qrow * 256 + wave * 64 + hh * 4;
+      f32x4 x2b[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x2b[j] = *reinterpret_cast<const f32x4*>(x2row + j * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xb[j] += x2b[j];
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -109,7 +137,7 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
 #pragma unroll
         for (int w = 0; w < NS; ++w) sum += lds_o[w][r][lane];
         // D row r of this lane = head dim (r&3) + 8*(r>>2) + 4*hh = j*8 + hh*4 + e
-        sum += fz.bq[head * ATT_HD + j * 8 + hh * 4 + e];
+        sum += bq4[j][e];
         qf[j][e] = sum * fz.qscale * 1.44269504088896340736f;
       }
     __syncthreads();   // lds_o is reused by the key-split merge below
@@ -123,16 +151,6 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
       qf[j] *= 1.44269504088896340736f;
     }
   }
-  const size_t key0 = (size_t)pair * ATT_KEYS + (size_t)wave * (ATT_KEYS / NS);
-  // K fragment (A operand of S^T): lane (key l31, half hh) reads k[key][j*8 + hh*4 .. +3]
-  const float* kg = k + (key0 + l31) * ldkv + head * ATT_HD + hh * 4;
-  // V fragment (A operand of O^T): lane (d l31, half hh) reads v[key(r, hh)][d]
-  const float* vg = v + (key0 + 4 * hh) * ldkv + head * ATT_HD + l31;
-
-  f32x4 kf[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kg + j * 8);
-
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
@@ -212,31 +230,33 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
   }
   __syncthreads();
   if constexpr (OP) {
-    // partial[head][row][n] = sum_d O[row][d] * Wo[n][head*32 + d]: wave w -> output columns [64w, 64w + 64)
-    float* pbase = fz.part + ((size_t)head * fz.rows_total + (size_t)pair * nq) * 256;
+    // partial[head][row][n] = sum_d O[row][d] * Wo[n][head*32 + d]: wave w -> output columns [64w, 64w + 64).  The accumulators
+    // go through a wave-private LDS tile so that the partial rows leave as float4 (one instruction = 4 rows x 256 B) instead of
+    // 32 scattered dword stores per lane
+    float* stage = lds_buf + wave * (32 * 68);    // aliases lds_o: every wave is past the merge (barrier above)
+    f32x4 af[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(&lds_out[l31][j * 8 + hh * 4]);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const int n = (wave * 2 + nb) * 32 + l31;
-      const float* worow = fz.wo + (size_t)n * 256 + head * ATT_HD + hh * 4;
       f32x16 pacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&lds_out[l31][j * 8 + hh * 4]);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(worow + j * 8);
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], pacc, 0, 0, 0);
-      }
+        for (int e = 0; e < 4; ++e) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], wof[nb][j][e], pacc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qo = qtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (qo < nq) {
-          float* dst = pbase + (size_t)qo * 256 + n;
-          if (fz.wt) __hip_atomic_store(dst, pacc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *dst = pacc[r];
-        }
-      }
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * 68 + nb * 32 + l31] = pacc[r];
+    }
+    float* pbase = fz.part + ((size_t)head * fz.rows_total + (size_t)pair * nq) * 256 + wave * 64;
+    const int sr = lane >> 4, sc = (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + sr;
+      const int qo = qtile * 32 + row;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * 68 + sc]);
+      if (qo < nq) store_f32x4(pbase + (size_t)qo * 256 + sc, val, fz.wt != 0);
     }
     if (o == nullptr) return;
   }
@@ -268,19 +288,19 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
   if (ns == 0) ns = 4;
   switch (ns) {
     case 1:
-      hipLaunchKernelGGL((attention_kernel<1, false, false>), grid, dim3(64), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+      hipLaunchKernelGGL((attention_kernel<1, 0, false>), grid, dim3(64), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     case 2:
-      hipLaunchKernelGGL((attention_kernel<2, false, false>), grid, dim3(128), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+      hipLaunchKernelGGL((attention_kernel<2, 0, false>), grid, dim3(128), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     case 4:
-      hipLaunchKernelGGL((attention_kernel<4, false, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+      hipLaunchKernelGGL((attention_kernel<4, 0, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     case 8:
-      hipLaunchKernelGGL((attention_kernel<8, false, false>), grid, dim3(512), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+      hipLaunchKernelGGL((attention_kernel<8, 0, false>), grid, dim3(512), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     case 16:
-      hipLaunchKernelGGL((attention_kernel<16, false, false>), grid, dim3(1024), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+      hipLaunchKernelGGL((attention_kernel<16, 0, false>), grid, dim3(1024), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
       break;
     default:
       return -1;
@@ -301,15 +321,17 @@ int launch_attention_fused(const float* q, int ldq, const float* x, const float*
   if (!op && o == nullptr) return -1;
   dim3 grid(((nq + 31) / 32) * 8, 1, nb);
   AttnFuse fz = {};
-  fz.x = x; fz.x2 = x2; fz.wq = wq; fz.bq = bq; fz.qscale = qscale;
+  fz.x = x ? x : x2; fz.x2 = x ? x2 : nullptr; fz.wq = wq; fz.bq = bq; fz.qscale = qscale;
   fz.wo = wo; fz.part = part; fz.rows_total = nb * nq; fz.wt = g_att_part_wt;
-  if (qp && op)
-    hipLaunchKernelGGL((attention_kernel<4, true, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
-  else if (qp)
-    hipLaunchKernelGGL((attention_kernel<4, true, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
-  else if (op)
-    hipLaunchKernelGGL((attention_kernel<4, false, true>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
-  else
-    hipLaunchKernelGGL((attention_kernel<4, false, false>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz);
+  const int qmode = !qp ? 0 : (fz.x2 ? 2 : 1);
+#define ATT_LAUNCH(QPV, OPV)                                                                                              \
+  hipLaunchKernelGGL((attention_kernel<4, QPV, OPV>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz)
+  if (qmode == 2 && op) ATT_LAUNCH(2, true);
+  else if (qmode == 2) ATT_LAUNCH(2, false);
+  else if (qmode == 1 && op) ATT_LAUNCH(1, true);
+  else if (qmode == 1) ATT_LAUNCH(1, false);
+  else if (op) ATT_LAUNCH(0, true);
+  else ATT_LAUNCH(0, false);
+#undef ATT_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

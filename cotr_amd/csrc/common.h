@@ -11,6 +11,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // wavefront's own first ds_read, which leaves the other wavefronts' reads unordered): state it explicitly.
 #define LDS_DMA_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
+// 16-byte store, optionally write-through (sc1): for buffers that another kernel reads exactly once from every XCD (the
+// per-chunk / per-head partial outputs), so that nothing dirty is left in this XCD's L2 for the launch boundary to write
+// back.  Scalar sc1 stores cost ~6x a 16-byte one per byte (MI355X_MICROARCH.md), hence the float4 form.
+__device__ __forceinline__ void store_f32x4(float* dst, const f32x4 v, const bool write_through) {
+  if (write_through) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+  else *reinterpret_cast<f32x4*>(dst) = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-device one-time state.  A process may hold handles on several GPUs (cotr_create(&h, device)): function attributes
 // (the > 64 KB dynamic-LDS opt-in is per device), the zero buffer of the LDS-DMA kernels and the arrival counters of the
@@ -114,6 +122,7 @@ bool gemm_cfg_supports_dual(int cfg);
 int gemm_num_configs();
 void gemm_set_xcd_policy(int v);  // 0 column tiles over XCDs, 1 by operand size (default), 2 row tiles over XCDs
 bool gemm_cfg_supports_ln(int cfg);
+void gemm_set_ks3(int v);  // 1 (default): three-stage LDS-DMA k-split instead of the two-stage one where K >= 768
 const float* gemm_zero_buffer();  // per-DEVICE buffer of zeros (LDS-DMA padding source), on the current device
 
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]

@@ -166,25 +166,31 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
 
   // partial output block of this wave: rows m0 + (r&3) + 8*(r>>2) + 4*hh, columns 32*wave + l31
   float* out = p.P + (size_t)chunk * p.M * FF_D;
+  if (p.counters == nullptr) {
+    // through a wave-private LDS tile (the W1 stage is free: no DMA is in flight after the last sub-chunk and every wave is
+    // past its last read of it, barrier "H complete") so that the rows leave as float4 - one instruction = 8 rows x 128 B.
+    // Write-through (sc1): the 8-16 MB of partial outputs are read once, by ln_reduce on all XCDs; left dirty in L2 they are
+    // written back at the kernel boundary (MI355X_MICROARCH.md price table: + dirty bytes / 6 TB/s per boundary).
+    float* stage = W1s + wave * (32 * 36);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * 36 + l31] = acc2[r];
+    const int sr = lane >> 3, sc = (lane & 7) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + sr;
+      const f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * 36 + sc]);
+      if (m0 + row < p.M) store_f32x4(out + (size_t)(m0 + row) * FF_D + 32 * wave + sc, val, p.wt_partials != 0);
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    if (m < p.M) {
-      // with the tail, partials are exchanged between workgroups of different XCDs inside this launch: agent-scope
-      // (sc1) stores / loads go to the memory side and bypass the per-XCD L2s, so no L2 write-back / invalidate is needed
-      // (a __threadfence() pair here cost ~50 us per launch)
-      // write-through (sc1) stores: the 8-16 MB of partial outputs are read once, by ln_reduce on all XCDs; left dirty in
-      // L2 they are written back at the kernel boundary (MI355X_MICROARCH.md price table: + dirty bytes / 6 TB/s per
-      // boundary).  Measured 1.037 -> 1.025 ms per forward; the same on GEMM / LayerNorm / attention outputs measured
-      // slower (1.057 vs 1.048 ms), so only here.  The in-kernel tail needs them as well (cross-XCD visibility).
-      if (p.counters != nullptr || p.wt_partials)
-        __hip_atomic_store(&out[(size_t)m * FF_D + 32 * wave + l31], acc2[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        out[(size_t)m * FF_D + 32 * wave + l31] = acc2[r];
-    }
+    // with the tail, partials are exchanged between workgroups of different XCDs inside this launch: agent-scope
+    // (sc1) stores / loads go to the memory side and bypass the per-XCD L2s, so no L2 write-back / invalidate is needed
+    if (m < p.M) __hip_atomic_store(&out[(size_t)m * FF_D + 32 * wave + l31], acc2[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 
-  if (p.counters == nullptr) return;
   // ---- tail: last arriver of this row tile reduces + normalises ----------------------------------------------------
   __shared__ int s_last;
   __builtin_amdgcn_s_waitcnt(0);                     // this thread's partial stores have reached the memory side ...

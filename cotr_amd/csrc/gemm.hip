@@ -43,7 +43,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   const float* a2_ptr[RA];
   bool a_ok[RA];
   int c_hi0[RA], c_wi0[RA];
-  const bool use_a2 = (MODE == GEMM_DENSE) && p.A2 != nullptr && (n0 % p.a2_period) < p.a2_width;
+  // x + pos prologue (q | k column tiles of an in-projection): the A2 loads must not sit behind a per-element wave-uniform
+  // branch (hipcc then waits for every load before the next one: measured 4 dependent L2 round trips per K step), so a launch
+  // with an A2 operand ALWAYS loads it - tiles that do not use it read a zero row with stride 0 - and adds it at the LDS store
+  const bool has_a2 = (MODE == GEMM_DENSE) && p.A2 != nullptr;
+  const bool use_a2 = has_a2 && (n0 % p.a2_period) < p.a2_width;
+  const int a2_step = use_a2 ? BK : 0;
   // stem bookkeeping (MODE == GEMM_STEM): one output pixel per thread, 16 k's per tile
   int s_hi0 = 0, s_wi0 = 0;
   const float* s_base = nullptr;
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       a_ok[i] = m < p.M;
       const int mm = a_ok[i] ? m : 0;
       a_ptr[i] = p.A + (size_t)mm * p.lda + lc;
-      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? mm % p.a2_row_mod : mm) * p.lda2 + lc : nullptr;
+      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? mm % p.a2_row_mod : mm) * p.lda2 + lc : p.zeros;
     }
   } else if constexpr (MODE == GEMM_CONV) {
     const int W2o = 2 * p.Wout;
@@ -95,7 +100,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < RW; ++i) w_ptr[i] = p.W + (size_t)(n0 + lr + 32 * i) * p.K + lc;
 
-  f32x4 ra[RA], rw[RW];
+  f32x4 ra[RA], ra2[RA], rw[RW];
   float rs[16];
 
   auto load_tile = [&](int kt) {
@@ -106,11 +111,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (a_ok[i]) {
-          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
-          if (use_a2) v += *reinterpret_cast<const f32x4*>(a2_ptr[i] + kt * BK);
-        }
+        if (a_ok[i]) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + kt * BK);
         ra[i] = v;
+      }
+      if (has_a2) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) ra2[i] = *reinterpret_cast<const f32x4*>(a2_ptr[i] + kt * a2_step);
       }
     } else if constexpr (MODE == GEMM_CONV) {
       const int tiles_per_tap = p.Cin / BK;
@@ -150,6 +156,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) As[(t & (BM - 1)) * LDSLD + (t >> 7) + 2 * i] = rs[i];
     } else {
+      if (has_a2) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) ra[i] += ra2[i];
+      }
 #pragma unroll
       for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lr + 32 * i) * LDSLD + lc]) = ra[i];
     }
@@ -264,7 +274,10 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   const float* a2_ptr[PA];
   bool a_ok[PA];
   int c_hi0[PA], c_wi0[PA];
-  const bool use_a2 = (MODE == GEMM_DENSE) && p.A2 != nullptr && (n0 % p.a2_period) < p.a2_width;
+  // see gemm_kernel: with an A2 operand every tile loads it (zero row, stride 0 where unused), no per-element uniform branch
+  const bool has_a2 = (MODE == GEMM_DENSE) && p.A2 != nullptr;
+  const bool use_a2 = has_a2 && (n0 % p.a2_period) < p.a2_width;
+  const int a2_step = use_a2 ? KS : 0;
   if constexpr (MODE == GEMM_DENSE) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
@@ -272,7 +285,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
       a_ok[i] = m < p.M;
       const int mm = a_ok[i] ? m : 0;
       a_ptr[i] = p.A + (size_t)mm * p.lda + lc4 * 4;
-      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? mm % p.a2_row_mod : mm) * p.lda2 + lc4 * 4 : nullptr;
+      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? mm % p.a2_row_mod : mm) * p.lda2 + lc4 * 4 : p.zeros;
     }
   } else {
     const int W2o = 2 * p.Wout;
@@ -297,7 +310,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
 #pragma unroll
   for (int i = 0; i < PW; ++i) w_ptr[i] = p.W + (size_t)(n0 + lr + 8 * i) * p.K + lc4 * 4;
 
-  f32x4 ra[PA], rw[PW];
+  f32x4 ra[PA], ra2[PA], rw[PW];
   const int tiles_per_tap = (MODE == GEMM_CONV) ? p.Cin / BK : 1;
 
   auto load_tile = [&](int st) {
@@ -311,11 +324,15 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         f32x4 v = z;
-        if (a_ok[i] && k_ok) {
-          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + st * KS);
-          if (use_a2) v += *reinterpret_cast<const f32x4*>(a2_ptr[i] + st * KS);
-        }
+        if (a_ok[i] && k_ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + st * KS);
         ra[i] = v;
+      }
+      if (has_a2) {   // rows past M re-read a valid row (never stored); k-tiles past K read the zero row (address select, no branch)
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const float* src = k_ok ? a2_ptr[i] + st * a2_step : p.zeros;
+          ra2[i] = *reinterpret_cast<const f32x4*>(src);
+        }
       }
     } else {
       const int tap = kt / tiles_per_tap;
@@ -337,6 +354,10 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   auto store_tile = [&](int buf) {
     float* As = smem + buf * TILE;
     float* Ws = As + BM * LD;
+    if (has_a2) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] += ra2[i];
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(&As[(lr + 8 * i) * LD + lc4 * 4]) = ra[i];
 #pragma unroll
@@ -402,7 +423,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   // so the LDS destination is wave-uniform as the instruction requires; out-of-range rows / padded taps
   // read a zero buffer instead.  The transfer of step st+1 runs under the MFMAs of step st.
   auto dma_tile = [&](int st, int buf) {
-    static_assert(DB != 2 || C4 == 64, "one wave instruction per LDS row needs 8 wavefronts");
+    static_assert(DB < 2 || C4 == 64, "one wave instruction per LDS row needs 8 wavefronts");
     float* As = smem + buf * TILE;
     float* Ws = As + BM * LD;
     const int kt = st * NWK + ktl;
@@ -437,7 +458,29 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
     }
   };
 
-  if constexpr (DB == 2) {
+  if constexpr (DB == 3) {
+    // Three LDS stages, TWO tiles of LDS-DMA in flight.  At one pair a CU holds a single workgroup and a K step's MFMAs
+    // (0.2 us) cannot cover the L2 / Infinity-Cache latency of the next tile's DMA (~1.3 us): with two stages every step
+    // costs one full DMA latency.  Here the wait before the barrier of step st is a COUNTED vmcnt that covers tile st only
+    // (one tile = PA + PW DMA instructions per wavefront), tile st+1 stays in flight across the raw s_barrier
+    // (__syncthreads() would drain the queue) and tile st+2 is requested right after it, into the stage whose last reads
+    // (step st-1) every wavefront retired (lgkmcnt(0)) before arriving at this barrier.
+    static_assert(PA + PW == 6, "the counted wait below is written for 6 DMA instructions per tile (32 x 16 tile, 8 waves)");
+    dma_tile(0, 0);
+    if (steps > 1) dma_tile(1, 1);
+    int stg = 0;
+    for (int st = 0; st < steps; ++st) {
+      if (st + 1 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");                    // no LDS access of this step may be scheduled above the barrier
+      if (st + 2 < steps) dma_tile(st + 2, stg == 0 ? 2 : stg - 1);
+      compute(stg);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are retired before the next barrier
+      stg = stg == 2 ? 0 : stg + 1;
+    }
+    __syncthreads();                                    // the stages are reused by the cross-wave reduction below
+  } else if constexpr (DB == 2) {
     dma_tile(0, 0);
     LDS_DMA_WAIT_ALL();
     __syncthreads();
@@ -589,6 +632,7 @@ static const GemmCfg kCfgs[] = {
     {4, 0, 2, 1},   // 27 large tile 128x64
     {5, 0, 2, 2},   // 28 large tile 128x128, three LDS stages (two tiles of LDS-DMA in flight, counted vmcnt)
     {5, 0, 2, 1},   // 29 large tile 128x64, three LDS stages
+    {6, 8, 1, 0},   // 30 k-split 8 waves, 32x16, LDS-DMA with THREE stages (two tiles in flight, counted vmcnt)
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -605,7 +649,7 @@ static int launch_t(const GemmParams& p, hipStream_t s) {
 template <int NWK, int TM, int TN, int DB>
 static constexpr size_t ks_smem() {
   size_t rows = (size_t)TM * 32 + (TN == 0 ? 16 : TN * 32);
-  size_t tile = (size_t)(DB ? 2 : 1) * rows * (NWK * BK + 4) * sizeof(float);
+  size_t tile = (size_t)(DB == 3 ? 3 : DB ? 2 : 1) * rows * (NWK * BK + 4) * sizeof(float);
   size_t red = (size_t)NWK * (TN == 0 ? 8 : TM * TN * 16) * 64 * sizeof(float);
   return tile > red ? tile : red;
 }
@@ -647,7 +691,7 @@ static int launch_ks_dual(const GemmParams& p0, const GemmParams& p1, hipStream_
 
 template <int NWK, int TM, int TN, int MODE, int DB = 0>
 static int launch_ks(const GemmParams& p, hipStream_t s) {
-  if constexpr (DB == 2) {
+  if constexpr (DB >= 2) {
     if (p.A2 != nullptr) return -1;  // the x+pos prologue needs the register path
     GemmParams q = p;
     if (q.zeros == nullptr) q.zeros = gemm_zero_buffer();
@@ -691,6 +735,7 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 27: return launch_gemm_big(MODE, 1, p, s);
     case 28: return launch_gemm_big(MODE, 2, p, s);
     case 29: return launch_gemm_big(MODE, 3, p, s);
+    case 30: return launch_ks<8, 1, 0, MODE, 3>(p, s);
     default: return -1;
   }
 }
@@ -727,7 +772,7 @@ static const TunedEntry kTuned[] = {
 
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  if (c.kind >= 4) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
+  if (c.kind == 4 || c.kind == 5) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
     if (p.A2 != nullptr || p.ldc % 4 != 0 || ((uintptr_t)p.C & 15)) return false;
     if (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15))) return false;
     return p.N % (64 * c.tn) == 0;
@@ -735,17 +780,17 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
   const int bn = c.tn == 0 ? 16 : (c.kind == 0 ? 2 : 1) * c.tn * 32;
   if (c.kind != 0) {  // dynamic LDS of the k-split kernels must fit the CU's 160 KB
     const size_t rows = (size_t)c.tm * 32 + (c.tn == 0 ? 16 : c.tn * 32);
-    const size_t tile = (size_t)(c.kind >= 2 ? 2 : 1) * rows * (c.a * BK + 4) * sizeof(float);
+    const size_t tile = (size_t)(c.kind == 6 ? 3 : c.kind >= 2 ? 2 : 1) * rows * (c.a * BK + 4) * sizeof(float);
     const size_t red = (size_t)c.a * (c.tn == 0 ? 8 : c.tm * c.tn * 16) * 64 * sizeof(float);
     if ((tile > red ? tile : red) > 163840) return false;
-    if (c.kind == 3 && p.A2 != nullptr) return false;  // LDS-DMA has no register prologue (x + pos)
+    if ((c.kind == 3 || c.kind == 6) && p.A2 != nullptr) return false;  // LDS-DMA has no register prologue (x + pos)
   }
   return p.N % bn == 0;
 }
 
 // rough cost model (cycles) for shapes outside the tuned table
 static double model_cost(const GemmCfg& c, const GemmParams& p) {
-  if (c.kind >= 4) {  // pays off once the chip is covered several times over
+  if (c.kind == 4 || c.kind == 5) {  // pays off once the chip is covered several times over
     const int bm = 128, bn = 64 * c.tn;
     const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
     const double rounds = ceil(wgs / 512.0);
@@ -756,7 +801,7 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
   const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
   const int kt = p.K / BK;
   const int steps = c.kind == 0 ? kt : (kt + c.a - 1) / c.a;
-  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)(c.kind >= 2 ? 2 : 1) * (bm + bn) * (c.a * 32 + 4) * 4.0;
+  const double lds = c.kind == 0 ? (bm + bn) * 36 * 4.0 : (double)(c.kind == 6 ? 3 : c.kind >= 2 ? 2 : 1) * (bm + bn) * (c.a * 32 + 4) * 4.0;
   double per_cu = floor(163840.0 / lds);
   if (per_cu > 32.0 / waves) per_cu = 32.0 / waves;
   if (per_cu > 4) per_cu = 4;
@@ -768,7 +813,18 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
   return rounds * (steps * step + 2500.0 + (c.kind != 0 ? 600.0 : 0.0));
 }
 
+static int g_ks3 = 1;  // gemm_set_ks3: use the three-stage LDS-DMA k-split (30) where the measured table says its two-stage form (24)
+void gemm_set_ks3(int v) { g_ks3 = v; }
+static int gemm_pick_config_table(int mode, const GemmParams& p);
+
 int gemm_pick_config(int mode, const GemmParams& p) {
+  const int cfg = gemm_pick_config_table(mode, p);
+  // few workgroups per CU (one pair): the three-stage form hides the DMA latency the two-stage one exposes at every K step
+  if (cfg == 24 && g_ks3 && p.K >= 3 * 256 && cfg_fits(30, p)) return 30;
+  return cfg;
+}
+
+static int gemm_pick_config_table(int mode, const GemmParams& p) {
   if (mode == GEMM_STEM) return 1;
   // 1. measured table, exact shape; 2. same (N, K) at the nearest measured row count (log distance): the best
   // configuration changes slowly with M; 3. cost model
@@ -807,7 +863,7 @@ void gemm_set_xcd_policy(int v) { g_xcd_policy = v; }
 // which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
 static void set_xcd_split(int mode, int cfg, GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  const int bm = c.kind >= 4 ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
+  const int bm = (c.kind == 4 || c.kind == 5) ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
   const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
   const double w_bytes = (double)p.N * p.K * 4.0;
   const bool fits = (p.M + bm - 1) / bm >= 8;
@@ -829,6 +885,10 @@ int launch_gemm_cfg(int mode, int cfg, const GemmParams& p0, hipStream_t s) {
   if (p0.N % 16 != 0 || cfg < 0 || cfg >= kNumCfgs || !cfg_fits(cfg, p0)) return -1;
   GemmParams p = p0;
   set_xcd_split(mode, cfg, p);
+  if (p.A2 != nullptr && p.zeros == nullptr) {   // the x + pos prologue reads a zero row where a tile does not use A2
+    p.zeros = gemm_zero_buffer();
+    if (p.zeros == nullptr) return -2;
+  }
   switch (mode) {
     case GEMM_DENSE:
       if (p.lda % 4 != 0 || (p.A2 && p.lda2 % 4 != 0)) return -1;

@@ -33,42 +33,41 @@ __device__ __forceinline__ float head_wave_sum(float v) {
   return v;
 }
 
-// dst[16][256] = relu(src[16][256] . W^T + b) for this wavefront's 32 columns
-__device__ __forceinline__ void head_linear(const float* src, float* dst, const float* __restrict__ W, const float* __restrict__ bias,
-                                            int wave, int lane) {
-  const int l15 = lane & 15, kq = lane >> 4;
-  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  const float* wrow0 = W + (size_t)(32 * wave + l15) * HD_D + kq * 4;
-  const float* wrow1 = wrow0 + 16 * HD_D;
-  const float* arow = src + l15 * HD_LD + kq * 4;
+// One half (8 k-steps of 16 = 128 of the 256 input channels) of this wavefront's weight fragment: 2 column blocks x 8 float4.
+// The loads are issued a stage ahead of their use (the kernel is otherwise bound by the L2 round trip of each group).
+struct HeadW {
+  f32x4 b[2][8];
+};
+__device__ __forceinline__ void head_load_w(HeadW& w, const float* __restrict__ W, int wave, int lane, int half) {
+  const float* wrow = W + (size_t)(32 * wave + (lane & 15)) * HD_D + (lane >> 4) * 4 + half * 128;
 #pragma unroll
-  for (int jg = 0; jg < 4; ++jg) {   // 4 groups of 4 k-steps (16 k each): 8 weight float4 in flight per group
-    f32x4 b0[4], b1[4];
+  for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      b0[j] = *reinterpret_cast<const f32x4*>(wrow0 + (jg * 4 + j) * 16);
-      b1[j] = *reinterpret_cast<const f32x4*>(wrow1 + (jg * 4 + j) * 16);
-    }
+    for (int j = 0; j < 8; ++j) w.b[cb][j] = *reinterpret_cast<const f32x4*>(wrow + cb * 16 * HD_D + j * 16);
+}
+__device__ __forceinline__ void head_mma(f32x4 (&acc)[2], const float* src, const HeadW& w, int lane, int half) {
+  const float* arow = src + (lane & 15) * HD_LD + (lane >> 4) * 4 + half * 128;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(arow + (jg * 4 + j) * 16);
+  for (int j = 0; j < 8; ++j) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(arow + j * 16);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[j][e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[j][e], acc[1], 0, 0, 0);
-      }
+    for (int e = 0; e < 4; ++e) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w.b[0][j][e], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w.b[1][j][e], acc[1], 0, 0, 0);
     }
   }
-  // D: column = lane & 15, row = (lane >> 4) * 4 + reg
+}
+// dst[16][32 columns of this wavefront] = relu(acc + bias); D: column = lane & 15, row = (lane >> 4) * 4 + reg
+__device__ __forceinline__ void head_store(const f32x4 (&acc)[2], float* dst, const float* __restrict__ bias, int wave, int lane) {
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
-    const int n = 32 * wave + cb * 16 + l15;
+    const int n = 32 * wave + cb * 16 + (lane & 15);
     const float bv = bias[n];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float v = acc[cb][r] + bv;
       v = (v < 0.f) ? 0.f : v;   // NaN passes through like torch.relu
-      dst[(kq * 4 + r) * HD_LD + n] = v;
+      dst[((lane >> 4) * 4 + r) * HD_LD + n] = v;
     }
   }
 }
@@ -78,6 +77,9 @@ __global__ __launch_bounds__(512) void dec_head_kernel(const HeadParams p) {
   __shared__ __attribute__((aligned(16))) float ys[16 * HD_LD];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m0 = blockIdx.x * 16;
+  HeadW wa, wb;                               // both halves of layer 0's weights are requested before the norm
+  head_load_w(wa, p.w0, wave, lane, 0);
+  head_load_w(wb, p.w0, wave, lane, 1);
 
   // ---- decoder.norm: wave w -> rows 2w, 2w+1 (same arithmetic as layernorm_kernel, pointwise.hip) ----
   {
@@ -101,9 +103,21 @@ __global__ __launch_bounds__(512) void dec_head_kernel(const HeadParams p) {
     }
   }
   __syncthreads();
-  head_linear(xs, ys, p.w0, p.b0, wave, lane);
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    head_mma(acc, xs, wa, lane, 0);
+    head_load_w(wa, p.w1, wave, lane, 0);     // layer 1's first half streams in under the second half of layer 0
+    head_mma(acc, xs, wb, lane, 1);
+    head_load_w(wb, p.w1, wave, lane, 1);
+    head_store(acc, ys, p.b0, wave, lane);
+  }
   __syncthreads();
-  head_linear(ys, xs, p.w1, p.b1, wave, lane);
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    head_mma(acc, ys, wa, lane, 0);
+    head_mma(acc, ys, wb, lane, 1);
+    head_store(acc, xs, p.b1, wave, lane);   // xs is free: every wave passed the barrier after its layer-0 reads
+  }
   __syncthreads();
   // ---- last layer 256 -> 2: wave w -> rows 2w, 2w+1 (same arithmetic as head2_kernel) ----
   {

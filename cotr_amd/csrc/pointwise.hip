@@ -57,7 +57,19 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
     for (int i = 0; i < 4; ++i) rr[i] = dd[i] * rs * pw[i] + pb[i];
   }
   v += rr;
-  for (int c = 0; c < np; ++c) v += *reinterpret_cast<const f32x4*>(parts + ((size_t)c * rows + row) * 256 + lane * 4);
+  // the partial rows are independent loads: request 8 at a time and add them in order afterwards (a plain
+  // "for c: v += load" is np dependent L2 round trips - the loop is not unrolled for a runtime np); same sum order as before
+  const float* prow = parts + (size_t)row * 256 + lane * 4;
+  const size_t pstride = (size_t)rows * 256;
+  int c = 0;
+  for (; c + 8 <= np; c += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(prow + (size_t)(c + k) * pstride);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += t[k];
+  }
+  for (; c < np; ++c) v += *reinterpret_cast<const f32x4*>(prow + (size_t)c * pstride);
   const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
   const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
   const float var = wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);

@@ -163,6 +163,8 @@ class COTR(nn.Module):
         self._handle_device = None
         self._weights_dirty = True
         self._encoded_batch = 0
+        self._ws = None             # scratch handed to the library (torch caching allocator), see _ensure_workspace
+        self._ws_shape = (0, 0)
 
     # ------------------------------------------------------------------ weight synchronisation
     def _apply(self, fn, *a, **kw):  # .cuda() / .to() / .float() move or replace the storage
@@ -191,6 +193,7 @@ class COTR(nn.Module):
             _lib.check(lib.cotr_create(ctypes.byref(handle), index), None, 'cotr_create')
             self._handle, self._handle_device = handle, index
             self._weights_dirty = True
+            self._ws, self._ws_shape = None, (0, 0)
         if self._weights_dirty:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             bad = [k for k, v in sd.items() if v.dtype != torch.float32]
@@ -207,6 +210,27 @@ class COTR(nn.Module):
             self._encoded_batch = 0
         return lib
 
+    def _ensure_workspace(self, lib, device, b, q, keep_encode=False):
+        """The library's encode cache + scratch come from torch's caching allocator (cotr_set_workspace): a larger batch then
+        costs one torch allocation instead of hipFree + hipMalloc (device synchronisations) inside the library.  The
+        workspace only grows; a cached encode is carried over into the new one (stream-ordered device copy; the old tensor
+        goes back to torch's pool, which is stream-ordered too)."""
+        b, q = max(b, self._ws_shape[0]), max(q, self._ws_shape[1])
+        if (b, q) == self._ws_shape:
+            return
+        need = ctypes.c_size_t()
+        _lib.check(lib.cotr_scratch_bytes(self._handle, b, max(q, 1), ctypes.byref(need)), self._handle, 'cotr_scratch_bytes')
+        if self._ws is None or self._ws.numel() < need.value + 256:
+            ws = torch.empty(need.value + 256, dtype=torch.uint8, device=device)
+            off = (-ws.data_ptr()) % 256
+            keep = int(keep_encode and b == self._ws_shape[0])     # same pairs, more queries: the cached encode moves along
+            _lib.check(lib.cotr_set_workspace(self._handle, ctypes.c_void_p(ws.data_ptr() + off), need.value, keep,
+                                              _lib.current_stream_ptr()), self._handle, 'cotr_set_workspace')
+            self._ws = ws
+            if not keep:
+                self._encoded_batch = 0
+        self._ws_shape = (b, q)
+
     def _release(self):
         handle = self.__dict__.get('_handle')
         if handle is not None:
@@ -222,6 +246,7 @@ class COTR(nn.Module):
     def __getstate__(self):  # the HIP handle is per process: never pickled / deep-copied
         state = self.__dict__.copy()
         state['_handle'], state['_handle_device'], state['_weights_dirty'], state['_encoded_batch'] = None, None, True, 0
+        state['_ws'], state['_ws_shape'] = None, (0, 0)
         return state
 
     # ------------------------------------------------------------------ the path
@@ -262,6 +287,7 @@ class COTR(nn.Module):
         lib = self._ensure_ready(img.device)
         img = img.contiguous().float()
         with torch.cuda.device(img.device):
+            self._ensure_workspace(lib, img.device, img.shape[0], self._ws_shape[1])
             _lib.check(lib.cotr_encode(self._handle, img.data_ptr(), img.shape[0], _lib.current_stream_ptr()),
                        self._handle, 'cotr_encode')
         self._encoded_batch = img.shape[0]
@@ -279,9 +305,19 @@ class COTR(nn.Module):
         qs = queries.contiguous().float()
         out = torch.empty((b, q, 2), dtype=torch.float32, device=qs.device)
         with torch.cuda.device(qs.device):
+            self._ensure_workspace(lib, qs.device, b, q, keep_encode=True)   # the cached encode moves along if it has to grow
+            if self._encoded_batch != b:
+                raise _lib.CotrHipError(f'decode of {b} pairs: the cached encode was dropped by a workspace change')
             _lib.check(lib.cotr_decode(self._handle, qs.data_ptr(), b, q, out.data_ptr(), _lib.current_stream_ptr()),
                        self._handle, 'cotr_decode')
         return out
+
+    def reserve(self, pairs, queries):
+        """Size the scratch workspace for calls of up to ``pairs`` x ``queries`` (optional; it otherwise grows on demand)."""
+        dev = next(self.parameters()).device
+        lib = self._ensure_ready(dev)
+        with torch.cuda.device(dev):
+            self._ensure_workspace(lib, dev, int(pairs), int(queries))
 
     def forward(self, samples, queries):
         if self.training:       # stage-1 training step: HIP backbone + HIP GEMMs under an autograd tape (training.py)
@@ -303,6 +339,7 @@ class COTR(nn.Module):
         qs = queries.contiguous().float()
         out = torch.empty((b, q, 2), dtype=torch.float32, device=img.device)
         with torch.cuda.device(img.device):
+            self._ensure_workspace(lib, img.device, b, q)
             _lib.check(lib.cotr_forward(self._handle, img.data_ptr(), qs.data_ptr(), b, q, out.data_ptr(),
                                         _lib.current_stream_ptr()), self._handle, 'cotr_forward')
         self._encoded_batch = b

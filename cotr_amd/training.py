@@ -134,6 +134,7 @@ def backbone_features(model, img):
     img = img.detach().contiguous().float()
     feat = torch.empty((img.shape[0] * TOK, CFEAT), dtype=torch.float32, device=img.device)
     with torch.cuda.device(img.device):
+        model._ensure_workspace(lib, img.device, img.shape[0], 1)
         _lib.check(lib.cotr_backbone(model._handle, img.data_ptr(), img.shape[0], feat.data_ptr(), _lib.current_stream_ptr()),
                    model._handle, 'cotr_backbone')
     return feat
@@ -163,6 +164,7 @@ def backbone_features_trainable(model, img):
     b = img.shape[0]
     l1 = torch.empty((b, 64, 128, 256), dtype=torch.float32, device=img.device)             # NHWC over the pair
     with torch.cuda.device(img.device):
+        model._ensure_workspace(lib, img.device, b, 1)
         _lib.check(lib.cotr_backbone_upto(model._handle, img.data_ptr(), b, 1, l1.data_ptr(), _lib.current_stream_ptr()),
                    model._handle, 'cotr_backbone_upto')
     body = model.backbone[0].body

@@ -94,8 +94,20 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
 int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, int Q, float* out,
                  cotr_stream stream);
 
-/* Bytes of handle-owned device memory after a call of that size (weights + scratch). */
+/* Bytes of device memory behind a call of that size (packed weights + encode cache + scratch). */
 int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes);
+
+/* Scratch from the CALLER's allocator ("torch allocates, passes in").  By default the encode cache and the two
+ * scratch arenas are grow-only hipMalloc'ed memory owned by the handle; growing one (a larger batch arrives) costs a
+ * hipFree + hipMalloc, i.e. a device synchronisation in the middle of the caller's stream.  With a workspace the handle
+ * carves the three regions from [ws, ws + bytes) instead (256-byte aligned `ws`, device memory, e.g. a torch uint8 tensor
+ * from the caching allocator) and never allocates or frees.  cotr_scratch_bytes(B, Q) is the size a call of that shape needs;
+ * a call that does not fit returns COTR_ERR_ARG.  keep_encode != 0: a cached encode is carried over into the new workspace
+ * (device copy on `stream`, so the old workspace must outlive the work enqueued so far; meant for a decode with more queries
+ * than the workspace was sized for - same number of pairs); otherwise, and with ws == NULL (back to handle-owned memory), it
+ * is dropped.  The packed weights (74 MB) and the 0.5 MB position table stay handle-owned. */
+int cotr_scratch_bytes(cotr_handle h, int B, int Q, size_t* bytes);
+int cotr_set_workspace(cotr_handle h, void* ws, size_t bytes, int keep_encode, cotr_stream stream);
 
 /* ---- test / profiling hooks (not needed by a binding) ------------------------------------ */
 
@@ -216,6 +228,9 @@ int cotr_set_ffn_preln(int enable);
  * of each row tile; same bits as the separate ln_reduce launch); 0 (default): two launches - the single-launch form
  * measured SLOWER (one CU has to pull the 512 KB of partials of its row tile), see DESIGN.md 4b */
 int cotr_set_ffn_tail(int enable);
+/* 1 (default): K-deep (K >= 768) small-M GEMMs / convolutions that the measured table gives to the two-stage LDS-DMA k-split
+ * kernel run on its three-stage form (two tiles of DMA in flight across the barrier, counted vmcnt); 0: two stages */
+int cotr_set_ks3(int enable);
 /* 1 (default): in the entry block of each ResNet stage the downsample convolution and conv1 (both read the block input) go
  * out as one launch at up to two pairs per pass; 0: two launches */
 int cotr_set_dual_conv(int enable);

@@ -237,6 +237,48 @@ def test_dual_conv_launch_is_bit_identical_to_two_launches():
     assert cotr_oracle.px_err(dual, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
 
 
+def test_caller_supplied_workspace():
+    """cotr_set_workspace: the library's encode cache + scratch live in the caller's (torch caching allocator's) memory.
+    Growing shapes re-carve a larger workspace; a cached encode survives the move; a workspace that is too small is an error,
+    not an overrun; NULL goes back to handle-owned memory; results do not depend on where the scratch lives."""
+    import ctypes
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    sd = synth_state_dict(0)
+    m = build_model(cotr_amd.default_args()).cuda().eval()
+    m.load_state_dict(sd)
+    img, qs = synth_inputs(2, 40, seed=23)
+    img, qs = img.cuda(), qs.cuda()
+    a = m(img[:1], qs[:1, :8])['pred_corrs'].clone()
+    assert m._ws is not None and m._ws_shape == (1, 8)
+    first_ws = m._ws.data_ptr()
+    b = m(img, qs)['pred_corrs'].clone()                       # larger B and Q: new workspace
+    assert m._ws_shape == (2, 40) and m._ws.data_ptr() != first_ws
+    assert torch.equal(m(img[:1], qs[:1, :8])['pred_corrs'], a)          # smaller call inside the larger workspace
+    m.encode(img)
+    small = m.decode(qs[:, :8]).clone()
+    _, big_q = synth_inputs(2, 3000, seed=24)
+    big = m.decode(big_q.cuda())                               # Q beyond the workspace: it grows, the cached encode moves along
+    assert m._ws_shape == (2, 3000)
+    assert torch.equal(m.decode(qs[:, :8]), small)
+    ref = cotr_oracle.cotr_forward(sd, img.cpu(), big_q[:, ::100])
+    assert cotr_oracle.px_err(big.cpu()[:, ::100], ref) < PX_BAR
+    assert cotr_oracle.px_err(b.cpu(), cotr_oracle.cotr_forward(sd, img.cpu(), qs.cpu())) < PX_BAR
+    # raw ABI: a workspace that is too small is refused with a message; NULL returns to handle-owned memory
+    tiny = torch.empty(1 << 20, dtype=torch.uint8, device='cuda')
+    off = (-tiny.data_ptr()) % 256
+    m._ws, m._ws_shape, m._encoded_batch = None, (0, 0), 0
+    assert lib.cotr_set_workspace(m._handle, ctypes.c_void_p(tiny.data_ptr() + off), (1 << 20) - 256, 0, None) == 0
+    out = torch.empty(2, 40, 2, device='cuda')
+    rc = lib.cotr_forward(m._handle, img.data_ptr(), qs.data_ptr(), 2, 40, out.data_ptr(), _lib.current_stream_ptr())
+    assert rc == -1 and b'workspace too small' in lib.cotr_last_error(m._handle)
+    assert lib.cotr_set_workspace(m._handle, None, 0, 0, None) == 0
+    rc = lib.cotr_forward(m._handle, img.data_ptr(), qs.data_ptr(), 2, 40, out.data_ptr(), _lib.current_stream_ptr())
+    assert rc == 0 and torch.equal(out, b)
+    need = ctypes.c_size_t()
+    assert lib.cotr_scratch_bytes(m._handle, 2, 40, ctypes.byref(need)) == 0 and need.value > (1 << 20)
+
+
 def test_dense_pass_shape_q131072():
     """cotr_patch_flow_exhaustive feeds q[1,131072,2] (inference_helper.py:116-127): 4 decoder chunks; a strided
     sample of it is checked against the oracle."""
@@ -289,6 +331,7 @@ def test_norm_folded_into_the_ffn_block_is_bit_identical():
     m = hip_model()
     try:
         outs = []
+        assert lib.cotr_set_attention_fusion_max_rows(0) == 0      # the experiment belongs to the six-launch layer
         for on in (0, 1):
             assert lib.cotr_set_ffn_preln(on) == 0
             outs.append(m(img.cuda(), qs.cuda())['pred_corrs'].clone())
@@ -299,6 +342,7 @@ def test_norm_folded_into_the_ffn_block_is_bit_identical():
             m.set_profiling(0)
     finally:
         lib.cotr_set_ffn_preln(0)
+        lib.cotr_set_attention_fusion_max_rows(1024)
     assert torch.equal(outs[0], outs[2])
     assert outs[1] - outs[3] == 12, (outs[1], outs[3])
 
