@@ -57,6 +57,27 @@ _PROTOS = {
     'cotr_op_ffn_block': (ctypes.c_int, [c_float_p] * 9 + [ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_ffn_chunks': (ctypes.c_int, [ctypes.c_int]),
     'cotr_op_posenc': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_train_add_rowmod': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_train_add_drop_ln_fwd': (ctypes.c_int, [c_float_p] * 7 + [ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]),
+    'cotr_train_ln_bwd_parts': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_train_ln_bwd': (ctypes.c_int, [c_float_p] * 8 + [ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]),
+    'cotr_train_dropout_fwd': (ctypes.c_int, [c_float_p, ctypes.c_size_t, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]),
+    'cotr_train_relu_drop_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p]),
+    'cotr_train_colsum_parts': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_train_colsum': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_train_transpose': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_train_gemm_tn_splits': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'cotr_train_gemm_tn': (ctypes.c_int, [c_float_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_train_head_fwd': (ctypes.c_int, [c_float_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_train_head_bwd_parts': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_train_head_bwd': (ctypes.c_int, [c_float_p] * 6 + [ctypes.c_int, ctypes.c_void_p]),
+    'cotr_train_attention_fwd': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p,
+                                                ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                                ctypes.c_uint32, ctypes.c_void_p]),
+    'cotr_train_attention_bwd': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p,
+                                                c_float_p, ctypes.c_int, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,
+                                                ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]),
     'cotr_crop_resize_pairs': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
                                               c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_dense_cycle': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_void_p]),

@@ -24,6 +24,7 @@
 
 #include "../../include/cotr_hip.h"
 #include "common.h"
+#include "train.h"
 
 int init_attention_attributes();
 void set_attention_splits(int ns);
@@ -1277,6 +1278,57 @@ int cotr_op_conv_dual_cfg(const float* x, const float* w0, const float* scale0, 
   const GemmParams p0 = conv_params(c0, x, nullptr, relu0, y0, B, Hin, Win), p1 = conv_params(c1, x, nullptr, relu1, y1, B, Hin, Win);
   return op_ret(launch_gemm_dual_cfg(GEMM_CONV, cfg, p0, p1, static_cast<hipStream_t>(stream)));
 }
+
+// ---- training step: kernels under the autograd tape of cotr_amd/training.py ---------------------------
+#define TS static_cast<hipStream_t>(stream)
+int cotr_train_add_rowmod(const float* x, const float* x2, int mod, float* y, int rows, cotr_stream stream) {
+  return op_ret(train_add_rowmod(x, x2, mod, y, rows, TS));
+}
+int cotr_train_add_drop_ln_fwd(const float* x, const float* a, const float* w, const float* b, float* s_out, float* y, float* stats,
+                               int rows, float p, uint32_t seed, cotr_stream stream) {
+  return op_ret(train_add_drop_ln_fwd(x, a, w, b, s_out, y, stats, rows, p, seed, TS));
+}
+int cotr_train_ln_bwd_parts(int rows) { return train_ln_bwd_parts(rows); }
+int cotr_train_ln_bwd(const float* dy, const float* s_in, const float* stats, const float* w, float* ds, float* da, float* part,
+                      float* dwb, int rows, float p, uint32_t seed, cotr_stream stream) {
+  return op_ret(train_ln_bwd(dy, s_in, stats, w, ds, da, part, dwb, rows, p, seed, TS));
+}
+int cotr_train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, cotr_stream stream) {
+  return op_ret(train_dropout_fwd(x, n, p, seed, TS));
+}
+int cotr_train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, float p, cotr_stream stream) {
+  return op_ret(train_relu_drop_bwd(dy, y, dx, n, p, TS));
+}
+int cotr_train_colsum_parts(int M) { return train_colsum_parts(M); }
+int cotr_train_colsum(const float* x, float* part, float* out, int M, int N, cotr_stream stream) {
+  return op_ret(train_colsum(x, part, out, M, N, TS));
+}
+int cotr_train_transpose(const float* src, float* dst, int R, int C, cotr_stream stream) {
+  return op_ret(train_transpose(src, dst, R, C, TS));
+}
+int cotr_train_gemm_tn_splits(int M, int N, int K) { return train_gemm_tn_splits(M, N, K); }
+int cotr_train_gemm_tn(const float* A, const float* B, float* part, float* out, int M, int N, int K, cotr_stream stream) {
+  return op_ret(train_gemm_tn(A, B, part, out, M, N, K, TS));
+}
+int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream) {
+  return op_ret(launch_head2(x, w, b, y, nb, nq, nq, TS));
+}
+int cotr_train_head_bwd_parts(int rows) { return train_head_bwd_parts(rows); }
+int cotr_train_head_bwd(const float* dy, const float* h, const float* w2, float* dh, float* part, float* dwb, int rows,
+                        cotr_stream stream) {
+  return op_ret(train_head_bwd(dy, h, w2, dh, part, dwb, rows, TS));
+}
+int cotr_train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
+                             int nb, int nq, float qscale, float p, uint32_t seed, cotr_stream stream) {
+  return op_ret(train_attention_fwd(q, ldq, k, ldk, v, ldv, o, ldo, lse, nb, nq, qscale, p, seed, TS));
+}
+int cotr_train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                             const float* d_o, int ldo, const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk,
+                             float* dv, int lddv, int nb, int nq, float qscale, float p, uint32_t seed, cotr_stream stream) {
+  return op_ret(train_attention_bwd(q, ldq, k, ldk, v, ldv, o, d_o, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, nb, nq, qscale, p,
+                                    seed, TS));
+}
+#undef TS
 
 // ---- engine-side input construction --------------------------------------------------
 int cotr_crop_resize_pairs(const uint8_t* img_a, int ha, int wa, const uint8_t* img_b, int hb, int wb,

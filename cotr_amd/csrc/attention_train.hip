@@ -1,0 +1,378 @@
+// Multi-head attention for the TRAINING step, forward and backward, fp32 MFMA, gfx950.
+//
+// nn.MultiheadAttention as the reference uses it (COTR/models/transformer.py:127,149-153 self-attention of the encoder,
+// :167,192-195 cross-attention of the decoder; 8 heads of 32, 512 keys): o = dropout(softmax(q k^T * hd^-0.5)) v per head.
+// The forward is the inference kernel's scheme (attention.hip: one workgroup = 32 queries x 1 head x 1 pair, its 4
+// wavefronts split the 512 keys, S^T = K Q^T so that a lane owns one query, online softmax in the log2 domain) with the
+// dropout mask applied to the probabilities after the normaliser is accumulated, and the log-sum-exp of every (query, head)
+// written out.  The backward recomputes the probabilities from it (nothing of size queries x keys is ever stored):
+//     dV = P~^T dO        dP~ = dO V^T       dP = dP~ * mask / (1-p)      dS = P * (dP - delta),  delta = rowsum(dO * O)
+//     dQ = dS K * scale   dK = dS^T (Q * scale)
+// in two deterministic kernels (no atomics): attn_bwd_dq (a workgroup per 32 queries, wavefronts split the keys, like the
+// forward) and attn_bwd_dkv (a workgroup per 32 keys, wavefronts split the query blocks).  Every matrix product is
+// v_mfma_f32_32x32x2_f32 with the operand layouts of the forward kernel: the "swapped" products keep the softmax row (or the
+// key column) lane-local, and their D registers feed the next product's B operand directly.
+#include "common.h"
+#include "train.h"
+
+#define ATT_KEYS 512
+#define ATT_HD 32
+#define LOG2E 1.44269504088896340736f
+
+namespace {
+
+__device__ __forceinline__ uint64_t mask_index(int pair, int head, int nq, int qi, int key) {
+  return (((uint64_t)(pair * 8 + head) * nq + qi) * ATT_KEYS + key);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                             int ldk, const float* __restrict__ v, int ldv, float* __restrict__ o,
+                                                             int ldo, float* __restrict__ lse, int nq, float qscale,
+                                                             uint32_t thresh, float inv_keep, uint32_t seed) {
+  constexpr int NS = 4, NBLK = ATT_KEYS / NS / 32;
+  __shared__ float lds_o[NS][16][64];
+  __shared__ float lds_m[NS][32];
+  __shared__ float lds_l[NS][32];
+  __shared__ __attribute__((aligned(16))) float lds_out[32][36];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int qtiles = gridDim.x >> 3;
+  const int head = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles;
+  const int pair = blockIdx.z;
+  const int qi = qtile * 32 + l31;
+  const bool q_ok = qi < nq;
+  const size_t qrow = (size_t)pair * nq + (q_ok ? qi : 0);
+
+  f32x4 qf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    qf[j] = *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4);
+    qf[j] *= qscale * LOG2E;
+  }
+  const int key_w = wave * (ATT_KEYS / NS);
+  const size_t key0 = (size_t)pair * ATT_KEYS + key_w;
+  const float* kg = k + (key0 + l31) * ldk + head * ATT_HD + hh * 4;
+  const float* vg = v + (key0 + 4 * hh) * ldv + head * ATT_HD + l31;
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+    f32x4 kf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kg + (size_t)kb * 32 * ldk + j * 8);
+    float vf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vf[r] = vg[(size_t)(kb * 32 + (r & 3) + 8 * (r >> 2)) * ldv];
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j][e], qf[j][e], s, 0, 0, 0);
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+      psum += s[r];                                   // the normaliser sums the UN-dropped probabilities
+    }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    if (thresh != 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key_w + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        s[r] = train_keep(seed, mask_index(pair, head, nq, q_ok ? qi : 0, key), thresh) ? s[r] * inv_keep : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], s[r], oacc, 0, 0, 0);
+  }
+  l_run += __shfl_xor(l_run, 32);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lds_o[wave][r][lane] = oacc[r];
+  if (hh == 0) {
+    lds_m[wave][l31] = m_run;
+    lds_l[wave][l31] = l_run;
+  }
+  __syncthreads();
+  float m_all = lds_m[0][l31];
+#pragma unroll
+  for (int w = 1; w < NS; ++w) m_all = fmaxf(m_all, lds_m[w][l31]);
+  float f[NS];
+  float l_all = 0.f;
+#pragma unroll
+  for (int w = 0; w < NS; ++w) {
+    f[w] = __builtin_amdgcn_exp2f(lds_m[w][l31] - m_all);
+    l_all += f[w] * lds_l[w][l31];
+  }
+  const float inv = 1.f / l_all;
+  {
+    const int r = wave;   // NS == 4: accumulator rows 4*wave .. 4*wave+3
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rr = r * 4 + i;
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NS; ++w) acc += f[w] * lds_o[w][rr][lane];
+      lds_out[l31][(rr & 3) + 8 * (rr >> 2) + 4 * hh] = acc * inv;
+    }
+  }
+  if (wave == 0 && hh == 0 && q_ok) lse[qrow * 8 + head] = m_all + __builtin_amdgcn_logf(l_all);   // v_log_f32 = log2
+  __syncthreads();
+  {
+    const int row = t >> 3, c4 = (t & 7) * 4;
+    const int qo = qtile * 32 + row;
+    if (qo < nq)
+      *reinterpret_cast<f32x4*>(o + ((size_t)pair * nq + qo) * ldo + head * ATT_HD + c4) =
+          *reinterpret_cast<const f32x4*>(&lds_out[row][c4]);
+  }
+}
+
+// delta[row][head] = sum_d dO[row][head*32 + d] * O[row][head*32 + d]: one wavefront per row, 8 lanes per head
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, int ldo,
+                                                         float* __restrict__ delta, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(o + (size_t)row * ldo + lane * 4);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(d_o + (size_t)row * ldo + lane * 4);
+  float sacc = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  sacc += __shfl_xor(sacc, 1);
+  sacc += __shfl_xor(sacc, 2);
+  sacc += __shfl_xor(sacc, 4);
+  if ((lane & 7) == 0) delta[(size_t)row * 8 + (lane >> 3)] = sacc;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// dQ: workgroup = 32 queries x head x pair, the 4 wavefronts split the keys
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                          int ldk, const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                                                          int ldo, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          float* __restrict__ dq, int lddq, int nq, float qscale, uint32_t thresh,
+                                                          float inv_keep, uint32_t seed) {
+  constexpr int NS = 4, NBLK = ATT_KEYS / NS / 32;
+  __shared__ float lds_o[NS][16][64];
+  __shared__ __attribute__((aligned(16))) float lds_out[32][36];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int qtiles = gridDim.x >> 3;
+  const int head = blockIdx.x / qtiles, qtile = blockIdx.x % qtiles;
+  const int pair = blockIdx.z;
+  const int qi = qtile * 32 + l31;
+  const bool q_ok = qi < nq;
+  const size_t qrow = (size_t)pair * nq + (q_ok ? qi : 0);
+  f32x4 qf[4], dof[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    qf[j] = *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4);
+    qf[j] *= qscale * LOG2E;
+    dof[j] = *reinterpret_cast<const f32x4*>(d_o + qrow * ldo + head * ATT_HD + j * 8 + hh * 4);
+  }
+  const float lse_q = lse[qrow * 8 + head], delta_q = delta[qrow * 8 + head];
+  const int key_w = wave * (ATT_KEYS / NS);
+  const size_t key0 = (size_t)pair * ATT_KEYS + key_w;
+  const float* kg = k + (key0 + l31) * ldk + head * ATT_HD + hh * 4;       // A operand of S^T: lane = key
+  const float* vga = v + (key0 + l31) * ldv + head * ATT_HD + hh * 4;      // A operand of dP^T = V dO^T: lane = key
+  const float* kt = k + (key0 + 4 * hh) * ldk + head * ATT_HD + l31;       // A operand of dQ^T = K^T dS^T: lane = head dim
+  f32x16 dqacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NBLK; ++kb) {
+    f32x4 kf[4], vf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kf[j] = *reinterpret_cast<const f32x4*>(kg + (size_t)kb * 32 * ldk + j * 8);
+      vf[j] = *reinterpret_cast<const f32x4*>(vga + (size_t)kb * 32 * ldv + j * 8);
+    }
+    float ktf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ktf[r] = kt[(size_t)(kb * 32 + (r & 3) + 8 * (r >> 2)) * ldk];
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j][e], qf[j][e], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j][e], dof[j][e], dp, 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(s[r] - lse_q);
+      float g = dp[r];
+      if (thresh != 0) {
+        const int key = key_w + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        g = train_keep(seed, mask_index(pair, head, nq, q_ok ? qi : 0, key), thresh) ? g * inv_keep : 0.f;
+      }
+      s[r] = q_ok ? p * (g - delta_q) : 0.f;          // dS[q][key]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ktf[r], s[r], dqacc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lds_o[wave][r][lane] = dqacc[r];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = wave * 4 + i;
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) acc += lds_o[w][rr][lane];
+    lds_out[l31][(rr & 3) + 8 * (rr >> 2) + 4 * hh] = acc * qscale;   // q_eff = q * qscale
+  }
+  __syncthreads();
+  {
+    const int row = t >> 3, c4 = (t & 7) * 4;
+    const int qo = qtile * 32 + row;
+    if (qo < nq)
+      *reinterpret_cast<f32x4*>(dq + ((size_t)pair * nq + qo) * lddq + head * ATT_HD + c4) =
+          *reinterpret_cast<const f32x4*>(&lds_out[row][c4]);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// dK, dV: workgroup = 32 keys x head x pair, the 4 wavefronts take every 4th block of 32 queries
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                           int ldk, const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                                                           int ldo, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, int nq,
+                                                           float qscale, uint32_t thresh, float inv_keep, uint32_t seed) {
+  constexpr int NS = 4;
+  __shared__ float lds_k[NS][16][64];
+  __shared__ float lds_v[NS][16][64];
+  __shared__ __attribute__((aligned(16))) float lds_out[2][32][36];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.x >> 4, ktile = blockIdx.x & 15;     // 16 key tiles of 32
+  const int pair = blockIdx.z;
+  const int kj = ktile * 32 + l31;
+  const size_t krow = (size_t)pair * ATT_KEYS + kj;
+  f32x4 kfb[4], vfb[4];                                          // B operands: lane = key
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    kfb[j] = *reinterpret_cast<const f32x4*>(k + krow * ldk + head * ATT_HD + j * 8 + hh * 4);
+    vfb[j] = *reinterpret_cast<const f32x4*>(v + krow * ldv + head * ATT_HD + j * 8 + hh * 4);
+  }
+  f32x16 dkacc, dvacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dkacc[r] = dvacc[r] = 0.f;
+  const int nqb = (nq + 31) / 32;
+  for (int qb = wave; qb < nqb; qb += NS) {
+    const int qa = qb * 32 + l31;                                // A-operand row of this lane (S^T, dP^T products)
+    const size_t qa_row = (size_t)pair * nq + (qa < nq ? qa : 0);
+    f32x4 qaf[4], doaf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qaf[j] = *reinterpret_cast<const f32x4*>(q + qa_row * ldq + head * ATT_HD + j * 8 + hh * 4);
+      qaf[j] *= qscale * LOG2E;
+      doaf[j] = *reinterpret_cast<const f32x4*>(d_o + qa_row * ldo + head * ATT_HD + j * 8 + hh * 4);
+    }
+    // rows of the D registers: query qr(r) = qb*32 + (r&3) + 8*(r>>2) + 4*hh
+    float qtf[16], dotf[16], lse_r[16], del_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const size_t row = (size_t)pair * nq + (qr < nq ? qr : 0);
+      qtf[r] = q[row * ldq + head * ATT_HD + l31] * qscale;      // A operand of dK^T = Q^T dS: lane = head dim
+      dotf[r] = d_o[row * ldo + head * ATT_HD + l31];            // A operand of dV^T = dO^T P~
+      lse_r[r] = lse[row * 8 + head];
+      del_r[r] = delta[row * 8 + head];
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qaf[j][e], kfb[j][e], s, 0, 0, 0);     // S[q][key], lane = key
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(doaf[j][e], vfb[j][e], dp, 0, 0, 0);  // dP~[q][key]
+      }
+    f32x16 pt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const bool ok = qr < nq;
+      const float p = ok ? __builtin_amdgcn_exp2f(s[r] - lse_r[r]) : 0.f;
+      float keep = 1.f;
+      if (thresh != 0) keep = train_keep(seed, mask_index(pair, head, nq, ok ? qr : 0, kj), thresh) ? inv_keep : 0.f;
+      pt[r] = p * keep;                                          // P~[q][key]
+      s[r] = p * (dp[r] * keep - del_r[r]);                      // dS[q][key]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dvacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dotf[r], pt[r], dvacc, 0, 0, 0);
+      dkacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qtf[r], s[r], dkacc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    lds_k[wave][r][lane] = dkacc[r];
+    lds_v[wave][r][lane] = dvacc[r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = wave * 4 + i;
+    float ak = 0.f, av = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+      ak += lds_k[w][rr][lane];
+      av += lds_v[w][rr][lane];
+    }
+    const int d = (rr & 3) + 8 * (rr >> 2) + 4 * hh;            // D rows = head dim, column (lane & 31) = key
+    lds_out[0][l31][d] = ak;
+    lds_out[1][l31][d] = av;
+  }
+  __syncthreads();
+  {
+    const int row = t >> 3, c4 = (t & 7) * 4;
+    const size_t orow = (size_t)pair * ATT_KEYS + ktile * 32 + row;
+    *reinterpret_cast<f32x4*>(dk + orow * lddk + head * ATT_HD + c4) = *reinterpret_cast<const f32x4*>(&lds_out[0][row][c4]);
+    *reinterpret_cast<f32x4*>(dv + orow * lddv + head * ATT_HD + c4) = *reinterpret_cast<const f32x4*>(&lds_out[1][row][c4]);
+  }
+}
+
+}  // namespace
+
+int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
+                        int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s) {
+  if (nb <= 0 || nq <= 0) return 0;
+  if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return -1;
+  dim3 grid(((nq + 31) / 32) * 8, 1, nb);
+  hipLaunchKernelGGL(attn_train_fwd_kernel, grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, lse, nq, qscale, train_thresh(p),
+                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, const float* d_o,
+                        int ldo, const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                        int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s) {
+  if (nb <= 0 || nq <= 0) return 0;
+  if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || lddq % 4 || lddk % 4 || lddv % 4) return -1;
+  const int rows = nb * nq;
+  const uint32_t thresh = train_thresh(p);
+  const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, o, d_o, ldo, delta, rows);
+  if (hipGetLastError() != hipSuccess) return -2;
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((nq + 31) / 32) * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse,
+                     delta, dq, lddq, nq, qscale, thresh, inv_keep, seed);
+  if (hipGetLastError() != hipSuccess) return -2;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(16 * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dk,
+                     lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,50 @@
+// Training-step kernels (train.hip, attention_train.hip): launch helpers and the counter-based dropout mask shared by the
+// forward and backward kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// keep(element) = hash(seed, index) >= p * 2^32: a 64 -> 32 bit integer mixer (two multiply / xor-shift rounds over both
+// words of the index); the same (seed, index) gives the same decision in the forward and in the backward kernel.
+__device__ __forceinline__ bool train_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
+  uint32_t x = (uint32_t)idx ^ (seed * 0x9E3779B9u);
+  const uint32_t hi = (uint32_t)(idx >> 32) ^ seed;
+  x ^= hi * 0x85EBCA6Bu + 0xC2B2AE35u;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x >= thresh;
+}
+static inline uint32_t train_thresh(float p) {
+  if (!(p > 0.f)) return 0u;
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+}
+
+int train_add_drop_ln_fwd(const float* x, const float* a, const float* w, const float* b, float* s_out, float* y, float* stats,
+                          int rows, float p, uint32_t seed, hipStream_t s);
+int train_ln_bwd_parts(int rows);
+int train_ln_bwd(const float* dy, const float* s_in, const float* stats, const float* w, float* ds, float* da, float* part,
+                 float* dwb, int rows, float p, uint32_t seed, hipStream_t s);
+int train_add_rowmod(const float* x, const float* x2, int mod, float* y, int rows, hipStream_t s);
+int train_sum_parts(const float* part, int nparts, size_t numel, float* out, hipStream_t s);
+int train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, hipStream_t s);
+int train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, float p, hipStream_t s);
+int train_colsum_parts(int M);
+int train_colsum(const float* x, float* part, float* out, int M, int N, hipStream_t s);
+int train_transpose(const float* src, float* dst, int R, int C, hipStream_t s);
+int train_gemm_tn_splits(int M, int N, int K);
+int train_gemm_tn(const float* A, const float* B, float* part, float* out, int M, int N, int K, hipStream_t s);
+int train_head_bwd_parts(int rows);
+int train_head_bwd(const float* dy, const float* h, const float* w2, float* dh, float* part, float* dwb, int rows, hipStream_t s);
+
+// attention_train.hip: softmax(q k^T * qscale) with dropout on the probabilities; q [nb*nq][ldq], k [nb*512][ldk], v [nb*512][ldv]
+// (8 heads x 32); lse [nb*nq][8] = log2-domain log-sum-exp of the scaled scores (for the backward)
+int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
+                        int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s);
+// dq [nb*nq][lddq], dk [nb*512][lddk], dv [nb*512][lddv]; delta [nb*nq][8] scratch (rowsum(dO * O) per head); o / d_o share ldo
+int train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, const float* d_o,
+                        int ldo, const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
+                        int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s);

@@ -1,0 +1,433 @@
+// Kernels of the TRAINING step (COTR/trainers/cotr_trainer.py:118-150 on COTR/models/transformer.py
+// with dropout active), fp32, gfx950.  The contractions of the forward pass reuse the inference GEMM kernels (gemm.hip); this
+// file holds what only training needs:
+//   add_drop_ln_fwd / ln_bwd      y = LayerNorm(x + dropout(a)) of every sub-layer (transformer.py:154-158,196-201) and its
+//                                 backward (dx, da, dgamma, dbeta); plain LayerNorm with x == nullptr, p == 0
+//   dropout_fwd / relu_drop_bwd   dropout(relu(linear1(x))) of the feed-forward block (:156,199)
+//   colsum / sum_parts            bias gradients and every other fixed-order cross-workgroup reduction (no atomics:
+//                                 a training step is bit-repeatable)
+//   gemm_tn                       dW = dY^T . X with both operands row-major (contraction over the strided row index),
+//                                 split over M, partial products summed in a fixed order
+//   transpose                     W -> W^T once per optimiser step for dX = dY . W on the inference GEMM kernels
+//   head_bwd                      backward of the 256 -> 2 output layer (position_encoding.py:23-26)
+// Attention forward (with dropout on the probabilities and the log-sum-exp saved) and backward live in attention_train.hip.
+//
+// Dropout masks are counter-based: keep(element) = hash(seed, element index) >= p * 2^32.  The backward kernels recompute
+// them from the same (seed, index), nothing is stored.  The masks are not torch's (no parity requirement on a random mask;
+// with p = 0 every kernel is exact and that is what the goldens pin).
+#include "common.h"
+#include "train.h"
+
+namespace {
+
+__device__ __forceinline__ float tr_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// y = LayerNorm(s), s = x + dropout(a)   (x may be nullptr: s = dropout(a));  one wavefront per row of 256, one float4 per
+// lane, two-pass statistics like layernorm_kernel (pointwise.hip).  s and (mean, rstd) are kept for the backward.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              float* __restrict__ s_out, float* __restrict__ y,
+                                                              float* __restrict__ stats, int rows, uint32_t thresh, float inv_keep,
+                                                              uint32_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t base = (size_t)row * 256 + lane * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(a + base);
+  if (thresh != 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = train_keep(seed, base + e, thresh) ? v[e] * inv_keep : 0.f;
+  }
+  if (x != nullptr) v += *reinterpret_cast<const f32x4*>(x + base);
+  const float mean = tr_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+  const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+  const float var = tr_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+  const float rstd = 1.f / sqrtf(var + 1e-5f);
+  const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
+  const f32x4 bb = *reinterpret_cast<const f32x4*>(b + lane * 4);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = d[e] * rstd * ww[e] + bb[e];
+  *reinterpret_cast<f32x4*>(y + base) = o;
+  if (s_out != nullptr) *reinterpret_cast<f32x4*>(s_out + base) = v;
+  if (lane == 0) {
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+  }
+}
+
+// Backward of the above: with xhat = (s - mean) * rstd and g = dy * gamma,
+//   ds = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat))       (= dx; da = ds * mask / (1 - p))
+//   dgamma = sum_rows dy * xhat,  dbeta = sum_rows dy           (per-workgroup partial sums, finished by sum_parts)
+// A workgroup owns rows_per_wg consecutive rows (a wavefront every 4th of them); the column sums stay in registers (lane =
+// 4 channels) and are combined across the 4 wavefronts through LDS in a fixed order.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                     const float* __restrict__ stats, const float* __restrict__ w,
+                                                     float* __restrict__ ds, float* __restrict__ da, float* __restrict__ part,
+                                                     int rows, int rows_per_wg, uint32_t thresh, float inv_keep, uint32_t seed) {
+  __shared__ __attribute__((aligned(16))) float red[2][4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
+  f32x4 gw = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int i = wave; i < rows_per_wg; i += 4) {
+    const int row = r0 + i;
+    if (row >= rows) break;
+    const size_t base = (size_t)row * 256 + lane * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dy + base);
+    const f32x4 sv = *reinterpret_cast<const f32x4*>(s + base);
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    f32x4 xh, gg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      xh[e] = (sv[e] - mean) * rstd;
+      gg[e] = g[e] * ww[e];
+      gw[e] += g[e] * xh[e];
+      gb[e] += g[e];
+    }
+    const float m1 = tr_wave_sum(gg[0] + gg[1] + gg[2] + gg[3]) * (1.f / 256.f);
+    const float m2 = tr_wave_sum(gg[0] * xh[0] + gg[1] * xh[1] + gg[2] * xh[2] + gg[3] * xh[3]) * (1.f / 256.f);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = rstd * (gg[e] - m1 - xh[e] * m2);
+    *reinterpret_cast<f32x4*>(ds + base) = o;
+    if (da != nullptr) {
+      if (thresh != 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = train_keep(seed, base + e, thresh) ? o[e] * inv_keep : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(da + base) = o;
+    }
+  }
+  *reinterpret_cast<f32x4*>(&red[0][wave][lane * 4]) = gw;
+  *reinterpret_cast<f32x4*>(&red[1][wave][lane * 4]) = gb;
+  __syncthreads();
+  const int c = threadIdx.x;   // 256 threads = 256 channels
+  float sw = 0.f, sb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sw += red[0][k][c];
+    sb += red[1][k][c];
+  }
+  part[(size_t)blockIdx.x * 512 + c] = sw;          // [workgroup][dgamma 256 | dbeta 256]
+  part[(size_t)blockIdx.x * 512 + 256 + c] = sb;
+}
+
+// out[i] = sum_p part[p][i], p in order (deterministic)
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int nparts, size_t numel,
+                                                        float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= numel) return;
+  float acc = 0.f;
+  int p = 0;
+  for (; p + 8 <= nparts; p += 8) {   // independent loads first, adds in order afterwards
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = part[(size_t)(p + k) * numel + i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += t[k];
+  }
+  for (; p < nparts; ++p) acc += part[(size_t)p * numel + i];
+  out[i] = acc;
+}
+
+// y[m][:] = x[m][:] + x2[m % mod][:] over rows of 256 (mod == 0: x2 has one row per row of x): src + pos, tgt + query_pos
+__global__ __launch_bounds__(256) void add_rowmod_kernel(const float* __restrict__ x, const float* __restrict__ x2, int mod,
+                                                         float* __restrict__ y, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int r2 = mod ? row % mod : row;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(x + (size_t)row * 256 + lane * 4);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(x2 + (size_t)r2 * 256 + lane * 4);
+  *reinterpret_cast<f32x4*>(y + (size_t)row * 256 + lane * 4) = a + b;
+}
+
+// x *= mask / (1 - p), element index = offset of the element in x
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(float* __restrict__ x, size_t n4, uint32_t thresh, float inv_keep,
+                                                          uint32_t seed) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = *reinterpret_cast<f32x4*>(x + i * 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = train_keep(seed, i * 4 + e, thresh) ? v[e] * inv_keep : 0.f;
+  *reinterpret_cast<f32x4*>(x + i * 4) = v;
+}
+
+// backward of y = dropout(relu(h)): dh = y > 0 ? dy / (1 - p) : 0 (a dropped or non-positive element has y == 0; torch's relu
+// backward is (result > 0) as well); p == 0: plain relu backward
+__global__ __launch_bounds__(256) void relu_drop_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            float* __restrict__ dx, size_t n4, float inv_keep) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+  const f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? g[e] * inv_keep : 0.f;
+  *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+}
+
+// part[wg][n] = sum over the workgroup's rows of x[row][n]  (bias gradients); N <= 4096, N % 4 == 0
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, int M, int N,
+                                                     int rows_per_wg) {
+  const int r0 = blockIdx.x * rows_per_wg;
+  const int r1 = (r0 + rows_per_wg < M) ? r0 + rows_per_wg : M;
+  for (int c = threadIdx.x * 4; c < N; c += 1024) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) acc += *reinterpret_cast<const f32x4*>(x + (size_t)r * N + c);
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.x * N + c) = acc;
+  }
+}
+
+// dst[C][R] = src[R][C]^T through a 32 x 33 LDS tile (coalesced both ways)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < R) dst[(size_t)c * R + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// part[split][n][k] = sum_{m in split} A[m][n] * B[m][k]:  dW = dY^T . X with A = dY [M][N], B = X [M][K] both ROW-major (the
+// contraction index m is the strided one: no operand is transposed).  Workgroup = 4 wavefronts = 64 x 64 output tile (each a
+// 32 x 32 block of v_mfma_f32_32x32x2_f32), walking its share of the rows 32 at a time through LDS: a fragment is one dword
+// per lane per MFMA (lane = output row / column, the two halves of the wavefront = the two rows of the K = 2 step), read
+// with ds_read_b32 at consecutive addresses (conflict-free).  Rows past M are zero-filled.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      float* __restrict__ part, int M, int N, int K, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float As[32][68];
+  __shared__ __attribute__((aligned(16))) float Bs[32][68];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int tiles_k = K / 64;
+  const int n0 = (blockIdx.x / tiles_k) * 64, k0 = (blockIdx.x % tiles_k) * 64;
+  const int split = blockIdx.y;
+  const int m_begin = split * rows_per_split;
+  const int m_end = (m_begin + rows_per_split < M) ? m_begin + rows_per_split : M;
+  const int wn = wave >> 1, wk = wave & 1;
+  // staging: thread -> (row t >> 4 (+16), float4 column (t & 15) * 4) of the 32 x 64 tile
+  const int sr = t >> 4, sc = (t & 15) * 4;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x4 ra[2], rb[2];
+  auto load = [&](int m) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m + sr + 16 * i;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ra[i] = row < m_end ? *reinterpret_cast<const f32x4*>(A + (size_t)row * N + n0 + sc) : z;
+      rb[i] = row < m_end ? *reinterpret_cast<const f32x4*>(B + (size_t)row * K + k0 + sc) : z;
+    }
+  };
+  load(m_begin);
+  for (int m = m_begin; m < m_end; m += 32) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(&As[sr + 16 * i][sc]) = ra[i];
+      *reinterpret_cast<f32x4*>(&Bs[sr + 16 * i][sc]) = rb[i];
+    }
+    __syncthreads();
+    if (m + 32 < m_end) load(m + 32);
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const float a = As[2 * s2 + hh][wn * 32 + l31];   // A operand: lane i = output row n, k = row 2*s2 + hh of the chunk
+      const float b = Bs[2 * s2 + hh][wk * 32 + l31];   // B operand: lane j = output column k
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  // D[i][j]: column j = lane & 31 (k), rows i = (r&3) + 8*(r>>2) + 4*hh (n)
+  float* out = part + (size_t)split * N * K;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    out[(size_t)n * K + k0 + wk * 32 + l31] = acc[r];
+  }
+}
+
+// backward of pred = h . W2^T + b2 (W2 [2][256]): dh[r][c] = dy[r][0] * W2[0][c] + dy[r][1] * W2[1][c];
+// part[wg][0..511] = per-workgroup sums of dy[r][j] * h[r][c] (j = 0, 1), part[wg][512..513] = sums of dy[r][j]
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ hin,
+                                                       const float* __restrict__ w2, float* __restrict__ dh,
+                                                       float* __restrict__ part, int rows, int rows_per_wg) {
+  __shared__ float red[4][2][256];
+  __shared__ float redb[4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const f32x4 w0 = *reinterpret_cast<const f32x4*>(w2 + lane * 4);
+  const f32x4 w1 = *reinterpret_cast<const f32x4*>(w2 + 256 + lane * 4);
+  f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f};
+  float b0 = 0.f, b1 = 0.f;
+  const int r0 = blockIdx.x * rows_per_wg;
+  for (int i = wave; i < rows_per_wg; i += 4) {
+    const int row = r0 + i;
+    if (row >= rows) break;
+    const float d0 = dy[2 * row], d1 = dy[2 * row + 1];
+    const f32x4 h = *reinterpret_cast<const f32x4*>(hin + (size_t)row * 256 + lane * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = d0 * w0[e] + d1 * w1[e];
+      g0[e] += d0 * h[e];
+      g1[e] += d1 * h[e];
+    }
+    *reinterpret_cast<f32x4*>(dh + (size_t)row * 256 + lane * 4) = o;
+    b0 += d0;
+    b1 += d1;
+  }
+  *reinterpret_cast<f32x4*>(&red[wave][0][lane * 4]) = g0;
+  *reinterpret_cast<f32x4*>(&red[wave][1][lane * 4]) = g1;
+  if (lane == 0) {
+    redb[wave][0] = b0;
+    redb[wave][1] = b1;
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    s0 += red[k][0][c];
+    s1 += red[k][1][c];
+  }
+  float* p = part + (size_t)blockIdx.x * 514;
+  p[c] = s0;
+  p[256 + c] = s1;
+  if (c < 2) p[512 + c] = redb[0][c] + redb[1][c] + redb[2][c] + redb[3][c];
+}
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
+
+int train_add_drop_ln_fwd(const float* x, const float* a, const float* w, const float* b, float* s_out, float* y, float* stats,
+                          int rows, float p, uint32_t seed, hipStream_t s) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, a, w, b, s_out, y, stats, rows,
+                     train_thresh(p), p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+  return LAUNCH_OK();
+}
+
+int train_ln_bwd_parts(int rows) {
+  int per = (rows + 511) / 512;
+  per = (per + 3) / 4 * 4;
+  return (rows + per - 1) / per;
+}
+
+// ds (and da = ds * mask / (1 - p) when da != nullptr); dwb [512] = dgamma | dbeta; part holds train_ln_bwd_parts(rows) * 512
+int train_ln_bwd(const float* dy, const float* s_in, const float* stats, const float* w, float* ds, float* da, float* part,
+                 float* dwb, int rows, float p, uint32_t seed, hipStream_t s) {
+  if (rows <= 0) return 0;
+  int per = (rows + 511) / 512;
+  per = (per + 3) / 4 * 4;
+  const int nwg = (rows + per - 1) / per;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nwg), dim3(256), 0, s, dy, s_in, stats, w, ds, da, part, rows, per, train_thresh(p),
+                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+  if (hipGetLastError() != hipSuccess) return -2;
+  return train_sum_parts(part, nwg, (size_t)512, dwb, s);
+}
+
+int train_add_rowmod(const float* x, const float* x2, int mod, float* y, int rows, hipStream_t s) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(add_rowmod_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, x2, mod, y, rows);
+  return LAUNCH_OK();
+}
+
+int train_sum_parts(const float* part, int nparts, size_t numel, float* out, hipStream_t s) {
+  if (numel == 0) return 0;
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, s, part, nparts, numel, out);
+  return LAUNCH_OK();
+}
+
+int train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, hipStream_t s) {
+  if (n == 0 || p <= 0.f) return 0;
+  if (n % 4) return -1;
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, n / 4, train_thresh(p),
+                     1.f / (1.f - p), seed);
+  return LAUNCH_OK();
+}
+
+int train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, float p, hipStream_t s) {
+  if (n == 0) return 0;
+  if (n % 4) return -1;
+  hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dy, y, dx, n / 4,
+                     p > 0.f ? 1.f / (1.f - p) : 1.f);
+  return LAUNCH_OK();
+}
+
+int train_colsum_parts(int M) {
+  const int per = (M + 255) / 256;
+  return (M + per - 1) / per;
+}
+
+int train_colsum(const float* x, float* part, float* out, int M, int N, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  if (N % 4 || N > 4096) return -1;
+  const int per = (M + 255) / 256;
+  const int nwg = (M + per - 1) / per;
+  hipLaunchKernelGGL(colsum_kernel, dim3(nwg), dim3(256), 0, s, x, part, M, N, per);
+  if (hipGetLastError() != hipSuccess) return -2;
+  return train_sum_parts(part, nwg, (size_t)N, out, s);
+}
+
+int train_transpose(const float* src, float* dst, int R, int C, hipStream_t s) {
+  if (R <= 0 || C <= 0) return 0;
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, dst, R, C);
+  return LAUNCH_OK();
+}
+
+int train_gemm_tn_splits(int M, int N, int K) {
+  const int tiles = (N / 64) * (K / 64);
+  int splits = (768 + tiles - 1) / tiles;                 // ~3 workgroups per CU in total
+  const int max_splits = (M + 63) / 64;                   // at least 64 rows per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+// out[N][K] = A[M][N]^T . B[M][K]; part holds train_gemm_tn_splits(M, N, K) * N * K floats
+int train_gemm_tn(const float* A, const float* B, float* part, float* out, int M, int N, int K, hipStream_t s) {
+  if (M <= 0) return -1;
+  if (N % 64 || K % 64) return -1;
+  const int splits = train_gemm_tn_splits(M, N, K);
+  int per = (M + splits - 1) / splits;
+  per = (per + 31) / 32 * 32;
+  const int nsplit = (M + per - 1) / per;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((N / 64) * (K / 64), nsplit), dim3(256), 0, s, A, B, part, M, N, K, per);
+  if (hipGetLastError() != hipSuccess) return -2;
+  return train_sum_parts(part, nsplit, (size_t)N * K, out, s);
+}
+
+int train_head_bwd_parts(int rows) {
+  int per = (rows + 255) / 256;
+  per = (per + 3) / 4 * 4;
+  return (rows + per - 1) / per;
+}
+
+// dh [rows][256]; dw2 [2][256] and db2 [2] contiguous in `dwb` (514 floats)
+int train_head_bwd(const float* dy, const float* h, const float* w2, float* dh, float* part, float* dwb, int rows, hipStream_t s) {
+  if (rows <= 0) return 0;
+  int per = (rows + 255) / 256;
+  per = (per + 3) / 4 * 4;
+  const int nwg = (rows + per - 1) / per;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), 0, s, dy, h, w2, dh, part, rows, per);
+  if (hipGetLastError() != hipSuccess) return -2;
+  return train_sum_parts(part, nwg, (size_t)514, dwb, s);
+}

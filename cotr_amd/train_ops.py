@@ -1,0 +1,310 @@
+"""torch.autograd Functions of the training step whose forward AND backward are hand-written HIP kernels
+(``cotr_amd/csrc/train.hip``, ``attention_train.hip`` and the inference GEMM kernels), called through the C ABI of
+``include/cotr_hip.h``.  PyTorch contributes the autograd tape, tensor allocation, the loss and the optimiser - no arithmetic.
+
+Every Function maps to a piece of the reference's training forward (COTR/models/transformer.py with dropout active,
+COTR/models/position_encoding.py:23-26), named in its docstring.  Dropout masks are counter-based (``train.h``): a site
+gets a fresh 32-bit seed from ``next_seed()`` in the forward and hands the same seed to its backward kernel, which
+recomputes the mask.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _P(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _sp():
+    return _lib.current_stream_ptr()
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise _lib.CotrHipError(f'{what} failed (code {rc})')
+
+
+def _empty(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+# ---- dropout seeds ----------------------------------------------------------------------------------------------------
+_seed = {'base': None, 'count': 0}
+
+
+def reseed(base=None):
+    """Start a new deterministic sequence of dropout seeds (default: torch's initial seed)."""
+    _seed['base'] = (torch.initial_seed() if base is None else int(base)) & 0xFFFFFFFF
+    _seed['count'] = 0
+
+
+def next_seed():
+    if _seed['base'] is None:
+        reseed()
+    _seed['count'] += 1
+    x = (_seed['base'] * 0x9E3779B1 + _seed['count'] * 0x85EBCA77) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 12
+    return x
+
+
+# ---- contractions ------------------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, relu=False):
+    """y[M,N] = relu?(a[M,K] . w[N,K]^T + bias) on the library's fp32-MFMA GEMM kernels."""
+    lib = _lib.load_library()
+    m, k = a.shape
+    n = w.shape[0]
+    assert a.is_contiguous() and w.is_contiguous() and w.shape[1] == k and k % 32 == 0 and n % 16 == 0, (a.shape, w.shape)
+    y = _empty((m, n), a)
+    if m:
+        with torch.cuda.device(a.device):
+            _chk(lib.cotr_op_linear(_P(a), None, 0, _P(w), None, _P(bias), None, int(relu), _P(y), m, n, k, _sp()),
+                 f'cotr_op_linear {m}x{n}x{k}')
+    return y
+
+
+def gemm_tn(dy, x, out):
+    """out[N,K] = dy[M,N]^T . x[M,K] (dW), operands row-major as they are: split over M, fixed-order sum of the partials."""
+    lib = _lib.load_library()
+    m, n = dy.shape
+    k = x.shape[1]
+    assert dy.is_contiguous() and x.is_contiguous() and out.is_contiguous() and x.shape[0] == m and out.shape == (n, k)
+    part = _empty((lib.cotr_train_gemm_tn_splits(m, n, k) * n * k,), dy)
+    with torch.cuda.device(dy.device):
+        _chk(lib.cotr_train_gemm_tn(_P(dy), _P(x), _P(part), _P(out), m, n, k, _sp()), f'cotr_train_gemm_tn {m}x{n}x{k}')
+    return out
+
+
+def colsum(x, out):
+    lib = _lib.load_library()
+    m, n = x.shape
+    part = _empty((lib.cotr_train_colsum_parts(m) * n,), x)
+    with torch.cuda.device(x.device):
+        _chk(lib.cotr_train_colsum(_P(x), _P(part), _P(out), m, n, _sp()), 'cotr_train_colsum')
+    return out
+
+
+_wt_cache = {}   # id(base tensor) -> (weakref to it, {(storage offset, shape): (version, W^T)})
+
+
+def weight_t(w):
+    """w[N,K] -> contiguous w^T [K,N] by the HIP transpose kernel, cached until the parameter changes (optimiser step).
+    The cache hangs on the identity of the parameter object (weak reference), not on its address: torch's allocator hands
+    the address of a freed model's weights to the next model."""
+    import weakref
+    base = w._base if w._base is not None else w
+    entry = _wt_cache.get(id(base))
+    if entry is None or entry[0]() is not base:
+        for k in [k for k, e in _wt_cache.items() if e[0]() is None]:      # drop entries of dead parameters
+            del _wt_cache[k]
+        entry = (weakref.ref(base), {})
+        _wt_cache[id(base)] = entry
+    key = (w.storage_offset(), tuple(w.shape))
+    hit = entry[1].get(key)
+    if hit is not None and hit[0] == base._version:
+        return hit[1]
+    lib = _lib.load_library()
+    n, k = w.shape
+    wt = _empty((k, n), w)
+    with torch.cuda.device(w.device):
+        _chk(lib.cotr_train_transpose(_P(w.detach()), _P(wt), n, k, _sp()), 'cotr_train_transpose')
+    entry[1][key] = (base._version, wt)
+    return wt
+
+
+class Proj(torch.autograd.Function):
+    """Row slices of ONE weight matrix applied to (possibly different) inputs: y_i = relu?(x_i . W[lo_i:hi_i]^T + b[lo_i:hi_i]),
+    optionally followed by dropout.  nn.Linear is the one-slice case; the packed in_proj of nn.MultiheadAttention
+    (transformer.py:149-153 with q = k = src + pos, v = src; :192-195 with q = tgt + query_pos, k = memory + pos, v = memory)
+    is the two / three-slice case.  Backward: dx_i = dy_i . W[lo:hi] (GEMM on the cached W^T slice), dW[lo:hi] = dy_i^T . x_i
+    (gemm_tn, written straight into its rows of the full-size gradient), db[lo:hi] = column sums."""
+
+    @staticmethod
+    def forward(ctx, w, b, ranges, relu, p, *xs):
+        assert len(xs) == len(ranges) and (not relu or len(xs) == 1)
+        xs = [x.contiguous() for x in xs]
+        wd, bd = w.detach(), None if b is None else b.detach()
+        ys = []
+        for x, (lo, hi) in zip(xs, ranges):
+            ys.append(gemm(x, wd[lo:hi], None if bd is None else bd[lo:hi], relu))
+        seed = 0
+        if relu and p > 0:
+            seed = next_seed()
+            lib = _lib.load_library()
+            with torch.cuda.device(ys[0].device):
+                _chk(lib.cotr_train_dropout_fwd(_P(ys[0]), ys[0].numel(), float(p), seed, _sp()), 'cotr_train_dropout_fwd')
+        ctx.ranges, ctx.relu, ctx.p, ctx.has_bias = ranges, relu, float(p), b is not None
+        ctx.save_for_backward(w, *xs, *(ys if relu else []))
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved = ctx.saved_tensors
+        w = saved[0]
+        n = len(ctx.ranges)
+        xs = saved[1:1 + n]
+        lib = _lib.load_library()
+        covered = sum(hi - lo for lo, hi in ctx.ranges) == w.shape[0]
+        need_w = ctx.needs_input_grad[0]
+        dw = (torch.empty_like(w) if covered else torch.zeros_like(w)) if need_w else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = _empty((w.shape[0],), w) if covered else torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
+        dxs = []
+        for i, ((lo, hi), x, dy) in enumerate(zip(ctx.ranges, xs, dys)):
+            if dy is None:      # an output nobody used
+                dy = torch.zeros((x.shape[0], hi - lo), dtype=torch.float32, device=x.device)
+            dy = dy.contiguous()
+            if ctx.relu:
+                y = saved[1 + n]
+                dh = torch.empty_like(dy)
+                with torch.cuda.device(dy.device):
+                    _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dh), dy.numel(), ctx.p, _sp()), 'cotr_train_relu_drop_bwd')
+                dy = dh
+            dxs.append(gemm(dy, weight_t(w[lo:hi])) if ctx.needs_input_grad[5 + i] else None)
+            if dw is not None:
+                gemm_tn(dy, x, dw[lo:hi])
+            if db is not None:
+                colsum(dy, db[lo:hi])
+        return (dw, db, None, None, None, *dxs)
+
+
+def linear(x, w, b=None, relu=False, p=0.0):
+    return Proj.apply(w, b, ((0, w.shape[0]),), relu, p, x)[0]
+
+
+class AddRows(torch.autograd.Function):
+    """x + x2[row % mod] over rows of 256 (mod == 0: same row): ``src + pos`` / ``memory + pos`` with the constant image
+    position table, ``tgt + query_pos`` with the (no-grad) query encoding.  Gradient: identity to x."""
+
+    @staticmethod
+    def forward(ctx, x, x2, mod):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _chk(_lib.load_library().cotr_train_add_rowmod(_P(x), _P(x2), int(mod), _P(y), x.shape[0], _sp()), 'cotr_train_add_rowmod')
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+class AddDropLN(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(a)): the tail of every sub-layer (transformer.py:154-155,157-158,196-198,200-201); with
+    x = None, p = 0 a plain LayerNorm (decoder.norm, :110-111)."""
+
+    @staticmethod
+    def forward(ctx, x, a, w, b, p):
+        lib = _lib.load_library()
+        a = a.contiguous()
+        rows = a.shape[0]
+        seed = next_seed() if p > 0 else 0
+        s, y, stats = torch.empty_like(a), torch.empty_like(a), _empty((rows, 2), a)
+        with torch.cuda.device(a.device):
+            _chk(lib.cotr_train_add_drop_ln_fwd(_P(None if x is None else x.contiguous()), _P(a), _P(w.detach()), _P(b.detach()),
+                                                _P(s), _P(y), _P(stats), rows, float(p), seed, _sp()), 'cotr_train_add_drop_ln_fwd')
+        ctx.p, ctx.seed, ctx.has_x = float(p), seed, x is not None
+        ctx.save_for_backward(s, stats, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load_library()
+        s, stats, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows = dy.shape[0]
+        ds = torch.empty_like(dy)
+        da = torch.empty_like(dy) if ctx.p > 0 else None          # p == 0: da == ds
+        part = _empty((lib.cotr_train_ln_bwd_parts(rows) * 512,), dy)
+        dwb = _empty((512,), dy)
+        with torch.cuda.device(dy.device):
+            _chk(lib.cotr_train_ln_bwd(_P(dy), _P(s), _P(stats), _P(w), _P(ds), _P(da), _P(part), _P(dwb), rows, ctx.p, ctx.seed,
+                                       _sp()), 'cotr_train_ln_bwd')
+        return (ds if ctx.has_x else None), (ds if da is None else da), dwb[:256], dwb[256:], None
+
+
+class Attention(torch.autograd.Function):
+    """o = dropout(softmax(q k^T * scale)) v per head - the core of nn.MultiheadAttention (transformer.py:149-153, 192-195).
+    ``qk`` given: q and k are the two column halves of one [rows, 512] tensor (encoder self-attention: one projection launch
+    produced both) and their gradient comes back as one tensor; otherwise q [nb*nq, 256] and k [nb*512, 256] are separate
+    (decoder cross-attention).  v [nb*512, 256].  The kernels take a pointer and a leading dimension per operand, so
+    nothing is copied or re-laid-out on the way in or out."""
+
+    @staticmethod
+    def forward(ctx, qk, q, k, v, nb, nq, scale, p):
+        lib = _lib.load_library()
+        packed = qk is not None
+        if packed:
+            qk = qk.contiguous()
+            q_t, k_t, ldq, ldk = qk, qk, 512, 512
+            k_ptr = ctypes.c_void_p(qk.data_ptr() + 256 * 4)
+        else:
+            q_t, k_t, ldq, ldk = q.contiguous(), k.contiguous(), 256, 256
+            k_ptr = _P(k_t)
+        v = v.contiguous()
+        rows = nb * nq
+        o, lse = _empty((rows, 256), v), _empty((rows, 8), v)
+        seed = next_seed() if p > 0 else 0
+        with torch.cuda.device(v.device):
+            _chk(lib.cotr_train_attention_fwd(_P(q_t), ldq, k_ptr, ldk, _P(v), 256, _P(o), 256, _P(lse), nb, nq, float(scale),
+                                              float(p), seed, _sp()), 'cotr_train_attention_fwd')
+        ctx.meta = (packed, nb, nq, float(scale), float(p), seed)
+        ctx.save_for_backward(q_t, k_t, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        lib = _lib.load_library()
+        packed, nb, nq, scale, p, seed = ctx.meta
+        q_t, k_t, v, o, lse = ctx.saved_tensors
+        d_o = d_o.contiguous()
+        rows = nb * nq
+        delta = _empty((rows, 8), o)
+        dv = _empty((nb * 512, 256), o)
+        if packed:
+            dqk = _empty((rows, 512), o)
+            k_ptr = ctypes.c_void_p(k_t.data_ptr() + 256 * 4)
+            dq_ptr, dk_ptr, ldq, ldk = _P(dqk), ctypes.c_void_p(dqk.data_ptr() + 256 * 4), 512, 512
+        else:
+            dq, dk = _empty((rows, 256), o), _empty((nb * 512, 256), o)
+            k_ptr = _P(k_t)
+            dq_ptr, dk_ptr, ldq, ldk = _P(dq), _P(dk), 256, 256
+        with torch.cuda.device(o.device):
+            _chk(lib.cotr_train_attention_bwd(_P(q_t), ldq, k_ptr, ldk, _P(v), 256, _P(o), _P(d_o), 256, _P(lse), _P(delta),
+                                              dq_ptr, ldq, dk_ptr, ldk, _P(dv), 256, nb, nq, scale, p, seed, _sp()),
+                 'cotr_train_attention_bwd')
+        if packed:
+            return dqk, None, None, dv, None, None, None, None
+        return None, dq, dk, dv, None, None, None, None
+
+
+class Head(torch.autograd.Function):
+    """pred = h . W2^T + b2, the last corr_embed layer (256 -> 2, position_encoding.py:23-26) -> [nb, nq, 2]."""
+
+    @staticmethod
+    def forward(ctx, h, w2, b2, nb, nq):
+        lib = _lib.load_library()
+        h = h.contiguous()
+        y = _empty((nb, nq, 2), h)
+        with torch.cuda.device(h.device):
+            _chk(lib.cotr_train_head_fwd(_P(h), _P(w2.detach().contiguous()), _P(b2.detach()), _P(y), nb, nq, _sp()), 'cotr_train_head_fwd')
+        ctx.save_for_backward(h, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load_library()
+        h, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows = h.shape[0]
+        dh = torch.empty_like(h)
+        part = _empty((lib.cotr_train_head_bwd_parts(rows) * 514,), h)
+        dwb = _empty((514,), h)
+        with torch.cuda.device(h.device):
+            _chk(lib.cotr_train_head_bwd(_P(dy), _P(h), _P(w2.contiguous()), _P(dh), _P(part), _P(dwb), rows, _sp()), 'cotr_train_head_bwd')
+        return dh, dwb[:512].view(2, 256), dwb[512:], None, None

@@ -1,23 +1,28 @@
-"""Training step, FIRST VERSION: the reference's stage 1 (frozen backbone, ``train_cotr.py
---lr_backbone=0``) and, with layer2 / layer3 of the backbone as torch convolutions under autograd, its stages 2-3
-(``--lr_backbone > 0``).
+"""Training step: the reference's stage 1 (frozen backbone, ``train_cotr.py --lr_backbone=0``) on
+hand-written HIP kernels forward AND backward, and, with layer2 / layer3 of the backbone as torch convolutions under
+autograd, its stages 2-3 (``--lr_backbone > 0``).
 
 What runs where:
-* backbone (ResNet-50 to layer3, FrozenBN; 70 % of the forward FLOPs, no gradient in stage 1): the hand-written HIP
-  kernels, through ``cotr_backbone`` (C ABI) - once per step, shared by the prediction and the cycle pass;
-* every contraction of the trainable part (input_proj, q/k/v and output projections, both FFN layers, the first two
-  layers of corr_embed) FORWARD AND BACKWARD: the library's fp32-MFMA GEMM kernels (``cotr_op_linear``), wrapped in a
-  ``torch.autograd.Function``:  dX = dY . W  and  dW = dY^T . X  are the same kernel on transposed operands;
-* the autograd tape, the small ops between the contractions (softmax(q k^T) v per head, LayerNorm, dropout, residual adds,
-  the lin_sine encodings and their derivative for the cycle pass, the 256 -> 2 output layer) and Adam: PyTorch on the GPU.
-  Hand-written backward kernels for attention / LayerNorm are the next step of this row; until then this module is the
-  only place where torch ops compute anything, and only under ``model.train()``.
+* backbone (ResNet-50 to layer3, FrozenBN; 70 % of the forward FLOPs, no gradient in stage 1): the inference kernels,
+  through ``cotr_backbone`` (C ABI) - once per step, shared by the prediction and the cycle pass;
+* the whole trainable part - input_proj, 6 encoder layers, 6 decoder layers, decoder.norm, corr_embed - forward and
+  backward: HIP kernels under a torch autograd tape (``cotr_amd/train_ops.py``): fp32-MFMA GEMMs for every contraction
+  (forward, dX on the cached W^T, dW = dY^T . X by a transpose-free split-M kernel), attention with dropout and its
+  recompute-softmax backward (dQ / dK,dV kernels), residual + dropout + LayerNorm fused forward and backward, ReLU + dropout,
+  bias gradients, the lin_sine encodings and the 256 -> 2 head.  Between ``forward_train``'s entry and the loss PyTorch
+  allocates tensors and records the tape; it computes nothing.  The loss (two ``mse_loss`` and a mask, cotr_trainer.py:
+  124-135) and Adam stay torch;
+* stages 2-3 (``--lr_backbone > 0``): conv1 + layer1 on the HIP kernels, layer2 / layer3 as torch convolutions under autograd
+  (conv dgrad / wgrad kernels of our own are not written).
+``forward_train_torch`` is the round-1 tape (HIP GEMMs + torch ops for everything else); it is kept as an independent
+cross-check of the kernels (tests) and is not used by the product path.
 
 Semantics follow the reference line by line: ``COTR.forward`` (COTR/models/cotr_model.py:26-40) with dropout active
 (COTR/models/transformer.py:143-159,185-201; ``nn.MultiheadAttention(dropout=...)``), ``COTRTrainer.train_batch``
 (COTR/trainers/cotr_trainer.py:118-150), the checkpoint dictionary of ``save_model`` (:75-88).  Because
 ``model(img, queries)`` works in training mode and the parameters are ordinary ``nn.Parameter`` objects, the reference's own
-trainer / ``torch.optim.Adam(optim_list)`` (train_cotr.py:49-57) also run unchanged on this model.
+trainer / ``torch.optim.Adam(optim_list)`` (train_cotr.py:49-57) also run unchanged on this model.  Dropout masks come from a
+counter-based generator of our own (not torch's stream): same distribution, different draws.
 """
 import math
 
@@ -183,8 +188,77 @@ def _backbone_trains(model):
     return any(p.requires_grad for p in model.backbone.parameters())
 
 
-def forward_train(model, img, queries, features=None, _query_grad=False):
-    """``COTR.forward`` in training mode -> pred_corrs [B,Q,2] with an autograd graph over the trainable part.
+_pos_tables = {}
+
+
+def _pos_table(device, d):
+    """The image position table [512, d] of this device: a constant, built once (reference: recomputed every call under no_grad)."""
+    key = (str(device), d)
+    if key not in _pos_tables:
+        with torch.no_grad():
+            _pos_tables[key] = image_pos_table(device, hidden=d).contiguous()
+    return _pos_tables[key]
+
+
+def _query_encoding(queries):
+    """lin_sine encoding of the queries on the HIP kernel (cotr_model.py:34-36); no gradient, like the reference
+    (position_encoding.py:40-45)."""
+    lib = _lib.load_library()
+    pts = queries.detach().reshape(-1, 2).float().contiguous()
+    out = torch.empty((pts.shape[0], 256), dtype=torch.float32, device=pts.device)
+    with torch.cuda.device(pts.device):
+        rc = lib.cotr_op_posenc(pts.data_ptr(), out.data_ptr(), pts.shape[0], _lib.current_stream_ptr())
+    if rc != 0:
+        raise _lib.CotrHipError(f'cotr_op_posenc failed (code {rc})')
+    return out
+
+
+def forward_train(model, img, queries, features=None):
+    """``COTR.forward`` in training mode -> pred_corrs [B,Q,2] with an autograd graph over the trainable part; every
+    operation of the graph is a HIP kernel (cotr_amd/train_ops.py).  Row layout is batch-major: row b*L + l is token / query
+    l of pair b.  The query encoding carries no gradient (``NerfPositionalEncoding.forward`` is ``@torch.no_grad()``,
+    COTR/models/position_encoding.py:40-45): in the cycle pass ``model(img, pred)`` nothing flows back through ``pred``."""
+    from . import train_ops as T
+    tr = model.transformer
+    nheads, d = tr.nhead, tr.d_model
+    assert d == 256 and nheads == 8
+    scale = float(d // nheads) ** -0.5
+    b, nq, _ = queries.shape
+    if features is None:
+        features = backbone_features_trainable(model, img) if _backbone_trains(model) else backbone_features(model, img)
+    pos = _pos_table(img.device, d)
+    src = T.linear(features, model.input_proj.weight.view(d, CFEAT), model.input_proj.bias)            # cotr_model.py:37
+    for layer in tr.encoder.layers:                                                                    # transformer.py:143-159
+        p = float(layer.self_attn.dropout) if model.training else 0.0
+        w, bias = layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias
+        qk, v = T.Proj.apply(w, bias, ((0, 2 * d), (2 * d, 3 * d)), False, 0.0, T.AddRows.apply(src, pos, TOK), src)
+        ao = T.Attention.apply(qk, None, None, v, b, TOK, scale, p)
+        ao = T.linear(ao, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)
+        src = T.AddDropLN.apply(src, ao, layer.norm1.weight, layer.norm1.bias, p)
+        hid = T.linear(src, layer.linear1.weight, layer.linear1.bias, relu=True, p=p)
+        src = T.AddDropLN.apply(src, T.linear(hid, layer.linear2.weight, layer.linear2.bias), layer.norm2.weight, layer.norm2.bias, p)
+    memory, mem_pos = src, T.AddRows.apply(src, pos, TOK)
+    query_pos = _query_encoding(queries)                                                               # cotr_model.py:34-36
+    tgt = None                                                                                         # zeros, transformer.py:54
+    for layer in tr.decoder.layers:                                                                    # transformer.py:185-201
+        p = float(layer.multihead_attn.dropout) if model.training else 0.0
+        w, bias = layer.multihead_attn.in_proj_weight, layer.multihead_attn.in_proj_bias
+        xq = query_pos if tgt is None else T.AddRows.apply(tgt, query_pos, 0)
+        q, k, v = T.Proj.apply(w, bias, ((0, d), (d, 2 * d), (2 * d, 3 * d)), False, 0.0, xq, mem_pos, memory)
+        ao = T.Attention.apply(None, q, k, v, b, nq, scale, p)
+        ao = T.linear(ao, layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias)
+        tgt = T.AddDropLN.apply(tgt, ao, layer.norm2.weight, layer.norm2.bias, p)
+        hid = T.linear(tgt, layer.linear1.weight, layer.linear1.bias, relu=True, p=p)
+        tgt = T.AddDropLN.apply(tgt, T.linear(hid, layer.linear2.weight, layer.linear2.bias), layer.norm3.weight, layer.norm3.bias, p)
+    hs = T.AddDropLN.apply(None, tgt, tr.decoder.norm.weight, tr.decoder.norm.bias, 0.0)   # only the last layer reaches the loss
+    mlp = model.corr_embed.layers                                                          # position_encoding.py:23-26
+    x = T.linear(hs, mlp[0].weight, mlp[0].bias, relu=True)
+    x = T.linear(x, mlp[1].weight, mlp[1].bias, relu=True)
+    return T.Head.apply(x, mlp[2].weight, mlp[2].bias, b, nq)
+
+
+def forward_train_torch(model, img, queries, features=None, _query_grad=False):
+    """Round-1 tape, kept as an independent cross-check (tests): HIP GEMMs, everything else torch ops.  Not the product path.
     Row layout is batch-major: row b*L + l is token / query l of pair b.
 
     The query encoding carries NO gradient: ``NerfPositionalEncoding.forward`` is ``@torch.no_grad()``

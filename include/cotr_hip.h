@@ -171,6 +171,49 @@ int cotr_op_ffn_chunks(int M);
 int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
 
 
+/* ---- training step ----------------------------------------------------------
+ * The kernels the autograd tape of cotr_amd/training.py runs besides the GEMMs above; they replace, op for op, what
+ * COTRTrainer.train_batch (COTR/trainers/cotr_trainer.py:118-150) has torch/cuDNN compute in COTR/models/transformer.py
+ * with dropout active.  All device pointers, fp32, rows of 256 channels unless stated.  Dropout is counter-based
+ * (keep = hash(seed, element index) >= p * 2^32): backward kernels recompute the mask from (seed, index), nothing is stored;
+ * p == 0 makes every kernel exact (what the gradient goldens pin).  Reductions across workgroups go through `part` scratch and
+ * are summed in a fixed order (no atomics: a step is bit-repeatable).  cotr_train_*_parts / _splits give the scratch sizes. */
+/* y[m] = x[m] + x2[m % mod] (mod == 0: row m): src + pos (transformer.py:147), tgt + query_pos (:192) */
+int cotr_train_add_rowmod(const float* x, const float* x2, int mod, float* y, int rows, cotr_stream stream);
+/* y = LayerNorm(s), s = x + dropout(a) (x may be NULL); s_out (may be NULL) and stats [rows][2] = (mean, rstd) for the backward:
+ * transformer.py:154-155,157-158 (encoder), :196-198,200-201 (decoder), :110-111 (decoder.norm with x NULL, p 0) */
+int cotr_train_add_drop_ln_fwd(const float* x, const float* a, const float* w, const float* b, float* s_out, float* y, float* stats,
+                               int rows, float p, uint32_t seed, cotr_stream stream);
+int cotr_train_ln_bwd_parts(int rows);
+/* ds = d loss / d s (= dx), da = ds * mask / (1-p) (may be NULL), dwb [512] = dgamma | dbeta; part: parts * 512 floats */
+int cotr_train_ln_bwd(const float* dy, const float* s_in, const float* stats, const float* w, float* ds, float* da, float* part,
+                      float* dwb, int rows, float p, uint32_t seed, cotr_stream stream);
+/* in place x *= mask / (1-p) (n % 4 == 0); backward of y = dropout(relu(h)): dx = y > 0 ? dy / (1-p) : 0 (p == 0: relu backward) */
+int cotr_train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, cotr_stream stream);
+int cotr_train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, float p, cotr_stream stream);
+/* out[N] = column sums of x [M][N] (bias gradients); part: parts(M) * N floats */
+int cotr_train_colsum_parts(int M);
+int cotr_train_colsum(const float* x, float* part, float* out, int M, int N, cotr_stream stream);
+/* dst [C][R] = src [R][C]^T (W^T once per optimiser step, for dX = dY . W on the GEMM kernels) */
+int cotr_train_transpose(const float* src, float* dst, int R, int C, cotr_stream stream);
+/* out [N][K] = A [M][N]^T . B [M][K] (dW = dY^T . X, both row-major, no transposed copies); N, K multiples of 64;
+ * part: splits(M, N, K) * N * K floats */
+int cotr_train_gemm_tn_splits(int M, int N, int K);
+int cotr_train_gemm_tn(const float* A, const float* B, float* part, float* out, int M, int N, int K, cotr_stream stream);
+/* last corr_embed layer 256 -> 2 (position_encoding.py:23-26): y [nb][nq][2]; backward: dh [rows][256], dwb [514] = dW2 | db2 */
+int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream);
+int cotr_train_head_bwd_parts(int rows);
+int cotr_train_head_bwd(const float* dy, const float* h, const float* w2, float* dh, float* part, float* dwb, int rows,
+                        cotr_stream stream);
+/* o = dropout(softmax(q k^T * qscale)) v per head (8 x 32; q [nb*nq][ldq], k [nb*512][ldk], v [nb*512][ldv]); lse [nb*nq][8]
+ * (log2-domain log-sum-exp) for the backward */
+int cotr_train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
+                             int nb, int nq, float qscale, float p, uint32_t seed, cotr_stream stream);
+/* dq [nb*nq][lddq], dk [nb*512][lddk], dv [nb*512][lddv]; delta: nb*nq*8 floats of scratch; o / d_o share ldo */
+int cotr_train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
+                             const float* d_o, int ldo, const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk,
+                             float* dv, int lddv, int nb, int nq, float qscale, float p, uint32_t seed, cotr_stream stream);
+
 /* ---- engine-side input construction (one launch per zoom level) -------------
  * For each of n tasks: crop the square box (xa, ya, size_a) of image A and (xb, yb, size_b) of image B
  * (uint8 HWC RGB, DEVICE pointers; boxes int32 [n][6] on the device, inside the images), resize both to

@@ -1,0 +1,192 @@
+"""Op-level parity of the training-step kernels (cotr_amd/csrc/train.hip, attention_train.hip) through their autograd
+wrappers (cotr_amd/train_ops.py): forward values and every gradient against the same op written with torch in fp64 on the
+CPU.  Dropout is 0 here (exact comparison); the masks' forward / backward consistency is pinned end to end by
+tests/test_training_gpu.py::test_dropout_masks_are_consistent_between_forward_and_backward."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cotr_amd import train_ops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach(), b.detach()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _leaf(t):
+    return t.cuda().requires_grad_()
+
+
+def _leaf64(t):
+    return t.double().requires_grad_()
+
+
+@pytest.mark.parametrize('rows', [1000, 37, 8192])
+@pytest.mark.parametrize('with_x', [True, False])
+def test_residual_layernorm_forward_backward(rows, with_x):
+    g = _g(rows)
+    x, a = torch.randn(rows, 256, generator=g), torch.randn(rows, 256, generator=g) * 2 + 0.3
+    w, b = torch.rand(256, generator=g) + 0.5, 0.1 * torch.randn(256, generator=g)
+    dy = torch.randn(rows, 256, generator=g)
+    xs = [_leaf(x) if with_x else None, _leaf(a), _leaf(w), _leaf(b)]
+    y = T.AddDropLN.apply(xs[0], xs[1], xs[2], xs[3], 0.0)
+    grads = torch.autograd.grad(y, [t for t in xs if t is not None], dy.cuda())
+    rs = [_leaf64(x) if with_x else None, _leaf64(a), _leaf64(w), _leaf64(b)]
+    s = rs[1] + rs[0] if with_x else rs[1]
+    yr = F.layer_norm(s, (256,), rs[2], rs[3])
+    refs = torch.autograd.grad(yr, [t for t in rs if t is not None], dy.double())
+    assert _rel(y, yr) < 1e-5
+    for got, want in zip(grads, refs):
+        assert _rel(got, want) < 3e-5
+
+
+@pytest.mark.parametrize('M,N,K,relu', [(1000, 256, 256, False), (8192, 1024, 256, True), (48, 256, 1024, False),
+                                        (1030, 512, 256, True), (200, 256, 1024, False)])
+def test_linear_forward_backward(M, N, K, relu):
+    """Proj with one slice = nn.Linear (+ ReLU): dX on the cached W^T, dW by the transpose-free split-M kernel, db column sums."""
+    g = _g(M + N + K)
+    x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / math.sqrt(K)
+    b, dy = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    xs = [_leaf(x), _leaf(w), _leaf(b)]
+    y = T.linear(xs[0], xs[1], xs[2], relu=relu)
+    grads = torch.autograd.grad(y, xs, dy.cuda())
+    rs = [_leaf64(x), _leaf64(w), _leaf64(b)]
+    yr = F.linear(*rs)
+    # the ReLU mask of the reference is the kernel's own (y > 0): an element within rounding of zero may fall on either side
+    # in fp32 vs fp64, and then carries a whole dy - not an error of the backward kernels
+    yr = yr * (y.detach().cpu() > 0).double() if relu else yr
+    refs = torch.autograd.grad(yr, rs, dy.double())
+    assert _rel(y, yr) < 2e-5
+    for got, want in zip(grads, refs):
+        assert _rel(got, want) < 5e-5
+    # the W^T cache follows the parameter: an in-place update (optimiser step) invalidates it
+    with torch.no_grad():
+        xs[1].mul_(2.0)
+    y2 = T.linear(xs[0], xs[1], xs[2], relu=relu)
+    gx2 = torch.autograd.grad(y2, xs[0], dy.cuda())[0]
+    mask = (y2.detach().cpu() > 0).double() if relu else torch.ones_like(yr)
+    assert _rel(gx2, (dy.double() * mask) @ (2 * w.double())) < 5e-5
+
+
+def test_packed_in_projection_slices():
+    """The packed in_proj of nn.MultiheadAttention as row slices of one weight applied to different inputs (encoder: q|k from
+    src + pos, v from src; decoder: three inputs with different row counts); the gradient of the weight is assembled in place."""
+    g = _g(5)
+    w, b = torch.randn(768, 256, generator=g) / 16, torch.randn(768, generator=g)
+    xa, xb, xc = torch.randn(300, 256, generator=g), torch.randn(1024, 256, generator=g), torch.randn(1024, 256, generator=g)
+    da, db_, dc = torch.randn(300, 256, generator=g), torch.randn(1024, 256, generator=g), torch.randn(1024, 256, generator=g)
+    xs = [_leaf(w), _leaf(b), _leaf(xa), _leaf(xb), _leaf(xc)]
+    ya, yb, yc = T.Proj.apply(xs[0], xs[1], ((0, 256), (256, 512), (512, 768)), False, 0.0, xs[2], xs[3], xs[4])
+    grads = torch.autograd.grad([ya, yb, yc], xs, [da.cuda(), db_.cuda(), dc.cuda()])
+    rs = [_leaf64(w), _leaf64(b), _leaf64(xa), _leaf64(xb), _leaf64(xc)]
+    outs = [F.linear(rs[2], rs[0][:256], rs[1][:256]), F.linear(rs[3], rs[0][256:512], rs[1][256:512]),
+            F.linear(rs[4], rs[0][512:], rs[1][512:])]
+    refs = torch.autograd.grad(outs, rs, [da.double(), db_.double(), dc.double()])
+    for got, want in zip([ya, yb, yc], outs):
+        assert _rel(got, want) < 2e-5
+    for got, want in zip(grads, refs):
+        assert _rel(got, want) < 5e-5
+    pos = torch.randn(512, 256, generator=g)
+    xr = _leaf(xb)
+    yr = T.AddRows.apply(xr, pos.cuda(), 512)
+    assert _rel(yr, (xb.view(2, 512, 256) + pos).view(1024, 256)) < 1e-7
+    assert torch.equal(torch.autograd.grad(yr, xr, db_.cuda())[0], db_.cuda())
+
+
+@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (2, 100, False), (1, 24, False), (3, 33, False)])
+def test_attention_forward_backward(nb, nq, packed):
+    """attn_train_fwd / attn_bwd_dq / attn_bwd_dkv (recompute-softmax backward) vs softmax attention under torch autograd."""
+    g = _g(nb * 1000 + nq)
+    scale = 32 ** -0.5
+    q = torch.randn(nb * nq, 256, generator=g) * 2
+    k, v = torch.randn(nb * 512, 256, generator=g), torch.randn(nb * 512, 256, generator=g)
+    d_o = torch.randn(nb * nq, 256, generator=g)
+    rq, rk, rv = _leaf64(q), _leaf64(k), _leaf64(v)
+    qh = rq.view(nb, nq, 8, 32).permute(0, 2, 1, 3) * scale
+    kh = rk.view(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    vh = rv.view(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    o_ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).permute(0, 2, 1, 3).reshape(nb * nq, 256)
+    gq, gk, gv = torch.autograd.grad(o_ref, [rq, rk, rv], d_o.double())
+    if packed:
+        qk = _leaf(torch.cat([q, k], dim=1))
+        vv = _leaf(v)
+        o = T.Attention.apply(qk, None, None, vv, nb, nq, scale, 0.0)
+        dqk, dv = torch.autograd.grad(o, [qk, vv], d_o.cuda())
+        dq, dk = dqk[:, :256], dqk[:, 256:]
+    else:
+        xs = [_leaf(q), _leaf(k), _leaf(v)]
+        o = T.Attention.apply(None, xs[0], xs[1], xs[2], nb, nq, scale, 0.0)
+        dq, dk, dv = torch.autograd.grad(o, xs, d_o.cuda())
+    assert _rel(o, o_ref) < 2e-5
+    assert _rel(dq, gq) < 5e-5 and _rel(dk, gk) < 5e-5 and _rel(dv, gv) < 5e-5
+
+
+def test_attention_dropout_statistics_and_determinism():
+    """With dropout the kernel drops ~p of the probabilities and rescales by 1/(1-p): the output is an unbiased estimate of the
+    un-dropped one; the same seed gives the same bits."""
+    nb, nq = 2, 256
+    g = _g(9)
+    q, k = torch.randn(nb * nq, 256, generator=g).cuda(), torch.randn(nb * 512, 256, generator=g).cuda()
+    v = torch.randn(nb * 512, 256, generator=g).cuda()
+    base = T.Attention.apply(None, q, k, v, nb, nq, 0.05, 0.0)
+    T.reseed(7)
+    a = T.Attention.apply(None, q, k, v, nb, nq, 0.05, 0.1)
+    T.reseed(7)
+    b = T.Attention.apply(None, q, k, v, nb, nq, 0.05, 0.1)
+    assert torch.equal(a, b) and not torch.equal(a, base)
+    acc = torch.zeros_like(base)
+    n = 40
+    for i in range(n):
+        acc += T.Attention.apply(None, q, k, v, nb, nq, 0.05, 0.1)
+    # near-uniform attention over 512 keys with zero-mean values: one draw is off by sqrt(p / (1-p)) = 33 % of |o| (relative),
+    # the mean of 40 draws by ~5 %; unbiased: the SIGNED mean deviation over the 131072 outputs is far smaller
+    dev = acc / n - base
+    assert 0.02 < float(dev.abs().mean() / base.abs().mean()) < 0.08
+    assert abs(float(dev.mean())) < 0.01 * float(base.abs().mean())
+
+
+@pytest.mark.parametrize('nb,nq', [(2, 100), (1, 1000), (3, 7)])
+def test_output_head_forward_backward(nb, nq):
+    g = _g(nb + nq)
+    R = nb * nq
+    h, w2, b2 = torch.randn(R, 256, generator=g), torch.randn(2, 256, generator=g) / 16, torch.randn(2, generator=g)
+    dy = torch.randn(nb, nq, 2, generator=g)
+    xs = [_leaf(h), _leaf(w2), _leaf(b2)]
+    y = T.Head.apply(xs[0], xs[1], xs[2], nb, nq)
+    grads = torch.autograd.grad(y, xs, dy.cuda())
+    rs = [_leaf64(h), _leaf64(w2), _leaf64(b2)]
+    yr = F.linear(*rs).view(nb, nq, 2)
+    refs = torch.autograd.grad(yr, rs, dy.double())
+    assert _rel(y, yr) < 2e-5
+    for got, want in zip(grads, refs):
+        assert _rel(got, want) < 3e-5
+
+
+def test_relu_dropout_backward_and_transpose():
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(11)
+    x = torch.randn(777, 1024, generator=g).cuda()
+    w, b = (torch.randn(1024, 256, generator=g) / 16).cuda(), torch.zeros(1024).cuda()
+    xin = torch.randn(777, 256, generator=g).cuda().requires_grad_()
+    T.reseed(3)
+    y = T.linear(xin, w, b, relu=True, p=0.25)
+    frac = (y > 0).float().mean().item()
+    assert 0.3 < frac < 0.45                                      # ~half positive, a quarter of those dropped
+    dy = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, xin, dy)
+    want = ((y > 0).float() * dy / 0.75) @ w                      # the kept, positive elements pass dy / (1 - p)
+    assert _rel(gx, want) < 5e-5
+    t = torch.empty(1024, 777, device='cuda')
+    assert lib.cotr_train_transpose(x.data_ptr(), t.data_ptr(), 777, 1024, _lib.current_stream_ptr()) == 0
+    assert torch.equal(t, x.t().contiguous())
