@@ -1306,9 +1306,22 @@ int cotr_train_colsum(const float* x, float* part, float* out, int M, int N, cot
 int cotr_train_transpose(const float* src, float* dst, int R, int C, cotr_stream stream) {
   return op_ret(train_transpose(src, dst, R, C, TS));
 }
+int cotr_train_im2col(const float* x, float* col, int B, int Hin, int Win, int Cin, int ksize, int stride, cotr_stream stream) {
+  return op_ret(train_im2col(x, col, B, Hin, Win, Cin, ksize, stride, TS));
+}
+int cotr_train_col2im(const float* dcol, float* dx, int B, int Hin, int Win, int Cin, int ksize, int stride, cotr_stream stream) {
+  return op_ret(train_col2im(dcol, dx, B, Hin, Win, Cin, ksize, stride, TS));
+}
+int cotr_train_scale_rows(const float* w, const float* scale, float* out, int rows, int cols, cotr_stream stream) {
+  return op_ret(train_scale_rows(w, scale, out, rows, cols, TS));
+}
+int cotr_train_transpose_batched(const float* src, float* dst, int batch, int R, int C, cotr_stream stream) {
+  return op_ret(train_transpose_batched(src, dst, batch, R, C, TS));
+}
 int cotr_train_gemm_tn_splits(int M, int N, int K) { return train_gemm_tn_splits(M, N, K); }
-int cotr_train_gemm_tn(const float* A, const float* B, float* part, float* out, int M, int N, int K, cotr_stream stream) {
-  return op_ret(train_gemm_tn(A, B, part, out, M, N, K, TS));
+int cotr_train_gemm_tn(const float* A, const float* B, float* part, float* out, float* colsum, int M, int N, int K,
+                       cotr_stream stream) {
+  return op_ret(train_gemm_tn(A, B, part, out, colsum, M, N, K, TS));
 }
 int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream) {
   return op_ret(launch_head2(x, w, b, y, nb, nq, nq, TS));

@@ -35,8 +35,12 @@ int train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, fl
 int train_colsum_parts(int M);
 int train_colsum(const float* x, float* part, float* out, int M, int N, hipStream_t s);
 int train_transpose(const float* src, float* dst, int R, int C, hipStream_t s);
+int train_im2col(const float* x, float* col, int B, int Hin, int Win, int Cin, int ksize, int stride, hipStream_t s);
+int train_col2im(const float* dcol, float* dx, int B, int Hin, int Win, int Cin, int ksize, int stride, hipStream_t s);
+int train_scale_rows(const float* w, const float* scale, float* out, int rows, int cols, hipStream_t s);
+int train_transpose_batched(const float* src, float* dst, int batch, int R, int C, hipStream_t s);
 int train_gemm_tn_splits(int M, int N, int K);
-int train_gemm_tn(const float* A, const float* B, float* part, float* out, int M, int N, int K, hipStream_t s);
+int train_gemm_tn(const float* A, const float* B, float* part, float* out, float* colsum, int M, int N, int K, hipStream_t s);
 int train_head_bwd_parts(int rows);
 int train_head_bwd(const float* dy, const float* h, const float* w2, float* dh, float* part, float* dwb, int rows, hipStream_t s);
 

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // with ds_read_b32 at consecutive addresses (conflict-free).  Rows past M are zero-filled.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                      float* __restrict__ part, int M, int N, int K, int rows_per_split) {
+                                                      float* __restrict__ part, int M, int N, int K, int rows_per_split,
+                                                      int with_colsum) {
   __shared__ __attribute__((aligned(16))) float As[32][68];
   __shared__ __attribute__((aligned(16))) float Bs[32][68];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -229,6 +230,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   f32x4 ra[2], rb[2];
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};      // column sums of A (the bias gradient) over this thread's rows; k-tile 0 only
+  const bool do_colsum = with_colsum && k0 == 0;
   auto load = [&](int m) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<f32x4*>(&As[sr + 16 * i][sc]) = ra[i];
       *reinterpret_cast<f32x4*>(&Bs[sr + 16 * i][sc]) = rb[i];
+      if (do_colsum) csum += ra[i];
     }
     __syncthreads();
     if (m + 32 < m_end) load(m + 32);
@@ -255,12 +259,116 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
   }
-  // D[i][j]: column j = lane & 31 (k), rows i = (r&3) + 8*(r>>2) + 4*hh (n)
-  float* out = part + (size_t)split * N * K;
+  // D[i][j]: column j = lane & 31 (k), rows i = (r&3) + 8*(r>>2) + 4*hh (n).  One partial = [N*K products | N column sums]
+  const size_t pstride = (size_t)N * K + (with_colsum ? N : 0);
+  float* out = part + (size_t)split * pstride;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
     out[(size_t)n * K + k0 + wk * 32 + l31] = acc[r];
+  }
+  if (do_colsum) {   // 16 row-threads per column group: fixed-order sum through LDS (As is free after the last barrier pair)
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&As[sr][sc]) = csum;
+    __syncthreads();
+    if (t < 64) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += As[r][t];
+      out[(size_t)N * K + n0 + t] = sum;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Convolution backward of the trainable backbone stages (layer2 / layer3, COTR/models/backbone.py:66-69) by explicit
+// im2col: with col[m][(ky*k + kx)*Cin + c] = x[pixel(m) shifted by the tap][c] (zero where the tap leaves the 256-wide half:
+// the two halves of a side-by-side pair are padded separately, as in the forward kernels),
+//     wgrad   dW[Cout][k*k*Cin] = dz^T . col          (gemm_tn)
+//     dgrad   dcol = dz . W ,  dx[pixel] = sum of the dcol entries that read it   (GEMM + col2im gather, fixed tap order)
+// Geometry as in GemmParams: activations NHWC side-by-side [B][Hin][2*Win][Cin], outputs [B][Hout][2*Wout].
+// ---------------------------------------------------------------------------------------------------------------------
+struct ConvGeo {
+  int B, Hin, Win, Cin, Hout, Wout, ksize, stride, pad;
+};
+
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, ConvGeo g, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = g.Cin / 4;
+  const int c = (int)(i % c4) * 4;
+  size_t r = i / c4;
+  const int tap = (int)(r % (g.ksize * g.ksize));
+  const size_t m = r / (g.ksize * g.ksize);
+  const int W2o = 2 * g.Wout;
+  const int wo = (int)(m % W2o);
+  const int ho = (int)((m / W2o) % g.Hout);
+  const int b = (int)(m / ((size_t)W2o * g.Hout));
+  const int side = wo / g.Wout, wl = wo - side * g.Wout;
+  const int ky = tap / g.ksize, kx = tap - ky * g.ksize;
+  const int hi = ho * g.stride - g.pad + ky, wi = wl * g.stride - g.pad + kx;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (hi >= 0 && hi < g.Hin && wi >= 0 && wi < g.Win)
+    v = *reinterpret_cast<const f32x4*>(x + (((size_t)b * g.Hin + hi) * (2 * g.Win) + side * g.Win + wi) * g.Cin + c);
+  *reinterpret_cast<f32x4*>(col + i * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dx, ConvGeo g, size_t total4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int c4 = g.Cin / 4;
+  const int c = (int)(i % c4) * 4;
+  size_t pix = i / c4;
+  const int wi2 = (int)(pix % (2 * g.Win));
+  const int hi = (int)((pix / (2 * g.Win)) % g.Hin);
+  const int b = (int)(pix / ((size_t)2 * g.Win * g.Hin));
+  const int side = wi2 / g.Win, wi = wi2 - side * g.Win;
+  const int K = g.ksize * g.ksize * g.Cin;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int ky = 0; ky < g.ksize; ++ky) {
+    const int hn = hi + g.pad - ky;
+    if (hn < 0 || hn % g.stride) continue;
+    const int ho = hn / g.stride;
+    if (ho >= g.Hout) continue;
+    for (int kx = 0; kx < g.ksize; ++kx) {
+      const int wn = wi + g.pad - kx;
+      if (wn < 0 || wn % g.stride) continue;
+      const int wo = wn / g.stride;
+      if (wo >= g.Wout) continue;
+      const size_t m = ((size_t)b * g.Hout + ho) * (2 * g.Wout) + side * g.Wout + wo;
+      acc += *reinterpret_cast<const f32x4*>(dcol + m * K + (ky * g.ksize + kx) * g.Cin + c);
+    }
+  }
+  *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+}
+
+// out[r][c] = w[r][c] * scale[r]   (FrozenBN folded into the weights for the backward: conv(x, W) * scale = conv(x, W * scale))
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                         float* __restrict__ out, int rows, int cols4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)rows * cols4) return;
+  const float sc = scale[i / cols4];
+  f32x4 v = *reinterpret_cast<const f32x4*>(w + i * 4);
+  v *= sc;
+  *reinterpret_cast<f32x4*>(out + i * 4) = v;
+}
+
+// per batch z: dst[z][C][R] = src[z][R][C]^T  (conv weights [Cout][Cin][k*k] <-> [Cout][k*k][Cin])
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C) {
+  __shared__ float tile[32][33];
+  const size_t off = (size_t)blockIdx.z * R * C;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? src[off + (size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < C && r < R) dst[off + (size_t)c * R + r] = tile[tx][ty + 8 * i];
   }
 }
 
@@ -393,26 +501,70 @@ int train_transpose(const float* src, float* dst, int R, int C, hipStream_t s) {
   return LAUNCH_OK();
 }
 
+static ConvGeo conv_geo(int B, int Hin, int Win, int Cin, int ksize, int stride) {
+  ConvGeo g;
+  g.B = B; g.Hin = Hin; g.Win = Win; g.Cin = Cin; g.ksize = ksize; g.stride = stride; g.pad = ksize / 2;
+  g.Hout = (Hin + 2 * g.pad - ksize) / stride + 1;
+  g.Wout = (Win + 2 * g.pad - ksize) / stride + 1;
+  return g;
+}
+
+// col [B*Hout*2*Wout][k*k*Cin] of x [B][Hin][2*Win][Cin]
+int train_im2col(const float* x, float* col, int B, int Hin, int Win, int Cin, int ksize, int stride, hipStream_t s) {
+  if (Cin % 4 || B <= 0) return -1;
+  const ConvGeo g = conv_geo(B, Hin, Win, Cin, ksize, stride);
+  const size_t total4 = (size_t)B * g.Hout * 2 * g.Wout * ksize * ksize * (Cin / 4);
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, col, g, total4);
+  return LAUNCH_OK();
+}
+
+// dx [B][Hin][2*Win][Cin] = gather of dcol [B*Hout*2*Wout][k*k*Cin]
+int train_col2im(const float* dcol, float* dx, int B, int Hin, int Win, int Cin, int ksize, int stride, hipStream_t s) {
+  if (Cin % 4 || B <= 0) return -1;
+  const ConvGeo g = conv_geo(B, Hin, Win, Cin, ksize, stride);
+  const size_t total4 = (size_t)B * Hin * 2 * Win * (Cin / 4);
+  hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, dcol, dx, g, total4);
+  return LAUNCH_OK();
+}
+
+int train_scale_rows(const float* w, const float* scale, float* out, int rows, int cols, hipStream_t s) {
+  if (cols % 4 || rows <= 0) return -1;
+  const size_t total = (size_t)rows * (cols / 4);
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, scale, out, rows, cols / 4);
+  return LAUNCH_OK();
+}
+
+int train_transpose_batched(const float* src, float* dst, int batch, int R, int C, hipStream_t s) {
+  if (batch <= 0 || R <= 0 || C <= 0) return 0;
+  if (batch > 65535) return -1;
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, s, src, dst, R, C);
+  return LAUNCH_OK();
+}
+
 int train_gemm_tn_splits(int M, int N, int K) {
   const int tiles = (N / 64) * (K / 64);
-  int splits = (768 + tiles - 1) / tiles;                 // ~3 workgroups per CU in total
-  const int max_splits = (M + 63) / 64;                   // at least 64 rows per split
+  int splits = (256 + tiles - 1) / tiles;                 // about one workgroup per CU: more splits = more partial traffic
+  const int max_splits = (M + 127) / 128;                 // at least 128 rows per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   return splits;
 }
 
-// out[N][K] = A[M][N]^T . B[M][K]; part holds train_gemm_tn_splits(M, N, K) * N * K floats
-int train_gemm_tn(const float* A, const float* B, float* part, float* out, int M, int N, int K, hipStream_t s) {
+// out[N][K] = A[M][N]^T . B[M][K] (and, with colsum != nullptr, colsum[N] = column sums of A: dW and db of a Linear from ONE
+// pass over dY); part holds train_gemm_tn_splits(M, N, K) * (N * K + N) floats; out and colsum must be ONE contiguous
+// [N*K + N] buffer when both are wanted (colsum == out + N*K): the partials are then finished by a single launch
+int train_gemm_tn(const float* A, const float* B, float* part, float* out, float* colsum, int M, int N, int K, hipStream_t s) {
   if (M <= 0) return -1;
   if (N % 64 || K % 64) return -1;
+  if (colsum != nullptr && colsum != out + (size_t)N * K) return -1;
   const int splits = train_gemm_tn_splits(M, N, K);
   int per = (M + splits - 1) / splits;
   per = (per + 31) / 32 * 32;
   const int nsplit = (M + per - 1) / per;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((N / 64) * (K / 64), nsplit), dim3(256), 0, s, A, B, part, M, N, K, per);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((N / 64) * (K / 64), nsplit), dim3(256), 0, s, A, B, part, M, N, K, per,
+                     colsum != nullptr ? 1 : 0);
   if (hipGetLastError() != hipSuccess) return -2;
-  return train_sum_parts(part, nsplit, (size_t)N * K, out, s);
+  return train_sum_parts(part, nsplit, (size_t)N * K + (colsum ? N : 0), out, s);
 }
 
 int train_head_bwd_parts(int rows) {

@@ -67,16 +67,20 @@ def gemm(a, w, bias=None, relu=False):
     return y
 
 
-def gemm_tn(dy, x, out):
-    """out[N,K] = dy[M,N]^T . x[M,K] (dW), operands row-major as they are: split over M, fixed-order sum of the partials."""
+def gemm_tn(dy, x, with_colsum=False):
+    """dW[N,K] = dy[M,N]^T . x[M,K] (operands row-major as they are: split over M, fixed-order sum of the partials) and, with
+    ``with_colsum``, db[N] = column sums of dy from the same pass.  -> (dW, db or None), views of one buffer."""
     lib = _lib.load_library()
     m, n = dy.shape
     k = x.shape[1]
-    assert dy.is_contiguous() and x.is_contiguous() and out.is_contiguous() and x.shape[0] == m and out.shape == (n, k)
-    part = _empty((lib.cotr_train_gemm_tn_splits(m, n, k) * n * k,), dy)
+    assert dy.is_contiguous() and x.is_contiguous() and x.shape[0] == m
+    extra = n if with_colsum else 0
+    buf = _empty((n * k + extra,), dy)
+    part = _empty((lib.cotr_train_gemm_tn_splits(m, n, k) * (n * k + extra),), dy)
+    cs = ctypes.c_void_p(buf.data_ptr() + n * k * 4) if with_colsum else None
     with torch.cuda.device(dy.device):
-        _chk(lib.cotr_train_gemm_tn(_P(dy), _P(x), _P(part), _P(out), m, n, k, _sp()), f'cotr_train_gemm_tn {m}x{n}x{k}')
-    return out
+        _chk(lib.cotr_train_gemm_tn(_P(dy), _P(x), _P(part), _P(buf), cs, m, n, k, _sp()), f'cotr_train_gemm_tn {m}x{n}x{k}')
+    return buf[:n * k].view(n, k), (buf[n * k:] if with_colsum else None)
 
 
 def colsum(x, out):
@@ -148,13 +152,9 @@ class Proj(torch.autograd.Function):
         n = len(ctx.ranges)
         xs = saved[1:1 + n]
         lib = _lib.load_library()
-        covered = sum(hi - lo for lo, hi in ctx.ranges) == w.shape[0]
         need_w = ctx.needs_input_grad[0]
-        dw = (torch.empty_like(w) if covered else torch.zeros_like(w)) if need_w else None
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[1]:
-            db = _empty((w.shape[0],), w) if covered else torch.zeros((w.shape[0],), dtype=torch.float32, device=w.device)
-        dxs = []
+        need_b = ctx.has_bias and ctx.needs_input_grad[1]
+        dws, dbs, dxs = [], [], []
         for i, ((lo, hi), x, dy) in enumerate(zip(ctx.ranges, xs, dys)):
             if dy is None:      # an output nobody used
                 dy = torch.zeros((x.shape[0], hi - lo), dtype=torch.float32, device=x.device)
@@ -166,10 +166,16 @@ class Proj(torch.autograd.Function):
                     _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dh), dy.numel(), ctx.p, _sp()), 'cotr_train_relu_drop_bwd')
                 dy = dh
             dxs.append(gemm(dy, weight_t(w[lo:hi])) if ctx.needs_input_grad[5 + i] else None)
-            if dw is not None:
-                gemm_tn(dy, x, dw[lo:hi])
-            if db is not None:
-                colsum(dy, db[lo:hi])
+            if need_w:
+                dwi, dbi = gemm_tn(dy, x, with_colsum=need_b)      # dW and db of this slice from one pass over dy
+                dws.append(dwi)
+                dbs.append(dbi)
+            elif need_b:
+                dbs.append(colsum(dy, _empty((hi - lo,), dy)))
+        assert [lo for lo, _ in ctx.ranges] == [0] + [hi for _, hi in ctx.ranges[:-1]] and ctx.ranges[-1][1] == w.shape[0], \
+            'the slices must tile the weight in order'
+        dw = (dws[0] if n == 1 else torch.cat(dws, dim=0)) if need_w else None
+        db = (dbs[0] if n == 1 else torch.cat(dbs, dim=0)) if need_b else None
         return (dw, db, None, None, None, *dxs)
 
 
@@ -281,6 +287,86 @@ class Attention(torch.autograd.Function):
         if packed:
             return dqk, None, None, dv, None, None, None, None
         return None, dq, dk, dv, None, None, None, None
+
+
+def _pack_conv_weight(w):
+    """torch's [Cout, Cin, k, k] -> the kernels' [Cout][k][k][Cin] (batched transpose on the device)."""
+    lib = _lib.load_library()
+    cout, cin, k, _ = w.shape
+    if k == 1:
+        return w.detach().reshape(cout, cin)
+    out = _empty((cout, k * k * cin), w)
+    with torch.cuda.device(w.device):
+        _chk(lib.cotr_train_transpose_batched(_P(w.detach().contiguous()), _P(out), cout, cin, k * k, _sp()), 'cotr_train_transpose_batched')
+    return out
+
+
+class ConvBN(torch.autograd.Function):
+    """One convolution of a trainable bottleneck (layer2 / layer3: COTR/models/backbone.py:66-69 trains only these) with its
+    FrozenBatchNorm2d affine (backbone.py:46-56), optional residual and ReLU, on the NHWC side-by-side layout of the inference
+    kernels: y = relu?(conv(x, W) * scale + bias (+ res)).  Forward = the inference implicit-GEMM kernel (cotr_op_conv).
+    Backward: dz = dy * (y > 0); wgrad = dz^T . im2col(x) * scale (transpose-free split-M GEMM); dgrad = col2im(dz . (W * scale));
+    1 x 1 stride-1 convolutions skip the im2col / col2im (the activation matrix is its own im2col)."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, bias, res, relu, stride):
+        lib = _lib.load_library()
+        x = x.contiguous()
+        b, h, w2, cin = x.shape
+        wd = w2 // 2
+        cout, _, k, _ = w.shape
+        pad = k // 2
+        ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+        wp = _pack_conv_weight(w)
+        y = _empty((b, ho, 2 * wo, cout), x)
+        with torch.cuda.device(x.device):
+            _chk(lib.cotr_op_conv(_P(x), _P(wp), _P(scale), _P(bias), _P(None if res is None else res.contiguous()), int(relu), _P(y),
+                                  b, h, wd, cin, cout, k, stride, _sp()), 'cotr_op_conv')
+        ctx.meta = (b, h, wd, cin, cout, k, stride, ho, wo, bool(relu), res is not None)
+        ctx.save_for_backward(x, wp, scale, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load_library()
+        b, h, wd, cin, cout, k, stride, ho, wo, relu, has_res = ctx.meta
+        x, wp, scale, y = ctx.saved_tensors
+        m, kk = b * ho * 2 * wo, k * k * cin
+        dy = dy.contiguous()
+        dz = dy
+        with torch.cuda.device(dy.device):
+            if relu:
+                dz = torch.empty_like(dy)
+                _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dz), dy.numel(), 0.0, _sp()), 'cotr_train_relu_drop_bwd')
+            dz2 = dz.view(m, cout)
+            direct = k == 1 and stride == 1
+            if direct:
+                col = x.view(m, cin)
+            else:
+                col = _empty((m, kk), x)
+                _chk(lib.cotr_train_im2col(_P(x), _P(col), b, h, wd, cin, k, stride, _sp()), 'cotr_train_im2col')
+            dw = None
+            if ctx.needs_input_grad[1]:
+                dwp, _ = gemm_tn(dz2, col)                                    # d(W * scale), packed layout
+                _chk(lib.cotr_train_scale_rows(_P(dwp), _P(scale), _P(dwp), cout, kk, _sp()), 'cotr_train_scale_rows')
+                if k == 1:
+                    dw = dwp.view(cout, cin, 1, 1)
+                else:
+                    dw = _empty((cout, cin, k, k), x)
+                    _chk(lib.cotr_train_transpose_batched(_P(dwp), _P(dw), cout, k * k, cin, _sp()), 'cotr_train_transpose_batched')
+            dx = None
+            if ctx.needs_input_grad[0]:
+                ws = torch.empty_like(wp)
+                _chk(lib.cotr_train_scale_rows(_P(wp), _P(scale), _P(ws), cout, kk, _sp()), 'cotr_train_scale_rows')
+                wst = _empty((kk, cout), x)
+                _chk(lib.cotr_train_transpose(_P(ws), _P(wst), cout, kk, _sp()), 'cotr_train_transpose')
+                dcol = gemm(dz2, wst)                                         # [m, k*k*cin]
+                if direct:
+                    dx = dcol.view(b, h, 2 * wd, cin)
+                else:
+                    dx = torch.empty_like(x)
+                    _chk(lib.cotr_train_col2im(_P(dcol), _P(dx), b, h, wd, cin, k, stride, _sp()), 'cotr_train_col2im')
+        return dx, dw, None, None, (dz if has_res else None), None, None
 
 
 class Head(torch.autograd.Function):

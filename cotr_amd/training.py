@@ -160,10 +160,41 @@ def _bottleneck(x, blk):
     return F.relu(out + idt)
 
 
-def backbone_features_trainable(model, img):
+_bn_cache = {}
+
+
+def _frozen_bn_affine(bn):
+    """(scale, bias) of a FrozenBatchNorm2d (backbone.py:46-56): buffers only -> constants, computed once per module."""
+    key = id(bn)
+    ver = tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
+    hit = _bn_cache.get(key)
+    if hit is None or hit[0] != ver or hit[1].device != bn.weight.device:
+        with torch.no_grad():
+            scale = bn.weight * (bn.running_var + 1e-5).rsqrt()
+            hit = (ver, scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
+        _bn_cache[key] = hit
+    return hit[1], hit[2]
+
+
+def _bottleneck_hip(x, blk):
+    """torchvision ResNet v1.5 Bottleneck (stride on the 3x3) with FrozenBN on the NHWC side-by-side layout, every convolution
+    forward and backward on the HIP kernels (train_ops.ConvBN)."""
+    from . import train_ops as T
+    stride = blk.conv2.stride[0]
+    out = T.ConvBN.apply(x, blk.conv1.weight, *_frozen_bn_affine(blk.bn1), None, True, 1)
+    out = T.ConvBN.apply(out, blk.conv2.weight, *_frozen_bn_affine(blk.bn2), None, True, stride)
+    idt = x
+    if hasattr(blk, 'downsample'):
+        idt = T.ConvBN.apply(x, blk.downsample[0].weight, *_frozen_bn_affine(blk.downsample[1]), None, False, stride)
+    return T.ConvBN.apply(out, blk.conv3.weight, *_frozen_bn_affine(blk.bn3), idt, True, 1)
+
+
+def backbone_features_trainable(model, img, use_torch_convs=False):
     """Stages 2-3 of the reference's recipe (--lr_backbone > 0): only layer2 / layer3 train (backbone.py:66-69), so conv1 +
-    layer1 still run on the HIP kernels (cotr_backbone_upto, no gradient) and layer2 / layer3 run as torch convolutions under
-    autograd, each 256-wide half on its own like BackboneBase.forward (backbone.py:79-92).  -> [B*512, 1024] with graph."""
+    layer1 run on the inference kernels (cotr_backbone_upto, no gradient) and layer2 / layer3 run under autograd - on the HIP
+    kernels forward and backward (train_ops.ConvBN, NHWC side-by-side: both halves of a pair in one tensor, each padded on its
+    own).  ``use_torch_convs``: the round-1 path (torch / MIOpen convolutions per 256-wide half), kept as a cross-check.
+    -> [B*512, 1024] with graph."""
     lib = model._ensure_ready(img.device)
     img = img.detach().contiguous().float()
     b = img.shape[0]
@@ -173,6 +204,11 @@ def backbone_features_trainable(model, img):
         _lib.check(lib.cotr_backbone_upto(model._handle, img.data_ptr(), b, 1, l1.data_ptr(), _lib.current_stream_ptr()),
                    model._handle, 'cotr_backbone_upto')
     body = model.backbone[0].body
+    if not use_torch_convs:
+        y = l1
+        for blk in list(body.layer2) + list(body.layer3):
+            y = _bottleneck_hip(y, blk)
+        return y.view(b * TOK, CFEAT)                                                        # [B,16,32,1024] = the token matrix
     x = l1.permute(0, 3, 1, 2)                                                               # [B,256,64,128]
     halves = []
     for half in (x[..., :64], x[..., 64:]):

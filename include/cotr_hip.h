@@ -196,10 +196,22 @@ int cotr_train_colsum_parts(int M);
 int cotr_train_colsum(const float* x, float* part, float* out, int M, int N, cotr_stream stream);
 /* dst [C][R] = src [R][C]^T (W^T once per optimiser step, for dX = dY . W on the GEMM kernels) */
 int cotr_train_transpose(const float* src, float* dst, int R, int C, cotr_stream stream);
-/* out [N][K] = A [M][N]^T . B [M][K] (dW = dY^T . X, both row-major, no transposed copies); N, K multiples of 64;
- * part: splits(M, N, K) * N * K floats */
+/* Convolution backward of the trainable backbone stages (layer2 / layer3, backbone.py:66-69) by explicit im2col over the NHWC
+ * side-by-side activations [B][Hin][2*Win][Cin] (each half padded on its own, like the forward kernels):
+ *   col [B*Hout*2*Wout][k*k*Cin] = im2col(x);  wgrad dW [Cout][k*k*Cin] = dz^T . col (cotr_train_gemm_tn);
+ *   dgrad dcol = dz . W (GEMM), dx = col2im(dcol) (gather over the taps in a fixed order).
+ * cotr_train_scale_rows: out[r][:] = w[r][:] * scale[r] (FrozenBN folded into the weights / unfolded from their gradient);
+ * cotr_train_transpose_batched: per batch element dst[C][R] = src[R][C]^T (torch's [Cout][Cin][k*k] <-> packed [Cout][k*k][Cin]) */
+int cotr_train_im2col(const float* x, float* col, int B, int Hin, int Win, int Cin, int ksize, int stride, cotr_stream stream);
+int cotr_train_col2im(const float* dcol, float* dx, int B, int Hin, int Win, int Cin, int ksize, int stride, cotr_stream stream);
+int cotr_train_scale_rows(const float* w, const float* scale, float* out, int rows, int cols, cotr_stream stream);
+int cotr_train_transpose_batched(const float* src, float* dst, int batch, int R, int C, cotr_stream stream);
+/* out [N][K] = A [M][N]^T . B [M][K] (dW = dY^T . X, both row-major, no transposed copies); N, K multiples of 64.
+ * colsum != NULL: also colsum [N] = column sums of A (db) from the same pass over dY; it must be out + N*K (one buffer
+ * [N*K + N]) so that one launch finishes both.  part: splits(M, N, K) * (N * K + N) floats */
 int cotr_train_gemm_tn_splits(int M, int N, int K);
-int cotr_train_gemm_tn(const float* A, const float* B, float* part, float* out, int M, int N, int K, cotr_stream stream);
+int cotr_train_gemm_tn(const float* A, const float* B, float* part, float* out, float* colsum, int M, int N, int K,
+                       cotr_stream stream);
 /* last corr_embed layer 256 -> 2 (position_encoding.py:23-26): y [nb][nq][2]; backward: dh [rows][256], dwb [514] = dW2 | db2 */
 int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream);
 int cotr_train_head_bwd_parts(int rows);

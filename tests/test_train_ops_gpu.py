@@ -190,3 +190,38 @@ def test_relu_dropout_backward_and_transpose():
     t = torch.empty(1024, 777, device='cuda')
     assert lib.cotr_train_transpose(x.data_ptr(), t.data_ptr(), 777, 1024, _lib.current_stream_ptr()) == 0
     assert torch.equal(t, x.t().contiguous())
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,stride,res,relu', [(2, 16, 128, 128, 3, 1, False, True), (1, 32, 256, 128, 3, 2, False, True),
+                                                            (2, 16, 256, 512, 1, 2, False, False), (1, 16, 128, 512, 1, 1, True, True),
+                                                            (3, 8, 512, 256, 1, 1, False, True)])
+def test_conv_frozenbn_forward_backward(B, H, cin, cout, k, stride, res, relu):
+    """train_ops.ConvBN (layer2 / layer3 of the trainable backbone): forward = the inference conv kernel, backward = im2col +
+    transpose-free wgrad + GEMM / col2im dgrad on the NHWC side-by-side layout; against F.conv2d on each 256-wide half (NCHW,
+    fp64) with the FrozenBN affine, residual and ReLU of the bottleneck."""
+    g = _g(B * 100 + H + cin + cout + k + stride)
+    x = torch.randn(B, cin, H, 2 * H, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    sc, bi = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    r = torch.randn(B, cout, Ho, 2 * Ho, generator=g) if res else None
+    dy = torch.randn(B, cout, Ho, 2 * Ho, generator=g)
+
+    def nhwc(t):
+        return t.permute(0, 2, 3, 1).contiguous()
+    xs = [_leaf(nhwc(x)), _leaf(w)] + ([_leaf(nhwc(r))] if res else [])
+    y = T.ConvBN.apply(xs[0], xs[1], sc.cuda(), bi.cuda(), xs[2] if res else None, relu, stride)
+    grads = torch.autograd.grad(y, xs, nhwc(dy).cuda())
+    rs = [_leaf64(x), _leaf64(w)] + ([_leaf64(r)] if res else [])
+    halves = [F.conv2d(rs[0][..., :H], rs[1], stride=stride, padding=k // 2), F.conv2d(rs[0][..., H:], rs[1], stride=stride, padding=k // 2)]
+    yr = torch.cat(halves, dim=-1) * sc.double().view(1, -1, 1, 1) + bi.double().view(1, -1, 1, 1)
+    if res:
+        yr = yr + rs[2]
+    if relu:
+        yr = yr * (y.detach().permute(0, 3, 1, 2).cpu() > 0).double()      # the kernel's own mask (see test_linear_forward_backward)
+    refs = torch.autograd.grad(yr, rs, dy.double())
+    assert _rel(y, nhwc(yr.detach())) < 3e-5
+    assert _rel(grads[0], nhwc(refs[0])) < 5e-5
+    assert _rel(grads[1], refs[1]) < 5e-5
+    if res:
+        assert _rel(grads[2], nhwc(refs[2])) < 5e-5
