@@ -31,6 +31,25 @@ def _empty(shape, like):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """Context that makes ``device`` current for a kernel call - a no-op when it already is (torch.cuda.device() costs ~15 us of
+    host time per use; a training step makes ~1500 kernel calls)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 # ---- dropout seeds ----------------------------------------------------------------------------------------------------
 _seed = {'base': None, 'count': 0}
 
@@ -61,7 +80,7 @@ def gemm(a, w, bias=None, relu=False):
     assert a.is_contiguous() and w.is_contiguous() and w.shape[1] == k and k % 32 == 0 and n % 16 == 0, (a.shape, w.shape)
     y = _empty((m, n), a)
     if m:
-        with torch.cuda.device(a.device):
+        with _on(a.device):
             _chk(lib.cotr_op_linear(_P(a), None, 0, _P(w), None, _P(bias), None, int(relu), _P(y), m, n, k, _sp()),
                  f'cotr_op_linear {m}x{n}x{k}')
     return y
@@ -78,7 +97,7 @@ def gemm_tn(dy, x, with_colsum=False):
     buf = _empty((n * k + extra,), dy)
     part = _empty((lib.cotr_train_gemm_tn_splits(m, n, k) * (n * k + extra),), dy)
     cs = ctypes.c_void_p(buf.data_ptr() + n * k * 4) if with_colsum else None
-    with torch.cuda.device(dy.device):
+    with _on(dy.device):
         _chk(lib.cotr_train_gemm_tn(_P(dy), _P(x), _P(part), _P(buf), cs, m, n, k, _sp()), f'cotr_train_gemm_tn {m}x{n}x{k}')
     return buf[:n * k].view(n, k), (buf[n * k:] if with_colsum else None)
 
@@ -87,7 +106,7 @@ def colsum(x, out):
     lib = _lib.load_library()
     m, n = x.shape
     part = _empty((lib.cotr_train_colsum_parts(m) * n,), x)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         _chk(lib.cotr_train_colsum(_P(x), _P(part), _P(out), m, n, _sp()), 'cotr_train_colsum')
     return out
 
@@ -114,7 +133,7 @@ def weight_t(w):
     lib = _lib.load_library()
     n, k = w.shape
     wt = _empty((k, n), w)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _chk(lib.cotr_train_transpose(_P(w.detach()), _P(wt), n, k, _sp()), 'cotr_train_transpose')
     entry[1][key] = (base._version, wt)
     return wt
@@ -139,7 +158,7 @@ class Proj(torch.autograd.Function):
         if relu and p > 0:
             seed = next_seed()
             lib = _lib.load_library()
-            with torch.cuda.device(ys[0].device):
+            with _on(ys[0].device):
                 _chk(lib.cotr_train_dropout_fwd(_P(ys[0]), ys[0].numel(), float(p), seed, _sp()), 'cotr_train_dropout_fwd')
         ctx.ranges, ctx.relu, ctx.p, ctx.has_bias = ranges, relu, float(p), b is not None
         ctx.save_for_backward(w, *xs, *(ys if relu else []))
@@ -162,7 +181,7 @@ class Proj(torch.autograd.Function):
             if ctx.relu:
                 y = saved[1 + n]
                 dh = torch.empty_like(dy)
-                with torch.cuda.device(dy.device):
+                with _on(dy.device):
                     _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dh), dy.numel(), ctx.p, _sp()), 'cotr_train_relu_drop_bwd')
                 dy = dh
             dxs.append(gemm(dy, weight_t(w[lo:hi])) if ctx.needs_input_grad[5 + i] else None)
@@ -191,7 +210,7 @@ class AddRows(torch.autograd.Function):
     def forward(ctx, x, x2, mod):
         x = x.contiguous()
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _chk(_lib.load_library().cotr_train_add_rowmod(_P(x), _P(x2), int(mod), _P(y), x.shape[0], _sp()), 'cotr_train_add_rowmod')
         return y
 
@@ -211,7 +230,7 @@ class AddDropLN(torch.autograd.Function):
         rows = a.shape[0]
         seed = next_seed() if p > 0 else 0
         s, y, stats = torch.empty_like(a), torch.empty_like(a), _empty((rows, 2), a)
-        with torch.cuda.device(a.device):
+        with _on(a.device):
             _chk(lib.cotr_train_add_drop_ln_fwd(_P(None if x is None else x.contiguous()), _P(a), _P(w.detach()), _P(b.detach()),
                                                 _P(s), _P(y), _P(stats), rows, float(p), seed, _sp()), 'cotr_train_add_drop_ln_fwd')
         ctx.p, ctx.seed, ctx.has_x = float(p), seed, x is not None
@@ -228,7 +247,7 @@ class AddDropLN(torch.autograd.Function):
         da = torch.empty_like(dy) if ctx.p > 0 else None          # p == 0: da == ds
         part = _empty((lib.cotr_train_ln_bwd_parts(rows) * 512,), dy)
         dwb = _empty((512,), dy)
-        with torch.cuda.device(dy.device):
+        with _on(dy.device):
             _chk(lib.cotr_train_ln_bwd(_P(dy), _P(s), _P(stats), _P(w), _P(ds), _P(da), _P(part), _P(dwb), rows, ctx.p, ctx.seed,
                                        _sp()), 'cotr_train_ln_bwd')
         return (ds if ctx.has_x else None), (ds if da is None else da), dwb[:256], dwb[256:], None
@@ -256,7 +275,7 @@ class Attention(torch.autograd.Function):
         rows = nb * nq
         o, lse = _empty((rows, 256), v), _empty((rows, 8), v)
         seed = next_seed() if p > 0 else 0
-        with torch.cuda.device(v.device):
+        with _on(v.device):
             _chk(lib.cotr_train_attention_fwd(_P(q_t), ldq, k_ptr, ldk, _P(v), 256, _P(o), 256, _P(lse), nb, nq, float(scale),
                                               float(p), seed, _sp()), 'cotr_train_attention_fwd')
         ctx.meta = (packed, nb, nq, float(scale), float(p), seed)
@@ -280,7 +299,7 @@ class Attention(torch.autograd.Function):
             dq, dk = _empty((rows, 256), o), _empty((nb * 512, 256), o)
             k_ptr = _P(k_t)
             dq_ptr, dk_ptr, ldq, ldk = _P(dq), _P(dk), 256, 256
-        with torch.cuda.device(o.device):
+        with _on(o.device):
             _chk(lib.cotr_train_attention_bwd(_P(q_t), ldq, k_ptr, ldk, _P(v), 256, _P(o), _P(d_o), 256, _P(lse), _P(delta),
                                               dq_ptr, ldq, dk_ptr, ldk, _P(dv), 256, nb, nq, scale, p, seed, _sp()),
                  'cotr_train_attention_bwd')
@@ -296,7 +315,7 @@ def _pack_conv_weight(w):
     if k == 1:
         return w.detach().reshape(cout, cin)
     out = _empty((cout, k * k * cin), w)
-    with torch.cuda.device(w.device):
+    with _on(w.device):
         _chk(lib.cotr_train_transpose_batched(_P(w.detach().contiguous()), _P(out), cout, cin, k * k, _sp()), 'cotr_train_transpose_batched')
     return out
 
@@ -319,7 +338,7 @@ class ConvBN(torch.autograd.Function):
         ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
         wp = _pack_conv_weight(w)
         y = _empty((b, ho, 2 * wo, cout), x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _chk(lib.cotr_op_conv(_P(x), _P(wp), _P(scale), _P(bias), _P(None if res is None else res.contiguous()), int(relu), _P(y),
                                   b, h, wd, cin, cout, k, stride, _sp()), 'cotr_op_conv')
         ctx.meta = (b, h, wd, cin, cout, k, stride, ho, wo, bool(relu), res is not None)
@@ -334,7 +353,7 @@ class ConvBN(torch.autograd.Function):
         m, kk = b * ho * 2 * wo, k * k * cin
         dy = dy.contiguous()
         dz = dy
-        with torch.cuda.device(dy.device):
+        with _on(dy.device):
             if relu:
                 dz = torch.empty_like(dy)
                 _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dz), dy.numel(), 0.0, _sp()), 'cotr_train_relu_drop_bwd')
@@ -377,7 +396,7 @@ class Head(torch.autograd.Function):
         lib = _lib.load_library()
         h = h.contiguous()
         y = _empty((nb, nq, 2), h)
-        with torch.cuda.device(h.device):
+        with _on(h.device):
             _chk(lib.cotr_train_head_fwd(_P(h), _P(w2.detach().contiguous()), _P(b2.detach()), _P(y), nb, nq, _sp()), 'cotr_train_head_fwd')
         ctx.save_for_backward(h, w2)
         return y
@@ -391,6 +410,6 @@ class Head(torch.autograd.Function):
         dh = torch.empty_like(h)
         part = _empty((lib.cotr_train_head_bwd_parts(rows) * 514,), h)
         dwb = _empty((514,), h)
-        with torch.cuda.device(h.device):
+        with _on(h.device):
             _chk(lib.cotr_train_head_bwd(_P(dy), _P(h), _P(w2.contiguous()), _P(dh), _P(part), _P(dwb), rows, _sp()), 'cotr_train_head_bwd')
         return dh, dwb[:512].view(2, 256), dwb[512:], None, None
