@@ -229,20 +229,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  f32x4 ra[2], rb[2];
+  // two chunks of 32 rows in flight in registers (the loop is otherwise bound by one global-load latency per 16 MFMAs)
+  f32x4 ra0[2], rb0[2], ra1[2], rb1[2];
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};      // column sums of A (the bias gradient) over this thread's rows; k-tile 0 only
   const bool do_colsum = with_colsum && k0 == 0;
-  auto load = [&](int m) {
+  auto load = [&](int m, f32x4 (&ra)[2], f32x4 (&rb)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int row = m + sr + 16 * i;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ra[i] = row < m_end ? *reinterpret_cast<const f32x4*>(A + (size_t)row * N + n0 + sc) : z;
-      rb[i] = row < m_end ? *reinterpret_cast<const f32x4*>(B + (size_t)row * K + k0 + sc) : z;
+      const int rc = row < m_end ? row : m_begin;          // clamped address, value zeroed below (no branch around the load)
+      ra[i] = *reinterpret_cast<const f32x4*>(A + (size_t)rc * N + n0 + sc);
+      rb[i] = *reinterpret_cast<const f32x4*>(B + (size_t)rc * K + k0 + sc);
+      if (row >= m_end) {
+        ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
-  load(m_begin);
-  for (int m = m_begin; m < m_end; m += 32) {
+  auto step = [&](f32x4 (&ra)[2], f32x4 (&rb)[2], int m_next) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -251,13 +255,19 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
       if (do_colsum) csum += ra[i];
     }
     __syncthreads();
-    if (m + 32 < m_end) load(m + 32);
+    if (m_next < m_end) load(m_next, ra, rb);             // this register set is free again: request the chunk after next
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
       const float a = As[2 * s2 + hh][wn * 32 + l31];   // A operand: lane i = output row n, k = row 2*s2 + hh of the chunk
       const float b = Bs[2 * s2 + hh][wk * 32 + l31];   // B operand: lane j = output column k
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+  };
+  load(m_begin, ra0, rb0);
+  if (m_begin + 32 < m_end) load(m_begin + 32, ra1, rb1);
+  for (int m = m_begin; m < m_end; m += 64) {
+    step(ra0, rb0, m + 64);
+    if (m + 32 < m_end) step(ra1, rb1, m + 96);
   }
   // D[i][j]: column j = lane & 31 (k), rows i = (r&3) + 8*(r>>2) + 4*hh (n).  One partial = [N*K products | N column sums]
   const size_t pstride = (size_t)N * K + (with_colsum ? N : 0);
@@ -543,7 +553,7 @@ int train_transpose_batched(const float* src, float* dst, int batch, int R, int 
 
 int train_gemm_tn_splits(int M, int N, int K) {
   const int tiles = (N / 64) * (K / 64);
-  int splits = (256 + tiles - 1) / tiles;                 // about one workgroup per CU: more splits = more partial traffic
+  int splits = (512 + tiles - 1) / tiles;                 // about two workgroups per CU: more splits = more partial traffic
   const int max_splits = (M + 127) / 128;                 // at least 128 rows per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
