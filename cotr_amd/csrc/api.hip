@@ -28,6 +28,7 @@
 
 int init_attention_attributes();
 void set_attention_splits(int ns);
+void set_attention_fused_splits(int v);
 
 namespace {
 
@@ -1215,6 +1216,12 @@ int cotr_set_xcd_mapping(int policy) {
   set_ffn_chunk_major((policy >> 2) & 1);
   set_attention_head_major((policy >> 3) & 1);
   set_ffn_write_through(((policy >> 4) & 1) == 0);   // bit 4 set = plain (write-back) stores for the FFN partial outputs
+  return COTR_OK;
+}
+
+int cotr_set_attention_fused_splits(int ns) {
+  if (ns != 0 && ns != 4 && ns != 8) return COTR_ERR_ARG;
+  set_attention_fused_splits(ns);
   return COTR_OK;
 }
 

@@ -51,11 +51,14 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
                                                             const float* __restrict__ v, int ldkv,
                                                             float* __restrict__ o, int ldo, int nq, int head_major,
                                                             const AttnFuse fz) {
-  static_assert(!(QP || OP) || NS == 4, "the fused variants are written for 4 key splits");
+  static_assert(!(QP || OP) || NS == 4 || NS == 8, "the fused variants are written for 4 or 8 key splits");
+  constexpr int NBO = 8 / (NS >= 4 ? NS : 4);  // OP: 32-column blocks of the out projection per wavefront (2 at NS = 4, 1 at NS = 8)
+  constexpr int SLD = 32 * (NBO > 0 ? NBO : 1) + 4;  // OP: padded row of a wave-private staging tile
+  constexpr int QCH = 256 / (NS >= 4 ? NS : 4);      // QP: model channels a wavefront contracts over
   constexpr int NBLK = ATT_KEYS / NS / 32;  // key blocks per wavefront
   constexpr int RPW = 16 / NS;              // accumulator rows finished per wavefront in the merge
   // key-split merge buffer [NS][16][64]; the out-projection epilogue reuses it as 4 wave-private staging tiles [32][68]
-  constexpr int LDS_BUF = OP ? (4 * 32 * 68 > NS * 16 * 64 ? 4 * 32 * 68 : NS * 16 * 64) : NS * 16 * 64;
+  constexpr int LDS_BUF = OP ? (NS * 32 * SLD > NS * 16 * 64 ? NS * 32 * SLD : NS * 16 * 64) : NS * 16 * 64;
   __shared__ __attribute__((aligned(16))) float lds_buf[LDS_BUF];
   float (*lds_o)[16][64] = reinterpret_cast<float (*)[16][64]>(lds_buf);
   __shared__ float lds_m[NS][32];
@@ -84,11 +87,11 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
   f32x4 kf[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kg + j * 8);
-  f32x4 wof[2][4];   // OP: W_out fragment of this wave's two 32-column blocks (B operand: lane n = l31, k = head dims)
+  f32x4 wof[NBO > 0 ? NBO : 1][4];   // OP: W_out fragment of this wave's 32-column blocks (B operand: lane n = l31, k = head dims)
   if constexpr (OP) {
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const float* worow = fz.wo + (size_t)((wave * 2 + nb) * 32 + l31) * 256 + head * ATT_HD + hh * 4;
+    for (int nb = 0; nb < NBO; ++nb) {
+      const float* worow = fz.wo + (size_t)((wave * NBO + nb) * 32 + l31) * 256 + head * ATT_HD + hh * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) wof[nb][j] = *reinterpret_cast<const f32x4*>(worow + j * 8);
     }
@@ -106,23 +109,24 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) qacc[r] = 0.f;
     // every load is unconditional (rows past nq re-read row 0 of the pair and are never stored): a per-element
     // "load or zero" select would make the compiler branch around each load and wait for it - 16 dependent L2 round trips
-    const float* wrow = fz.wq + (size_t)(head * ATT_HD + l31) * 256 + wave * 64 + hh * 4;
-    const float* xrow = fz.x + qrow * 256 + wave * 64 + hh * 4;
-    f32x4 wa[8], xb[8];
+    constexpr int QJ = QCH / 8;
+    const float* wrow = fz.wq + (size_t)(head * ATT_HD + l31) * 256 + wave * QCH + hh * 4;
+    const float* xrow = fz.x + qrow * 256 + wave * QCH + hh * 4;
+    f32x4 wa[QJ], xb[QJ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wa[j] = *reinterpret_cast<const f32x4*>(wrow + j * 8);
+    for (int j = 0; j < QJ; ++j) wa[j] = *reinterpret_cast<const f32x4*>(wrow + j * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8);
+    for (int j = 0; j < QJ; ++j) xb[j] = *reinterpret_cast<const f32x4*>(xrow + j * 8);
     if constexpr (QP == 2) {
-      const float* x2row = fz.x2 + qrow * 256 + wave * 64 + hh * 4;
-      f32x4 x2b[8];
+      const float* x2row = fz.x2 + qrow * 256 + wave * QCH + hh * 4;
+      f32x4 x2b[QJ];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) x2b[j] = *reinterpret_cast<const f32x4*>(x2row + j * 8);
+      for (int j = 0; j < QJ; ++j) x2b[j] = *reinterpret_cast<const f32x4*>(x2row + j * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xb[j] += x2b[j];
+      for (int j = 0; j < QJ; ++j) xb[j] += x2b[j];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < QJ; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e) qacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][e], xb[j][e], qacc, 0, 0, 0);
 #pragma unroll
@@ -233,12 +237,12 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
     // partial[head][row][n] = sum_d O[row][d] * Wo[n][head*32 + d]: wave w -> output columns [64w, 64w + 64).  The accumulators
     // go through a wave-private LDS tile so that the partial rows leave as float4 (one instruction = 4 rows x 256 B) instead of
     // 32 scattered dword stores per lane
-    float* stage = lds_buf + wave * (32 * 68);    // aliases lds_o: every wave is past the merge (barrier above)
+    float* stage = lds_buf + wave * (32 * SLD);   // aliases lds_o: every wave is past the merge (barrier above)
     f32x4 af[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(&lds_out[l31][j * 8 + hh * 4]);
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NBO; ++nb) {
       f32x16 pacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
@@ -247,15 +251,17 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e) pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], wof[nb][j][e], pacc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * 68 + nb * 32 + l31] = pacc[r];
+      for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * SLD + nb * 32 + l31] = pacc[r];
     }
-    float* pbase = fz.part + ((size_t)head * fz.rows_total + (size_t)pair * nq) * 256 + wave * 64;
-    const int sr = lane >> 4, sc = (lane & 15) * 4;
+    float* pbase = fz.part + ((size_t)head * fz.rows_total + (size_t)pair * nq) * 256 + wave * (32 * NBO);
+    constexpr int LPR = 8 * NBO;                  // lanes (float4) per staged row
+    constexpr int RPI = 64 / LPR;                 // rows per wave instruction
+    const int sr = lane / LPR, sc = (lane % LPR) * 4;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 4 + sr;
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int row = it * RPI + sr;
       const int qo = qtile * 32 + row;
-      const f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * 68 + sc]);
+      const f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * SLD + sc]);
       if (qo < nq) store_f32x4(pbase + (size_t)qo * 256 + sc, val, fz.wt != 0);
     }
     if (o == nullptr) return;
@@ -270,6 +276,8 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
 }
 
 static int g_att_splits = 0;  // 0 = automatic
+static int g_att_fused_splits = 0;  // 0 = default (4); set_attention_fused_splits
+void set_attention_fused_splits(int v) { g_att_fused_splits = (v == 4 || v == 8) ? v : 0; }
 static int g_att_part_wt = 1;  // write-through stores for the out-projection partials (set_attention_part_wt)
 void set_attention_part_wt(int v) { g_att_part_wt = v; }
 static int g_att_head_major = 0;  // measured: -88 MB of fabric traffic per forward, +0.4 % time -> off (cotr_set_xcd_mapping bit 3)
@@ -324,14 +332,24 @@ int launch_attention_fused(const float* q, int ldq, const float* x, const float*
   fz.x = x ? x : x2; fz.x2 = x ? x2 : nullptr; fz.wq = wq; fz.bq = bq; fz.qscale = qscale;
   fz.wo = wo; fz.part = part; fz.rows_total = nb * nq; fz.wt = g_att_part_wt;
   const int qmode = !qp ? 0 : (fz.x2 ? 2 : 1);
-#define ATT_LAUNCH(QPV, OPV)                                                                                              \
-  hipLaunchKernelGGL((attention_kernel<4, QPV, OPV>), grid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz)
-  if (qmode == 2 && op) ATT_LAUNCH(2, true);
-  else if (qmode == 2) ATT_LAUNCH(2, false);
-  else if (qmode == 1 && op) ATT_LAUNCH(1, true);
-  else if (qmode == 1) ATT_LAUNCH(1, false);
-  else if (op) ATT_LAUNCH(0, true);
-  else ATT_LAUNCH(0, false);
+  // 8 key splits (8 wavefronts per workgroup) were tried where 4 leave CUs without a workgroup (the encoder of one pair is
+  // 16 query tiles x 8 heads = 128 workgroups on 256 CUs): measured 0.978 vs 0.973 ms per forward, the merge of 8 partial
+  // softmaxes and the narrower out-projection blocks cost more than the idle CUs -- kept as a knob only
+  const int ns = g_att_fused_splits ? g_att_fused_splits : 4;
+#define ATT_LAUNCH(NSV, QPV, OPV)                                                                                         \
+  hipLaunchKernelGGL((attention_kernel<NSV, QPV, OPV>), grid, dim3(NSV * 64), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz)
+#define ATT_PICK(NSV)                              \
+  do {                                             \
+    if (qmode == 2 && op) ATT_LAUNCH(NSV, 2, true);   \
+    else if (qmode == 2) ATT_LAUNCH(NSV, 2, false);   \
+    else if (qmode == 1 && op) ATT_LAUNCH(NSV, 1, true); \
+    else if (qmode == 1) ATT_LAUNCH(NSV, 1, false);   \
+    else if (op) ATT_LAUNCH(NSV, 0, true);            \
+    else ATT_LAUNCH(NSV, 0, false);                   \
+  } while (0)
+  if (ns == 8) ATT_PICK(8);
+  else ATT_PICK(4);
+#undef ATT_PICK
 #undef ATT_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

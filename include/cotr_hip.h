@@ -300,6 +300,9 @@ int cotr_set_fused_stem(int enable);
  *   bit 4     fused FFN: plain write-back stores for the partial outputs instead of the default write-through (sc1) ones
  * Experiments / profiling only; see DESIGN.md for the measured trade-off. */
 int cotr_set_xcd_mapping(int policy);
+/* key splits of the FUSED attention variants (q-projection prologue / out-projection epilogue): 4, 8, or 0 = default (4; 8 measured
+ * slower even on the 128-workgroup encoder grid of one pair) */
+int cotr_set_attention_fused_splits(int ns);
 /* key splits (wavefronts per workgroup) of the attention kernel: 1, 2, 4, 8, 16, or 0 = automatic */
 int cotr_set_attention_splits(int ns);
 /* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured

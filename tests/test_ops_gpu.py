@@ -158,9 +158,19 @@ def test_attention_softmax_extremes(case):
         assert e < tol, (case, ns, e)
 
 
+@pytest.fixture
+def fused_splits(request):
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    assert lib.cotr_set_attention_fused_splits(request.param) == 0
+    yield request.param
+    lib.cotr_set_attention_fused_splits(0)
+
+
+@pytest.mark.parametrize('fused_splits', [4, 8], indirect=True)
 @pytest.mark.parametrize('nb,nq', [(1, 1000), (2, 77), (3, 1)])
-def test_attention_with_fused_projections(nb, nq):
-    """attention_kernel<4, QP, OP>: q projection in the prologue (decoder, transformer.py:192 with the packed in_proj of
+def test_attention_with_fused_projections(nb, nq, fused_splits):
+    """attention_kernel<4 or 8, QP, OP>: q projection in the prologue (decoder, transformer.py:192 with the packed in_proj of
     nn.MultiheadAttention: q = Wq(tgt + query_pos) * head_dim^-0.5) and out_proj in the epilogue as 8 per-head partial
     outputs that ln_reduce sums (+ bias + residual + LayerNorm, transformer.py:195-198), against fp64 torch."""
     from cotr_amd import _lib
