@@ -96,6 +96,9 @@ _PROTOS = {
     'cotr_set_head_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_splits': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_fused_splits': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_attention_wide_min_rows': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_pos_table_min_rows': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_attention_wide_occupancy': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_fused_stem': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_dual_conv': (ctypes.c_int, [ctypes.c_int]),

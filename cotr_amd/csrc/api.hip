@@ -29,6 +29,8 @@
 int init_attention_attributes();
 void set_attention_splits(int ns);
 void set_attention_fused_splits(int v);
+void set_attention_wide_min_rows(long v);
+void set_attention_wide_occupancy(int v);
 
 namespace {
 
@@ -62,6 +64,7 @@ struct Arena {
 thread_local std::string g_create_error;
 int g_head_fuse_max_rows = 0;     // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower at 1000 rows: 63 workgroups each pull all 512 KB of weights; off)
 int g_attn_fuse_max_rows = 1024;  // attention with the out-projection (and, in the decoder, the q projection) fused in, up to this many rows
+int g_pos_table_min_rows = 8192;  // token rows from which the encoder in-projection / decoder K-V projection take pos . W^T from the tables
 int g_ffn_fuse_max_rows = 1024;  // fused FFN block up to this many rows (forward at B=1,Q=1000: 1.064 vs 1.083 ms; slower from ~1300 rows on)
 }  // namespace
 
@@ -81,6 +84,12 @@ struct cotr_ctx {
   const float* mlp_w[3] = {nullptr, nullptr, nullptr};
   const float* mlp_b[3] = {nullptr, nullptr, nullptr};
   float* pos = nullptr;  // [512][256]
+  // pos . W^T of the encoder in-projections [L][512][768] (q|k columns, q pre-scaled; v columns zero) and of the hoisted decoder
+  // K/V projection [512][L*512] (k columns; v zero): (x + pos) . W^T = x . W^T + pos . W^T, and the second term depends on the
+  // weights only - with many rows it enters as a row-periodic residual of a plain GEMM on the LDS-DMA large-tile kernel instead
+  // of an x + pos prologue that only the register-staged kernels have (transformer.py:147-153, 192-195)
+  float* tab_qkv = nullptr;
+  float* tab_kv = nullptr;
   // cached encode
   Arena memkv;  // memory [B*512*256] then kv [B*512*L*512]
   int enc_B = 0;
@@ -152,10 +161,17 @@ struct DeviceScope {
 int ensure(cotr_ctx* h, Arena& a, size_t floats) {
   if (a.cap >= floats) return COTR_OK;
   if (h->ws != nullptr && (&a == &h->memkv || &a == &h->enc_scr || &a == &h->dec_scr)) {
-    // caller-supplied workspace: bump allocation, 256-byte aligned; nothing is freed or allocated on the device (no
-    // synchronisation in the middle of a stream).  A region that has to grow takes a new carve: the caller sizes the
-    // workspace with cotr_scratch_bytes for the largest (B, Q) it will pass.
-    const size_t off = (h->ws_used + 255) & ~size_t(255);
+    // caller-supplied workspace: the three regions lie in the fixed order [encode cache | encoder scratch | decoder scratch],
+    // 256-byte aligned; nothing is freed or allocated on the device (no synchronisation in the middle of a stream).  A region
+    // that has to grow grows in place and the regions behind it are re-carved at their next use (they hold scratch only: the
+    // encode cache is the first region and only grows inside encode, which rewrites it) - so a workspace sized with
+    // cotr_scratch_bytes for the largest (B, Q) serves every smaller shape in any order.
+    Arena* order[3] = {&h->memkv, &h->enc_scr, &h->dec_scr};
+    size_t off = 0;
+    int idx = 0;
+    for (; order[idx] != &a; ++idx)
+      if (order[idx]->ptr) off = (size_t)(reinterpret_cast<char*>(order[idx]->ptr) - h->ws) + order[idx]->cap * sizeof(float);
+    off = (off + 255) & ~size_t(255);
     if (off + floats * sizeof(float) > h->ws_bytes) {
       char msg[160];
       snprintf(msg, sizeof msg, "workspace too small: %zu bytes given, %zu needed so far (size it with cotr_scratch_bytes)",
@@ -166,6 +182,7 @@ int ensure(cotr_ctx* h, Arena& a, size_t floats) {
     a.ptr = reinterpret_cast<float*>(h->ws + off);
     a.cap = floats;
     a.external = true;
+    for (int j = idx + 1; j < 3; ++j) *order[j] = Arena();
     h->ws_used = off + floats * sizeof(float);
     return COTR_OK;
   }
@@ -219,13 +236,13 @@ GemmParams base_params() {
 // y[M,N] = epi( (x (+x2)) . w^T )
 int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_period, int a2_width,
            const float* w, const float* bias, const float* residual, int relu, float colscale, int colscale_n,
-           float* y, int M, int N, int K, hipStream_t s, int ldc = 0) {
+           float* y, int M, int N, int K, hipStream_t s, int ldc = 0, int res_row_mod = 0) {
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K;
   p.A = x; p.lda = K;
   p.A2 = x2; p.lda2 = K; p.a2_row_mod = x2_row_mod; p.a2_period = a2_period; p.a2_width = a2_width;
   p.W = w; p.C = y; p.ldc = ldc ? ldc : N;
-  p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
+  p.bias = bias; p.residual = residual; p.ldr = N; p.res_row_mod = res_row_mod; p.relu = relu;
   p.colscale = colscale; p.colscale_n = colscale_n;
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, gemm_pick_config(GEMM_DENSE, p)); prof_mark(h, nm, s, 2); }
@@ -555,6 +572,7 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
     return COTR_ERR_WEIGHTS;
   }
 
+  const size_t tab_qkv = reserve((size_t)n_enc * TOK * 3 * D), tab_kv = reserve((size_t)TOK * n_dec * 2 * D);  // zeros; filled below
   HIPCHK(h, hipDeviceSynchronize());
   if (h->wbuf && h->wfloats < host.size()) {
     HIPCHK(h, hipFree(h->wbuf));
@@ -580,6 +598,17 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
   h->kv_w = base + kv_w; h->kv_b = base + kv_b;
   h->dn_w = base + dn_w; h->dn_b = base + dn_b;
   for (int i = 0; i < 3; ++i) { h->mlp_w[i] = base + mw[i]; h->mlp_b[i] = base + mb[i]; }
+  // pos . W^T tables (see cotr_ctx): q|k rows of every encoder in_proj (q scaled as the projection's epilogue scales it), k rows of
+  // every decoder layer's slice of the hoisted K/V weight; the v columns stay zero
+  h->tab_qkv = h->wbuf + tab_qkv;
+  h->tab_kv = h->wbuf + tab_kv;
+  for (int l = 0; l < n_enc; ++l)
+    if (int r = linear(h, h->pos, nullptr, 0, 1, 0, h->enc[l].in_w, nullptr, nullptr, 0, QSCALE, D,
+                       h->tab_qkv + (size_t)l * TOK * 3 * D, TOK, 2 * D, D, nullptr, 3 * D)) return r;
+  for (int l = 0; l < n_dec; ++l)
+    if (int r = linear(h, h->pos, nullptr, 0, 1, 0, h->kv_w + (size_t)l * 2 * D * D, nullptr, nullptr, 0, 1.f, 0,
+                       h->tab_kv + (size_t)l * 2 * D, TOK, D, D, nullptr, n_dec * 2 * D)) return r;
+  HIPCHK(h, hipStreamSynchronize(nullptr));
   h->loaded = true;
   h->enc_B = 0;  // a cached encode belongs to the old weights
   return COTR_OK;
@@ -706,7 +735,10 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     for (size_t li = 0; li < h->enc.size(); ++li) {
       const EncW& e = h->enc[li];
       // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
-      if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
+      if (M >= g_pos_table_min_rows) {
+        if ((r = linear(h, xin, nullptr, 0, 1, 0, e.in_w, e.in_b, h->tab_qkv + li * TOK * 3 * D, 0, QSCALE, D, t_qkv, M, 3 * D, D, s, 0, TOK)))
+          return r;
+      } else if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
       float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
       if (n_part != 0 && M <= g_attn_fuse_max_rows && M <= g_ffn_fuse_max_rows && !g_ffn_preln) {
         // out_proj inside the attention kernel (8 per-head partial outputs), summed + bias + residual + norm1 by ln_reduce
@@ -728,7 +760,9 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     prof_mark(h, "encoder", s);
     // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195)
     float* kv_c = kv + (size_t)b0 * TOK * KVLD;
-    if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
+    if (M >= g_pos_table_min_rows) {
+      if ((r = linear(h, mem_c, nullptr, 0, 1, 0, h->kv_w, h->kv_b, h->tab_kv, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s, 0, TOK))) return r;
+    } else if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
     prof_mark(h, "dec_kv", s);
   }
   if (feat_out) return COTR_OK;
@@ -915,15 +949,15 @@ int cotr_scratch_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   const size_t Bc = B < g_enc_chunk ? B : g_enc_chunk;
   const size_t per_pair = (size_t)128 * 256 * 64 + (size_t)64 * 128 * 64 + 5 * (size_t)64 * 128 * 256 +
                           6 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
-  const size_t q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
-  const size_t pairs_per = (Q > 0 && Q < DEC_ROWS) ? (DEC_ROWS / Q) : 1;
-  const size_t nb = (size_t)B < pairs_per ? B : pairs_per;
-  const size_t R = nb * q_chunk;
-  // (an upper bound over the fusion thresholds' settings: flipping a tuning knob must not make a sized workspace too small)
+  // Monotone in B and in Q, and an upper bound over the fusion thresholds' settings: a workspace sized for (B, Q) must serve
+  // every (B' <= B, Q' <= Q) - whose decoder passes can have MORE rows than (B, Q)'s own (2 x 16000 rows against 1 x 20000)
+  // and, below the thresholds, more scratch per row - and flipping a tuning knob must not make a sized workspace too small.
+  const size_t R = (size_t)B * Q < (size_t)DEC_ROWS ? (size_t)B * Q : (size_t)DEC_ROWS;
   const size_t thr_a = g_attn_fuse_max_rows > 1024 ? g_attn_fuse_max_rows : 1024, thr_f = g_ffn_fuse_max_rows > 1024 ? g_ffn_fuse_max_rows : 1024;
   const size_t f_memkv = (size_t)B * TOK * (D + L * 2 * D);
-  const size_t f_enc = per_pair * Bc + (Bc * TOK <= thr_a ? 8 * Bc * TOK * D : 0);
-  const size_t f_dec = R * (7 * D + (R <= thr_f ? 4 * FFN : FFN) + (R <= thr_a ? 8 * D : 0));
+  const size_t enc_rows = Bc * TOK;
+  const size_t f_enc = per_pair * Bc + 8 * (enc_rows < thr_a ? enc_rows : thr_a) * D;
+  const size_t f_dec = R * (7 * D + FFN) + (R < thr_f ? R : thr_f) * 3 * FFN + (R < thr_a ? R : thr_a) * 8 * D;
   size_t total = 0;
   for (size_t f : {f_memkv, f_enc, f_dec}) total = ((total + 255) & ~size_t(255)) + f * sizeof(float);
   *bytes = total + 256;
@@ -1222,6 +1256,22 @@ int cotr_set_xcd_mapping(int policy) {
 int cotr_set_attention_fused_splits(int ns) {
   if (ns != 0 && ns != 4 && ns != 8) return COTR_ERR_ARG;
   set_attention_fused_splits(ns);
+  return COTR_OK;
+}
+
+int cotr_set_pos_table_min_rows(int rows) {
+  g_pos_table_min_rows = rows < 0 ? 0 : rows;
+  return COTR_OK;
+}
+
+int cotr_set_attention_wide_occupancy(int waves_per_simd) {
+  if (waves_per_simd != 2 && waves_per_simd != 3) return COTR_ERR_ARG;
+  set_attention_wide_occupancy(waves_per_simd);
+  return COTR_OK;
+}
+
+int cotr_set_attention_wide_min_rows(int rows) {
+  set_attention_wide_min_rows(rows);
   return COTR_OK;
 }
 

@@ -275,6 +275,178 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
   }
 }
 
+
+// ---- many query rows (the batched engine calls, the dense pass) --------------------------------------------------------------
+// Two 32-query tiles per wavefront (64 queries per workgroup): every K and V fragment a wavefront fetches feeds both tiles, which
+// halves the L2 -> CU traffic and the load instructions per flop of the kernel above (its 128 KB of K_h/V_h per 32 queries is
+// 4.6 TB/s out of L2 at 32768 rows), and the two tiles are independent MFMA chains: the softmax VALU of one tile sits next to
+// the matrix instructions of the other in the instruction stream.  Same arithmetic per query as attention_kernel<NS, 0, false>
+// (same key split, same merge order) - results are bit-identical to it.
+// OCC = wavefronts per SIMD the register budget is set for: 2 keeps the Q fragments in registers (210 VGPRs), 3 parks them in LDS
+// (8 KB per workgroup, re-read per key block) to fit 168
+template <int NS, int OCC>
+__global__ __launch_bounds__(NS * 64, OCC) void attention_wide_kernel(const float* __restrict__ q, int ldq,
+                                                                 const float* __restrict__ k,
+                                                                 const float* __restrict__ v, int ldkv,
+                                                                 float* __restrict__ o, int ldo, int nq, int head_major) {
+  constexpr int NBLK = ATT_KEYS / NS / 32;
+  constexpr int RPW = 16 / NS;
+  __shared__ __attribute__((aligned(16))) float lds_o[NS][2][16][64];
+  __shared__ float lds_m[NS][2][32];
+  __shared__ float lds_l[NS][2][32];
+  __shared__ __attribute__((aligned(16))) float lds_out[64][36];
+  constexpr bool QL = OCC >= 3;
+  __shared__ __attribute__((aligned(16))) f32x4 lds_q[QL ? 2 * 4 * 64 : 1];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int qtiles = gridDim.x >> 3;
+  const int head = head_major ? (blockIdx.x & 7) : (blockIdx.x / qtiles);
+  const int qtile = head_major ? (blockIdx.x >> 3) : (blockIdx.x % qtiles);
+  const int pair = blockIdx.z;
+
+  const size_t key0 = (size_t)pair * ATT_KEYS + (size_t)wave * (ATT_KEYS / NS);
+  const float* kg = k + (key0 + l31) * ldkv + head * ATT_HD + hh * 4;
+  const float* vg = v + (key0 + 4 * hh) * ldkv + head * ATT_HD + l31;
+  f32x4 kf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kg + j * 8);
+
+  f32x4 qf[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int qi = qtile * 64 + u * 32 + l31;
+    const bool q_ok = qi < nq;
+    const size_t qrow = (size_t)pair * nq + (q_ok ? qi : 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qf[u][j] = *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4);
+      qf[u][j] *= q_ok ? 1.44269504088896340736f : 0.f;   // log2 domain; rows past nq compute on zeros and are never stored
+    }
+  }
+  if constexpr (QL) {
+    if (wave == 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds_q[(u * 4 + j) * 64 + lane] = qf[u][j];
+    }
+    __syncthreads();
+  }
+  f32x16 oacc[2];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[u][r] = 0.f;
+    m_run[u] = -INFINITY;
+    l_run[u] = 0.f;
+  }
+
+#pragma unroll 1
+  for (int kb = 0; kb < NBLK; ++kb) {
+    float vf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vf[r] = vg[(size_t)(kb * 32 + (r & 3) + 8 * (r >> 2)) * ldkv];
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 qv = QL ? lds_q[(u * 4 + j) * 64 + lane] : qf[u][j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j][e], qv[e], s[u], 0, 0, 0);
+      }
+    if (kb + 1 < NBLK) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kf[j] = *reinterpret_cast<const f32x4*>(kg + (size_t)(kb + 1) * 32 * ldkv + j * 8);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float mx = s[u][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[u][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[u], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[u][r] = __builtin_amdgcn_exp2f(s[u][r] - m_new);
+        psum += s[u][r];
+      }
+      l_run[u] = l_run[u] * alpha + psum;
+      m_run[u] = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[u][r] *= alpha;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], s[u][r], oacc[u], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // ---- merge the NS key splits (fixed order, as attention_kernel) -------------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    l_run[u] += __shfl_xor(l_run[u], 32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds_o[wave][u][r][lane] = oacc[u][r];
+    if (hh == 0) {
+      lds_m[wave][u][l31] = m_run[u];
+      lds_l[wave][u][l31] = l_run[u];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float m_all = lds_m[0][u][l31];
+#pragma unroll
+    for (int w = 1; w < NS; ++w) m_all = fmaxf(m_all, lds_m[w][u][l31]);
+    float f[NS];
+    float l_all = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+      f[w] = __builtin_amdgcn_exp2f(lds_m[w][u][l31] - m_all);
+      l_all += f[w] * lds_l[w][u][l31];
+    }
+    const float inv = 1.f / l_all;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave * RPW + i;
+      float acc = 0.f;
+#pragma unroll
+      for (int w = 0; w < NS; ++w) acc += f[w] * lds_o[w][u][r][lane];
+      lds_out[u * 32 + l31][(r & 3) + 8 * (r >> 2) + 4 * hh] = acc * inv;
+    }
+  }
+  __syncthreads();
+  for (int i = t; i < 512; i += NS * 64) {  // 64 rows x 128 B, one float4 per thread
+    const int row = i >> 3, c4 = (i & 7) * 4;
+    const int qo = qtile * 64 + row;
+    if (qo < nq)
+      *reinterpret_cast<f32x4*>(o + ((size_t)pair * nq + qo) * ldo + head * ATT_HD + c4) =
+          *reinterpret_cast<const f32x4*>(&lds_out[row][c4]);
+  }
+}
+
+// 3 wavefronts per SIMD measured 162-164 us at 32768 query rows against 168-193 for 2 (and 206 for the 32-query kernel).  An in-wave
+// software pipeline pinned with sched_group_barrier (softmax of one tile between the MFMAs of the other) measured the same 164 us:
+// hipcc honours the pattern for the score MFMAs only, and three wavefronts per SIMD already interleave the phases in hardware.
+static int g_att_wide_occ = 3;  // set_attention_wide_occupancy
+void set_attention_wide_occupancy(int v) { g_att_wide_occ = v == 2 ? 2 : 3; }
+static int g_att_wide_head_major = 1;  // set_attention_wide_head_major
+void set_attention_wide_head_major(int v) { g_att_wide_head_major = v != 0; }
+static long g_att_wide_min_rows = 4096;  // query rows of a launch from which the 64-query kernel is used (set_attention_wide_min_rows)
+void set_attention_wide_min_rows(long v) { g_att_wide_min_rows = v < 0 ? 0 : v; }
+
 static int g_att_splits = 0;  // 0 = automatic
 static int g_att_fused_splits = 0;  // 0 = default (4); set_attention_fused_splits
 void set_attention_fused_splits(int v) { g_att_fused_splits = (v == 4 || v == 8) ? v : 0; }
@@ -290,9 +462,19 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
                      int nb, int nq, hipStream_t s) {
   if (nb <= 0 || nq <= 0) return 0;
   if (ldq % 4 || ldkv % 4 || ldo % 4) return -1;
+  int ns = g_att_splits;
+  if (ns == 0 && (long)nb * nq >= g_att_wide_min_rows) {
+    dim3 wgrid(((nq + 63) / 64) * 8, 1, nb);
+    // head-major workgroup order here (head = XCD): with many pairs in flight every XCD then keeps one head's K/V slice of each
+    // pair in its L2 instead of all eight (32 pairs x 1000 queries: 176 -> 163 us; one pair: no difference)
+    if (g_att_wide_occ == 3)
+      hipLaunchKernelGGL((attention_wide_kernel<4, 3>), wgrid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_wide_head_major);
+    else
+      hipLaunchKernelGGL((attention_wide_kernel<4, 2>), wgrid, dim3(256), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_wide_head_major);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   dim3 grid(((nq + 31) / 32) * 8, 1, nb);
   AttnFuse fz = {};
-  int ns = g_att_splits;
   if (ns == 0) ns = 4;
   switch (ns) {
     case 1:

@@ -75,6 +75,7 @@ struct GemmParams {
   const float* bias;
   const float* residual;
   int ldr;
+  int res_row_mod;     // > 0: the residual is a row-periodic table, row m reads residual[m % res_row_mod] (large-tile kernels only)
   int relu;
   float colscale;
   int colscale_n;

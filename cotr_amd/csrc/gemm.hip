@@ -777,6 +777,7 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
     if (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15))) return false;
     return p.N % (64 * c.tn) == 0;
   }
+  if (p.res_row_mod > 0) return false;  // row-periodic residual tables: large-tile kernels only
   const int bn = c.tn == 0 ? 16 : (c.kind == 0 ? 2 : 1) * c.tn * 32;
   if (c.kind != 0) {  // dynamic LDS of the k-split kernels must fit the CU's 160 KB
     const size_t rows = (size_t)c.tm * 32 + (c.tn == 0 ? 16 : c.tn * 32);

@@ -130,7 +130,8 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int m = m0 + wm * 64 + a * 32 + it * RPI + er;
-        res[a][it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(m < p.M ? m : 0) * p.ldr + ncol);
+        const int mr = m < p.M ? (p.res_row_mod > 0 ? m % p.res_row_mod : m) : 0;
+        res[a][it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mr * p.ldr + ncol);
       }
   }
   int st = 0;                                           // stage of tile kt

@@ -303,6 +303,15 @@ int cotr_set_xcd_mapping(int policy);
 /* key splits of the FUSED attention variants (q-projection prologue / out-projection epilogue): 4, 8, or 0 = default (4; 8 measured
  * slower even on the 128-workgroup encoder grid of one pair) */
 int cotr_set_attention_fused_splits(int ns);
+/* encoder in-projections and the hoisted decoder K/V projection over at least this many token rows take the pos . W^T term
+ * from tables computed at cotr_load_weights (a row-periodic residual of a plain GEMM on the LDS-DMA large-tile kernel) instead of
+ * adding pos to the activations in a register prologue; default 8192 (16 pairs) */
+int cotr_set_pos_table_min_rows(int rows);
+/* launches with at least this many query rows (pairs x queries) use the 64-queries-per-workgroup attention kernel (two query
+ * tiles per wavefront share every K/V fragment); bit-identical results; default 4096; only when attention_splits is automatic */
+int cotr_set_attention_wide_min_rows(int rows);
+/* register budget of that kernel: 3 wavefronts per SIMD with Q parked in LDS (default), or 2 with Q in registers */
+int cotr_set_attention_wide_occupancy(int waves_per_simd);
 /* key splits (wavefronts per workgroup) of the attention kernel: 1, 2, 4, 8, 16, or 0 = automatic */
 int cotr_set_attention_splits(int ns);
 /* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured

@@ -158,6 +158,39 @@ def test_attention_softmax_extremes(case):
         assert e < tol, (case, ns, e)
 
 
+@pytest.mark.parametrize('occ', [2, 3])
+@pytest.mark.parametrize('nb,nq', [(1, 1), (3, 77), (2, 64), (1, 65), (2, 1000), (5, 2048)])
+def test_attention_wide_kernel_is_bit_identical(nb, nq, occ):
+    """attention_wide_kernel (64 queries per workgroup, two query tiles per wavefront; taken from 4096 query rows up) does the
+    arithmetic of attention_kernel<4> per query - same key split, same merge order - so its output must be bit-identical, ragged
+    last tiles included, and both must match the fp64 reference (transformer.py:149-153, 192-195)."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(nb * 7919 + nq)
+    q = torch.randn(nb * nq, 256, generator=g) * 3.0 / math.sqrt(32)
+    kv = torch.randn(nb * 512, 512, generator=g)
+    qh = q.double().view(nb, nq, 8, 32).permute(0, 2, 1, 3)
+    kh = kv[:, :256].double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    vh = kv[:, 256:].double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).permute(0, 2, 1, 3).reshape(nb * nq, 256)
+    d = G.dev()
+    qd, kvd = q.to(d), kv.to(d)
+    outs = []
+    try:
+        for min_rows in (1 << 30, 0):
+            assert lib.cotr_set_attention_wide_min_rows(min_rows) == 0
+            assert lib.cotr_set_attention_wide_occupancy(occ) == 0
+            o = torch.full((nb * nq + 1, 256), float('nan'), device=d)      # one guard row behind the output
+            assert lib.cotr_op_attention(G.P(qd), 256, G.P(kvd), G.P(kvd[:, 256:]), 512, G.P(o), 256, nb, nq, G.sptr()) == 0
+            assert torch.isnan(o[-1]).all()
+            outs.append(o[:-1])
+    finally:
+        lib.cotr_set_attention_wide_min_rows(4096)
+        lib.cotr_set_attention_wide_occupancy(3)
+    assert torch.equal(outs[0], outs[1])
+    assert G.rel_err(outs[1], ref) < 2e-5
+
+
 @pytest.fixture
 def fused_splits(request):
     from cotr_amd import _lib

@@ -58,6 +58,34 @@ def test_golden_vectors_from_the_reference(name, golden_dir):
         assert float((mem - torch.from_numpy(g['memory'])).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize('name', ['ragged_b2_q257', 'peaky16_b1_q64', 'flat_b1_q64'])
+def test_pos_tables_and_wide_attention_on_the_golden_cases(name, golden_dir):
+    """The many-rows forms - pos . W^T taken from the tables of cotr_load_weights as a row-periodic residual of the in-projection
+    GEMMs (instead of adding pos to the activations, transformer.py:147-153,192-195) and the 64-query attention kernel - forced onto
+    the small golden cases of the reference: same bars as the default path."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    wseed, gain = make_golden.CASES[name][:2]
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    sd, img, qs = make_golden.case_inputs(name)
+    m = hip_model(wseed, gain)
+    base = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    try:
+        assert lib.cotr_set_pos_table_min_rows(0) == 0 and lib.cotr_set_attention_wide_min_rows(0) == 0
+        assert lib.cotr_set_attention_fusion_max_rows(0) == 0
+        out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    finally:
+        lib.cotr_set_pos_table_min_rows(8192)
+        lib.cotr_set_attention_wide_min_rows(4096)
+        lib.cotr_set_attention_fusion_max_rows(1024)
+    ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), torch.from_numpy(g['pred_f64']))
+    bar = max(PX_BAR, 3 * ref_gap)
+    assert cotr_oracle.px_err(out, torch.from_numpy(g['pred_f64'])) < bar
+    assert cotr_oracle.px_err(out, base) < max(SHAPE_NOISE_PX, 3 * ref_gap)
+    if name != 'flat_b1_q64':      # (q = k = bias only: pos . W^T is zero there and the paths may agree bit for bit)
+        assert not torch.equal(out, base), 'the knobs did not change the path'
+
+
 def test_stage_taps_against_oracle():
     sd, img, qs = make_golden.case_inputs('ragged_b2_q257')
     taps = {}
@@ -277,6 +305,29 @@ def test_caller_supplied_workspace():
     assert rc == 0 and torch.equal(out, b)
     need = ctypes.c_size_t()
     assert lib.cotr_scratch_bytes(m._handle, 2, 40, ctypes.byref(need)) == 0 and need.value > (1 << 20)
+
+
+def test_workspace_serves_smaller_shapes_in_any_order():
+    """One workspace sized for the largest (B, Q) must serve every smaller shape in any order: few pairs x many queries, then
+    more pairs x few queries (the encoder scratch has to grow AFTER the decoder scratch was carved), then back - the order
+    tools/time_configs.py walks BASELINE.json's configs in.  Results equal those of a fresh model per shape."""
+    sd = synth_state_dict(0)
+    m = build_model(cotr_amd.default_args()).cuda().eval()
+    m.load_state_dict(sd)
+    m.reserve(4, 700)
+    ws = m._ws.data_ptr()
+    shapes = [(1, 700), (2, 300), (4, 16), (1, 700), (3, 1), (4, 700)]
+    outs = []
+    for b, q in shapes:
+        img, qs = synth_inputs(b, q, seed=100 + b * 1000 + q)
+        outs.append(m(img.cuda(), qs.cuda())['pred_corrs'].clone())
+        assert m._ws.data_ptr() == ws, 'the reserved workspace must be enough'
+    for (b, q), o in zip(shapes[1:4], outs[1:4]):
+        fresh = build_model(cotr_amd.default_args()).cuda().eval()
+        fresh.load_state_dict(sd)
+        img, qs = synth_inputs(b, q, seed=100 + b * 1000 + q)
+        assert torch.equal(fresh(img.cuda(), qs.cuda())['pred_corrs'], o), (b, q)
+    assert torch.equal(outs[0], outs[3])
 
 
 def test_dense_pass_shape_q131072():
