@@ -98,6 +98,7 @@ _PROTOS = {
     'cotr_set_attention_fused_splits': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_wide_min_rows': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_pos_table_min_rows': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_conv_patch': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_wide_occupancy': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_fused_stem': (ctypes.c_int, [ctypes.c_int]),

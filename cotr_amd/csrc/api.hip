@@ -260,7 +260,16 @@ int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float
 // partial outputs + ln_reduce (sum, bias, residual, norm); above: linear1, linear2 (+residual), layernorm.
 // `hid` holds max(M*1024, chunks*M*256) floats, `tmp` M*256.
 int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, const float* l2w, const float* l2b,
-              const float* nw, const float* nb, float* hid, float* tmp, float* y, int M, hipStream_t s) {
+              const float* nw, const float* nb, float* hid, float* tmp, float* y, int M, hipStream_t s,
+              const float* post_w = nullptr, const float* post_b = nullptr) {
+  if (post_w != nullptr) {   // (callers check ffn_block_takes_post_norm first)
+    const int nch = ffn_fused_chunks(M);
+    KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
+    if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
+    KCHK(h, launch_ln_reduce_post(hid, nch, l2b, x, nw, nb, post_w, post_b, y, M, s), "ln_reduce");
+    prof_mark(h, "ln_reduce +norm", s, 2);
+    return COTR_OK;
+  }
   if (M <= g_ffn_fuse_max_rows) {
     const int nch = ffn_fused_chunks(M);
     if (g_ffn_tail) {  // partial sums + bias + residual + LayerNorm by the last workgroup of each row tile: one launch
@@ -841,6 +850,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   const int R = nb * nq;
   int r;
   const bool fused = d.part != nullptr && R <= g_attn_fuse_max_rows && R <= g_ffn_fuse_max_rows && !g_ffn_preln;
+  bool hs_normed = false;
   if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s, fused))) return r;
   // transformer.py:185-201 per layer (cross-attention only, post-norm)
   for (int li = 0; li < L; ++li) {
@@ -854,7 +864,11 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       prof_mark(h, "qproj+attention+oproj dec", s, 2);
       KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
       prof_mark(h, "ln_reduce heads", s, 2);
-      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, d.tgt, R, s))) return r;
+      // last layer: decoder.norm rides in the same ln_reduce launch (its input has no other consumer); pre2 = the normed 'hs'
+      const bool post = li + 1 == L && !g_ffn_tail && R > g_head_fuse_max_rows;
+      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
+                         post ? h->dn_w : nullptr, post ? h->dn_b : nullptr))) return r;
+      hs_normed = post;
       continue;
     }
     // q = Wq(tgt + query_pos) * 32^-0.5 ; tgt == 0 at layer 0 (transformer.py:54): computed by dec_prologue
@@ -873,7 +887,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
     prof_mark(h, "dec_head norm+mlp", s, 2);
     return COTR_OK;
   }
-  if ((r = layernorm(h, d.tgt, h->dn_w, h->dn_b, d.pre2, R, s))) return r;
+  if (!hs_normed && (r = layernorm(h, d.tgt, h->dn_w, h->dn_b, d.pre2, R, s))) return r;
   if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s))) return r;
   if ((r = linear(h, d.ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d.q, R, D, D, s))) return r;
   KCHK(h, launch_head2(d.q, h->mlp_w[2], h->mlp_b[2], odst, nb, nq, Q, s), "head2");
@@ -1256,6 +1270,11 @@ int cotr_set_xcd_mapping(int policy) {
 int cotr_set_attention_fused_splits(int ns) {
   if (ns != 0 && ns != 4 && ns != 8) return COTR_ERR_ARG;
   set_attention_fused_splits(ns);
+  return COTR_OK;
+}
+
+int cotr_set_conv_patch(int enable) {
+  gemm_set_patch(enable != 0);
   return COTR_OK;
 }
 

@@ -123,7 +123,8 @@ bool gemm_cfg_supports_dual(int cfg);
 int gemm_num_configs();
 void gemm_set_xcd_policy(int v);  // 0 column tiles over XCDs, 1 by operand size (default), 2 row tiles over XCDs
 bool gemm_cfg_supports_ln(int cfg);
-void gemm_set_ks3(int v);  // 1 (default): three-stage LDS-DMA k-split instead of the two-stage one where K >= 768
+void gemm_set_ks3(int v);
+void gemm_set_patch(int v);  // 1 (default): three-stage LDS-DMA k-split instead of the two-stage one where K >= 768
 const float* gemm_zero_buffer();  // per-DEVICE buffer of zeros (LDS-DMA padding source), on the current device
 
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]
@@ -171,6 +172,8 @@ int launch_ffn_fused(const float* X, const float* W1, const float* b1, const flo
 // same + the reduce / bias / residual / LayerNorm tail inside the kernel (last-arriving workgroup of a row tile)
 int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
                         const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
+int launch_ln_reduce_post(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
+                          const float* post_w, const float* post_b, float* y, int rows, hipStream_t s);
 int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                      float* y, int rows, hipStream_t s);
 // the same two with the LayerNorm that precedes the FFN folded in: X / residual are the PRE-norm rows

@@ -258,7 +258,14 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   constexpr int PA = BM / 8, PW = BN / 8;  // passes: 8 rows per pass (NT / C4 == 8)
   constexpr int NB = N16 ? 1 : TM * TN;
   static_assert(NT / C4 == 8, "8 rows per pass");
-  constexpr int TILE = (BM + BN) * LD;  // floats per LDS stage (A rows then W rows)
+  // DB == 4 ("patch"): 3x3 stride-1 convolution over Cin = 256 channels (layer3) - a K step is exactly one tap, and the nine
+  // A tiles of a 32-pixel row segment are nine shifted views of the same 3 x 34 input pixels.  Those are loaded ONCE (102 rows
+  // of 1 KB instead of 9 x 32) and the taps read their A fragments from the patch at the tap's offset; the weights go straight
+  // to registers.  Everything the workgroup needs is requested up front: one memory round trip instead of nine half ones.
+  constexpr bool PATCH = (DB == 4);
+  constexpr int PROWS = 2 * 3 * 18;   // most patch rows: two 16-pixel segments (3 x 18 each); one 32-pixel segment is 3 x 34
+  static_assert(!PATCH || (MODE == GEMM_CONV && N16 && NWK == 8), "the patch variant is the 32 x 16 tile, 8 wavefronts, convolution");
+  constexpr int TILE = PATCH ? BN * LD : (BM + BN) * LD;  // floats per LDS stage (A rows then W rows; PATCH: W rows only)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int t = threadIdx.x;
@@ -458,7 +465,62 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
     }
   };
 
-  if constexpr (DB == 3) {
+  if constexpr (PATCH) {
+    // a 32-row tile is one 32-pixel segment of an output row (Wout a multiple of 32) or, on layer3's 16-wide halves, the two
+    // 16-pixel rows of the left and the right half (each with its own zero padding at the seam): nseg segments of seg pixels
+    const int seg = p.Wout == 16 ? 16 : 32, segrows = 3 * (seg + 2), nrows = (32 / seg) * segrows;
+    {
+      const int W2o = 2 * p.Wout;
+      const int b = m0 / (p.Hout * W2o);
+      const int rem = m0 - b * (p.Hout * W2o);
+      const int ho = rem / W2o;
+      const int wo = rem - ho * W2o;
+      const int side0 = wo / p.Wout;
+      const int wl0 = wo - side0 * p.Wout;
+      const float* img = p.A + (size_t)b * p.Hin * (2 * p.Win) * p.Cin + lane * 4;
+      for (int r = wave; r < nrows; r += NWK) {         // one wave instruction = one pixel (256 channels = 1 KB)
+        const int sg = r / segrows, rr = r - sg * segrows;
+        const int dy = rr / (seg + 2), j = rr - dy * (seg + 2);
+        const int hi = ho - 1 + dy, wi = wl0 - 1 + j;
+        const bool ok = hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
+        const float* src = ok ? img + ((size_t)hi * (2 * p.Win) + (size_t)(side0 + sg) * p.Win + wi) * p.Cin : p.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + r * LD), 16, 0, 0);
+      }
+    }
+    const int a1_off = (seg == 16 ? segrows : 16) * LD;  // tile rows 16..31: the second segment, or the same segment 16 pixels on
+    // Weights: global -> registers in MFMA operand layout, ALL nine taps requested before anything is waited for (18 b128 loads
+    // per lane).  The K loop of the staged variants is bound by latency x steps, not by bytes: with two tiles in flight a step
+    // costs half an L2-miss round trip (measured slope 1.2 us per 256-deep step; the patch alone, 43 % fewer bytes, gained
+    // nothing).  Here the whole working set of the workgroup - patch in LDS, weights in registers - is one round trip.
+    f32x4 wreg[9][2];
+    {
+      const float* wrow = p.W + (size_t)(n0 + l15) * p.K + wave * BK + q4 * 4;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) wreg[tap][jj] = *reinterpret_cast<const f32x4*>(wrow + tap * KS + jj * 16);
+    }
+    LDS_DMA_WAIT_ALL();
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const float* As = smem + (ky * (seg + 2) + kx) * LD;   // row i of a segment = pixel (ky, kx + i) of its patch
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int ko = wave * BK + jj * 16 + q4 * 4;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&As[l15 * LD + ko]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&As[l15 * LD + ko + a1_off]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], wreg[tap][jj][e], acc16[0], 0, 0, 0);
+          acc16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], wreg[tap][jj][e], acc16[1], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  } else if constexpr (DB == 3) {
     // Three LDS stages, TWO tiles of LDS-DMA in flight.  At one pair a CU holds a single workgroup and a K step's MFMAs
     // (0.2 us) cannot cover the L2 / Infinity-Cache latency of the next tile's DMA (~1.3 us): with two stages every step
     // costs one full DMA latency.  Here the wait before the barrier of step st is a COUNTED vmcnt that covers tile st only
@@ -633,6 +695,7 @@ static const GemmCfg kCfgs[] = {
     {5, 0, 2, 2},   // 28 large tile 128x128, three LDS stages (two tiles of LDS-DMA in flight, counted vmcnt)
     {5, 0, 2, 1},   // 29 large tile 128x64, three LDS stages
     {6, 8, 1, 0},   // 30 k-split 8 waves, 32x16, LDS-DMA with THREE stages (two tiles in flight, counted vmcnt)
+    {7, 8, 1, 0},   // 31 the same for 3x3 stride-1 convolutions over 256 channels with the input patch loaded once (DB == 4)
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -650,6 +713,7 @@ template <int NWK, int TM, int TN, int DB>
 static constexpr size_t ks_smem() {
   size_t rows = (size_t)TM * 32 + (TN == 0 ? 16 : TN * 32);
   size_t tile = (size_t)(DB == 3 ? 3 : DB ? 2 : 1) * rows * (NWK * BK + 4) * sizeof(float);
+  if (DB == 4) tile = (size_t)(2 * 3 * 18) * (NWK * BK + 4) * sizeof(float);  // the input patch (weights go to registers)
   size_t red = (size_t)NWK * (TN == 0 ? 8 : TM * TN * 16) * 64 * sizeof(float);
   return tile > red ? tile : red;
 }
@@ -691,8 +755,11 @@ static int launch_ks_dual(const GemmParams& p0, const GemmParams& p1, hipStream_
 
 template <int NWK, int TM, int TN, int MODE, int DB = 0>
 static int launch_ks(const GemmParams& p, hipStream_t s) {
-  if constexpr (DB >= 2) {
+  if constexpr (DB == 4 && MODE != GEMM_CONV) {
+    return -1;
+  } else if constexpr (DB >= 2) {
     if (p.A2 != nullptr) return -1;  // the x+pos prologue needs the register path
+    if (DB == 4 && !(p.ksize == 3 && p.stride == 1 && p.Cin == 256 && (p.Wout == 16 || p.Wout % 32 == 0) && p.M % 32 == 0)) return -1;
     GemmParams q = p;
     if (q.zeros == nullptr) q.zeros = gemm_zero_buffer();
     if (q.zeros == nullptr) return -2;
@@ -736,6 +803,7 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 28: return launch_gemm_big(MODE, 2, p, s);
     case 29: return launch_gemm_big(MODE, 3, p, s);
     case 30: return launch_ks<8, 1, 0, MODE, 3>(p, s);
+    case 31: return launch_ks<8, 1, 0, MODE, 4>(p, s);
     default: return -1;
   }
 }
@@ -778,6 +846,8 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
     return p.N % (64 * c.tn) == 0;
   }
   if (p.res_row_mod > 0) return false;  // row-periodic residual tables: large-tile kernels only
+  if (c.kind == 7)
+    return p.A2 == nullptr && p.ksize == 3 && p.stride == 1 && p.Cin == 256 && (p.Wout == 16 || p.Wout % 32 == 0) && p.M % 32 == 0 && p.N % 16 == 0;
   const int bn = c.tn == 0 ? 16 : (c.kind == 0 ? 2 : 1) * c.tn * 32;
   if (c.kind != 0) {  // dynamic LDS of the k-split kernels must fit the CU's 160 KB
     const size_t rows = (size_t)c.tm * 32 + (c.tn == 0 ? 16 : c.tn * 32);
@@ -816,11 +886,14 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
 
 static int g_ks3 = 1;  // gemm_set_ks3: use the three-stage LDS-DMA k-split (30) where the measured table says its two-stage form (24)
 void gemm_set_ks3(int v) { g_ks3 = v; }
+static int g_patch = 1;  // gemm_set_patch: 3x3 stride-1 convolutions over 256 channels load their input patch once (31) where the table says 24 / 30
+void gemm_set_patch(int v) { g_patch = v; }
 static int gemm_pick_config_table(int mode, const GemmParams& p);
 
 int gemm_pick_config(int mode, const GemmParams& p) {
   const int cfg = gemm_pick_config_table(mode, p);
   // few workgroups per CU (one pair): the three-stage form hides the DMA latency the two-stage one exposes at every K step
+  if (mode == GEMM_CONV && g_patch && (cfg == 24 || cfg == 30) && cfg_fits(31, p)) return 31;
   if (cfg == 24 && g_ks3 && p.K >= 3 * 256 && cfg_fits(30, p)) return 30;
   return cfg;
 }

@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ parts, int np, const float* __restrict__ bias,
                                                         const float* __restrict__ residual, const float* __restrict__ pre_w,
                                                         const float* __restrict__ pre_b, const float* __restrict__ w,
-                                                        const float* __restrict__ b, float* __restrict__ y, int rows) {
+                                                        const float* __restrict__ b, const float* __restrict__ post_w,
+                                                        const float* __restrict__ post_b, float* __restrict__ y, int rows) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -79,14 +80,32 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
   f32x4 out;
 #pragma unroll
   for (int i = 0; i < 4; ++i) out[i] = d[i] * rstd * ww[i] + bb[i];
+  if (post_w != nullptr) {   // a second LayerNorm of the result: decoder.norm after the last layer's norm3 (transformer.py:110-111)
+    const float m2 = wave_sum(out[0] + out[1] + out[2] + out[3]) * (1.f / 256.f);
+    const f32x4 d2 = {out[0] - m2, out[1] - m2, out[2] - m2, out[3] - m2};
+    const float v2 = wave_sum(d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2] + d2[3] * d2[3]) * (1.f / 256.f);
+    const float r2 = 1.f / sqrtf(v2 + 1e-5f);
+    const f32x4 w2 = *reinterpret_cast<const f32x4*>(post_w + lane * 4);
+    const f32x4 b2 = *reinterpret_cast<const f32x4*>(post_b + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = d2[i] * r2 * w2[i] + b2[i];
+  }
   *reinterpret_cast<f32x4*>(y + (size_t)row * 256 + lane * 4) = out;
+}
+
+int launch_ln_reduce_post(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
+                          const float* post_w, const float* post_b, float* y, int rows, hipStream_t s) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, nullptr, nullptr, w, b,
+                     post_w, post_b, y, rows);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const float* residual, const float* pre_w,
                          const float* pre_b, const float* w, const float* b, float* y, int rows, hipStream_t s) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, pre_w, pre_b, w, b, y,
-                     rows);
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, pre_w, pre_b, w, b,
+                     nullptr, nullptr, y, rows);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -303,6 +303,9 @@ int cotr_set_xcd_mapping(int policy);
 /* key splits of the FUSED attention variants (q-projection prologue / out-projection epilogue): 4, 8, or 0 = default (4; 8 measured
  * slower even on the 128-workgroup encoder grid of one pair) */
 int cotr_set_attention_fused_splits(int ns);
+/* 3x3 stride-1 convolutions over 256 input channels (layer3) at few pairs: load the 3 x 34 input pixels of a 32-pixel output
+ * row segment once and read the nine taps from that patch, instead of nine shifted A tiles (default on) */
+int cotr_set_conv_patch(int enable);
 /* encoder in-projections and the hoisted decoder K/V projection over at least this many token rows take the pos . W^T term
  * from tables computed at cotr_load_weights (a row-periodic residual of a plain GEMM on the LDS-DMA large-tile kernel) instead of
  * adding pos to the activations in a register prologue; default 8192 (16 pairs) */

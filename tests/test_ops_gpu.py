@@ -423,7 +423,8 @@ def test_every_gemm_config_conv():
     lib = _lib.load_library()
     d = G.dev()
     ran = 0
-    for B, H, cin, cout, k, stride in [(3, 16, 64, 128, 3, 1), (2, 16, 128, 256, 3, 2), (5, 8, 64, 256, 1, 1), (2, 32, 256, 128, 1, 2)]:
+    for B, H, cin, cout, k, stride in [(3, 16, 64, 128, 3, 1), (2, 16, 128, 256, 3, 2), (5, 8, 64, 256, 1, 1), (2, 32, 256, 128, 1, 2),
+                                       (2, 32, 256, 64, 3, 1)]:   # (the last one also fits the input-patch variant, cfg 31)
         g = _g(B + H + cin + cout)
         x = torch.randn(B, cin, H, 2 * H, generator=g)
         w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
@@ -445,6 +446,38 @@ def test_every_gemm_config_conv():
             assert e < 3e-5, (cfg, B, H, cin, cout, k, stride, e)
             ran += 1
     assert ran >= 80
+
+
+@pytest.mark.parametrize('B,H,W', [(1, 16, 16), (3, 16, 16), (1, 16, 32), (1, 32, 64), (2, 8, 32)])
+def test_conv3x3_input_patch_variant(B, H, W):
+    """cfg 31: 3x3 stride-1 convolution over 256 channels with the input pixels of a 32-row output tile (one 32-pixel row segment,
+    or on layer3's 16-wide halves the 16-pixel rows of both halves) loaded once (layer3's conv2 at few pairs, torchvision Bottleneck.conv2 + FrozenBatchNorm2d + ReLU): zero padding at the image
+    border AND at the seam between the two halves, against torch per half; it declines what it is not written for."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    cin, cout = 256, 256
+    g = _g(B * 1000 + H * 10 + W)
+    x = torch.randn(B, cin, H, 2 * W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    sc, b = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    pre = G.per_half(lambda t: F.conv2d(t, w, padding=1), x) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    res = torch.randn(pre.shape, generator=g)
+    ref = F.relu(pre + res)
+    d = G.dev()
+    xd, wd = G.nchw_to_sbs(x).to(d), G.pack_conv_weight(w).to(d)
+    scd, bd, rd = sc.to(d), b.to(d), G.nchw_to_sbs(res).to(d)
+    y = torch.full((B, H, 2 * W, cout), float('nan'), device=d)
+    assert lib.cotr_op_conv_cfg(G.P(xd), G.P(wd), G.P(scd), G.P(bd), G.P(rd), 1, G.P(y), B, H, W, cin, cout, 3, 1, 31, G.sptr()) == 0
+    assert G.rel_err(G.sbs_to_nchw(y.cpu()), ref) < 3e-5
+    y30 = torch.full_like(y, float('nan'))
+    assert lib.cotr_op_conv_cfg(G.P(xd), G.P(wd), G.P(scd), G.P(bd), G.P(rd), 1, G.P(y30), B, H, W, cin, cout, 3, 1, 30, G.sptr()) == 0
+    assert torch.equal(y, y30)          # same contraction order per wavefront, same reduction: bit-identical to the 9-tile form
+    # not its shape: stride 2, 1x1, 128 channels, a width that is not a multiple of 32
+    for (ci, k, st, ww) in ((256, 3, 2, W), (256, 1, 1, W), (128, 3, 1, W), (256, 3, 1, 8)):
+        xx = torch.zeros(1, H, 2 * ww, ci, device=d)
+        wx = torch.zeros(cout, k * k * ci, device=d)
+        yy = torch.zeros(1, H // st, 2 * (ww // st), cout, device=d)
+        assert lib.cotr_op_conv_cfg(G.P(xx), G.P(wx), G.P(scd), G.P(bd), None, 1, G.P(yy), 1, H, ww, ci, cout, k, st, 31, G.sptr()) != 0
 
 
 @pytest.mark.parametrize('B,H,cin,c_ds,c_1,stride', [(1, 64, 64, 256, 64, 1), (1, 64, 256, 512, 128, 2), (1, 32, 512, 1024, 256, 2),
