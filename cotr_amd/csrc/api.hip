@@ -1346,6 +1346,23 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
   return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
 }
 
+// one convolution launch with the k-split kernels' phase timestamps written to `times` (device, [workgroups][8] uint64, 100 MHz
+// wall clock; slots 0..4 = entry, loads issued, first data usable, K loop done, stored): tools/conv_phases.py
+int cotr_debug_conv_times(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int Hin, int Win,
+                          int Cin, int Cout, int ksize, int stride, int cfg, unsigned long long* times, cotr_stream stream) {
+  GemmParams p = base_params();
+  const int pad = ksize / 2;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin;
+  p.Hout = (Hin + 2 * pad - ksize) / stride + 1;
+  p.Wout = (Win + 2 * pad - ksize) / stride + 1;
+  p.ksize = ksize; p.stride = stride; p.pad = pad;
+  p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
+  p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout;
+  p.scale = scale; p.bias = bias; p.relu = 1;
+  p.dbg = times;
+  return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
+}
+
 // two independent convolutions of the same block input in one launch (tests): both outputs, explicit config
 int cotr_op_conv_dual_cfg(const float* x, const float* w0, const float* scale0, const float* bias0, int relu0, float* y0, int Cout0,
                           int ksize0, int stride0, const float* w1, const float* scale1, const float* bias1, int relu1, float* y1,

@@ -81,6 +81,8 @@ struct GemmParams {
   int colscale_n;
   const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
   int xcd_msplit;      // workgroup -> tile mapping, see gemm_tile_coords
+  unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock) written by wavefront 0 of the
+                            // k-split kernels: entry, loads issued, first data usable, K loop done, stored (cotr_debug_conv_times)
 };
 
 // blockIdx -> (row tile, column tile).  Consecutive workgroups land on consecutive XCDs (8, each with its own 4 MB L2), so the

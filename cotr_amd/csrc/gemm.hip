@@ -271,7 +271,16 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   const int t = threadIdx.x;
   int m0, n0;
   if (!gemm_tile_coords(p, BM, BN, bid, m0, n0)) return;
-  const int lr = t / C4, lc4 = t % C4;
+#define KS_STAMP(slot)                                                        \
+  do {                                                                        \
+    if (p.dbg != nullptr && t == 0) p.dbg[(size_t)bid * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+  KS_STAMP(0);
+  // with 8 wavefronts a wavefront loads whole rows (C4 == 64 lanes per row): the row index, and with it all of the row's
+  // addressing (the convolution's pixel decomposition: three integer divisions per row), is wave-uniform - taken through
+  // readfirstlane it runs on the scalar unit instead of per lane behind exec-masked branches
+  const int lr = (C4 == 64) ? __builtin_amdgcn_readfirstlane(t / C4) : t / C4;
+  const int lc4 = t % C4;
   const int ktl = lc4 >> 3;            // which 32-wide k-tile of the step this thread loads
   const int lcc = (lc4 & 7) * 4;       // column inside that k-tile
   const int KT = p.K / BK;
@@ -469,6 +478,14 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
     // a 32-row tile is one 32-pixel segment of an output row (Wout a multiple of 32) or, on layer3's 16-wide halves, the two
     // 16-pixel rows of the left and the right half (each with its own zero padding at the seam): nseg segments of seg pixels
     const int seg = p.Wout == 16 ? 16 : 32, segrows = 3 * (seg + 2), nrows = (32 / seg) * segrows;
+    const int a1_off = (seg == 16 ? segrows : 16) * LD;  // tile rows 16..31: the second segment, or the same segment 16 pixels on
+    // Everything the workgroup needs is requested up front, in the order it is used: [patch rows of input row dy, weights of the
+    // three taps ky = dy] for dy = 0, 1, 2.  Measured with the phase stamps (tools/conv_phases.py): the K loop is bound by what
+    // one CU can pull while all 256 pull at once (~35-40 GB/s per CU, 9-10 TB/s chip-wide out of the L2s) - 442 KB per workgroup
+    // in the 9-tile form (10.6 us), 259 KB here (7.4 us) - and the tile's MFMAs are 4.5 us on top unless they overlap the tail of
+    // the loads: the taps of input row dy start as soon as ITS rows and weights have landed (counted vmcnt: every wavefront issues
+    // exactly 5 patch DMAs + 6 weight loads per phase, idle DMA slots go to a dummy row).
+    f32x4 wreg[9][2];
     {
       const int W2o = 2 * p.Wout;
       const int b = m0 / (p.Hout * W2o);
@@ -477,36 +494,61 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
       const int wo = rem - ho * W2o;
       const int side0 = wo / p.Wout;
       const int wl0 = wo - side0 * p.Wout;
-      const float* img = p.A + (size_t)b * p.Hin * (2 * p.Win) * p.Cin + lane * 4;
-      for (int r = wave; r < nrows; r += NWK) {         // one wave instruction = one pixel (256 channels = 1 KB)
-        const int sg = r / segrows, rr = r - sg * segrows;
-        const int dy = rr / (seg + 2), j = rr - dy * (seg + 2);
-        const int hi = ho - 1 + dy, wi = wl0 - 1 + j;
-        const bool ok = hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
-        const float* src = ok ? img + ((size_t)hi * (2 * p.Win) + (size_t)(side0 + sg) * p.Win + wi) * p.Cin : p.zeros;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + r * LD), 16, 0, 0);
+      // all of the patch addressing is wave-uniform (a wave instruction moves one pixel): kept on the scalar unit by taking the
+      // wavefront index through readfirstlane - per-lane integer divisions and exec-masked branches around every DMA were 4 us
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const float* img = p.A + (size_t)b * p.Hin * (2 * p.Win) * p.Cin;
+      const float* wrow = p.W + (size_t)(n0 + l15) * p.K + wave * BK + q4 * 4;
+      const int per_dy = (32 / seg) * (seg + 2);          // 36 (two 16-pixel segments) or 34 patch rows per input row
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {                     // one wave instruction = one pixel (256 channels = 1 KB)
+          const int sl = wv + NWK * i;                    // slot 0..39 of this phase
+          const int sg = (seg == 16 && sl >= 18) ? 1 : 0, j = sl - sg * 18;
+          const int hi = ho - 1 + dy, wi = wl0 - 1 + j;
+          const bool slot_ok = sl < per_dy;
+          const bool ok = slot_ok && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
+          const float* base = ok ? img + ((size_t)hi * (2 * p.Win) + (size_t)(side0 + sg) * p.Win + wi) * p.Cin : p.zeros;
+          const float* src = base + (ok ? lane * 4 : 0);
+          const int r = slot_ok ? sg * segrows + dy * (seg + 2) + j : nrows;   // dummy row behind the patch
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(smem + r * LD), 16, 0, 0);
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+            // (asm: hipcc's own wait insertion falls back to vmcnt(0) in front of the first MFMA because of the scalar branches
+            // between the loads; the counted waits below cover these registers - they are issued in phase order)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wreg[dy * 3 + kx][jj]) : "v"(wrow + (dy * 3 + kx) * KS + jj * 16) : "memory");
       }
     }
-    const int a1_off = (seg == 16 ? segrows : 16) * LD;  // tile rows 16..31: the second segment, or the same segment 16 pixels on
-    // Weights: global -> registers in MFMA operand layout, ALL nine taps requested before anything is waited for (18 b128 loads
-    // per lane).  The K loop of the staged variants is bound by latency x steps, not by bytes: with two tiles in flight a step
-    // costs half an L2-miss round trip (measured slope 1.2 us per 256-deep step; the patch alone, 43 % fewer bytes, gained
-    // nothing).  Here the whole working set of the workgroup - patch in LDS, weights in registers - is one round trip.
-    f32x4 wreg[9][2];
-    {
-      const float* wrow = p.W + (size_t)(n0 + l15) * p.K + wave * BK + q4 * 4;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) wreg[tap][jj] = *reinterpret_cast<const f32x4*>(wrow + tap * KS + jj * 16);
-    }
-    LDS_DMA_WAIT_ALL();
-    __syncthreads();
+    KS_STAMP(1);
+    // per wavefront 33 loads are in flight, in use order: [5 patch DMAs, 2 weight loads of tap 3dy], [2 of tap 3dy+1], [2 of tap
+    // 3dy+2] for dy = 0, 1, 2.  A tap starts when its own data has landed (counted wait); only the first tap of an input row needs
+    // the barrier (patch rows come from every wavefront), the other two need this wavefront's own weight registers only.
+#define PATCH_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const float* As = smem + (ky * (seg + 2) + kx) * LD;   // row i of a segment = pixel (ky, kx + i) of its patch
+      const int dy = tap / 3, kx = tap - dy * 3;
+      switch (tap) {
+        case 0: PATCH_WAIT(26); break;
+        case 1: PATCH_WAIT(24); break;
+        case 2: PATCH_WAIT(22); break;
+        case 3: PATCH_WAIT(15); break;
+        case 4: PATCH_WAIT(13); break;
+        case 5: PATCH_WAIT(11); break;
+        case 6: PATCH_WAIT(4); break;
+        case 7: PATCH_WAIT(2); break;
+        default: PATCH_WAIT(0); break;
+      }
+      if (kx == 0) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tap == 0) KS_STAMP(2);
+      }
+      const float* As = smem + (dy * (seg + 2) + kx) * LD;   // row i of a segment = pixel (dy, kx + i) of its patch
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int ko = wave * BK + jj * 16 + q4 * 4;
@@ -519,6 +561,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
         }
       }
     }
+#undef PATCH_WAIT
     __syncthreads();
   } else if constexpr (DB == 3) {
     // Three LDS stages, TWO tiles of LDS-DMA in flight.  At one pair a CU holds a single workgroup and a K step's MFMAs
@@ -530,12 +573,14 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
     static_assert(PA + PW == 6, "the counted wait below is written for 6 DMA instructions per tile (32 x 16 tile, 8 waves)");
     dma_tile(0, 0);
     if (steps > 1) dma_tile(1, 1);
+    KS_STAMP(1);
     int stg = 0;
     for (int st = 0; st < steps; ++st) {
       if (st + 1 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");                    // no LDS access of this step may be scheduled above the barrier
+      if (st == 0) KS_STAMP(2);
       if (st + 2 < steps) dma_tile(st + 2, stg == 0 ? 2 : stg - 1);
       compute(stg);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are retired before the next barrier
@@ -581,6 +626,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   }
 
   // ---- cross-wave reduction through LDS: red[wave][block][r][lane] ----------------------------
+  KS_STAMP(3);
   float* red = smem;
   if constexpr (N16) {
     // D of 16x16x4: column = lane&15, row = (lane>>4)*4 + reg; 2 blocks x 4 regs = 8 slots per lane
@@ -606,6 +652,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
         p.C[(size_t)m * p.ldc + n] = v;
       }
     }
+    KS_STAMP(4);
     return;
   }
 #pragma unroll
@@ -713,7 +760,7 @@ template <int NWK, int TM, int TN, int DB>
 static constexpr size_t ks_smem() {
   size_t rows = (size_t)TM * 32 + (TN == 0 ? 16 : TN * 32);
   size_t tile = (size_t)(DB == 3 ? 3 : DB ? 2 : 1) * rows * (NWK * BK + 4) * sizeof(float);
-  if (DB == 4) tile = (size_t)(2 * 3 * 18) * (NWK * BK + 4) * sizeof(float);  // the input patch (weights go to registers)
+  if (DB == 4) tile = (size_t)(2 * 3 * 18 + 1) * (NWK * BK + 4) * sizeof(float);  // the input patch + a dummy row (weights go to registers)
   size_t red = (size_t)NWK * (TN == 0 ? 8 : TM * TN * 16) * 64 * sizeof(float);
   return tile > red ? tile : red;
 }

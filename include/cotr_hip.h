@@ -329,6 +329,11 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
                      int relu, float* y, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int cfg,
                      cotr_stream stream);
 
+/* one convolution launch whose k-split kernel writes phase timestamps (100 MHz wall clock) of every workgroup to `times`
+ * (device memory, [workgroups][8] uint64; slots 0..4 = entry, loads issued, first data usable, K loop done, stored) */
+int cotr_debug_conv_times(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int Hin, int Win,
+                          int Cin, int Cout, int ksize, int stride, int cfg, unsigned long long* times, cotr_stream stream);
+
 /* two independent convolutions of the SAME input in one launch under config `cfg` (the dual-launch path of the entry blocks) */
 int cotr_op_conv_dual_cfg(const float* x, const float* w0, const float* scale0, const float* bias0, int relu0, float* y0, int Cout0,
                           int ksize0, int stride0, const float* w1, const float* scale1, const float* bias1, int relu1, float* y1,
