@@ -249,20 +249,15 @@ def _query_encoding(queries):
     return out
 
 
-def forward_train(model, img, queries, features=None):
-    """``COTR.forward`` in training mode -> pred_corrs [B,Q,2] with an autograd graph over the trainable part; every
-    operation of the graph is a HIP kernel (cotr_amd/train_ops.py).  Row layout is batch-major: row b*L + l is token / query
-    l of pair b.  The query encoding carries no gradient (``NerfPositionalEncoding.forward`` is ``@torch.no_grad()``,
-    COTR/models/position_encoding.py:40-45): in the cycle pass ``model(img, pred)`` nothing flows back through ``pred``."""
+def encode_train(model, features, b):
+    """input_proj + the 6 encoder layers (cotr_model.py:37, transformer.py:143-159) on ``features`` [b*512, 1024] ->
+    (memory, memory + pos), each [b*512, 256], with an autograd graph; every operation is a HIP kernel (train_ops.py)."""
     from . import train_ops as T
     tr = model.transformer
     nheads, d = tr.nhead, tr.d_model
     assert d == 256 and nheads == 8
     scale = float(d // nheads) ** -0.5
-    b, nq, _ = queries.shape
-    if features is None:
-        features = backbone_features_trainable(model, img) if _backbone_trains(model) else backbone_features(model, img)
-    pos = _pos_table(img.device, d)
+    pos = _pos_table(features.device, d)
     src = T.linear(features, model.input_proj.weight.view(d, CFEAT), model.input_proj.bias)            # cotr_model.py:37
     for layer in tr.encoder.layers:                                                                    # transformer.py:143-159
         p = float(layer.self_attn.dropout) if model.training else 0.0
@@ -273,7 +268,19 @@ def forward_train(model, img, queries, features=None):
         src = T.AddDropLN.apply(src, ao, layer.norm1.weight, layer.norm1.bias, p)
         hid = T.linear(src, layer.linear1.weight, layer.linear1.bias, relu=True, p=p)
         src = T.AddDropLN.apply(src, T.linear(hid, layer.linear2.weight, layer.linear2.bias), layer.norm2.weight, layer.norm2.bias, p)
-    memory, mem_pos = src, T.AddRows.apply(src, pos, TOK)
+    return src, T.AddRows.apply(src, pos, TOK)
+
+
+def decode_train(model, memory, mem_pos, queries):
+    """The 6 cross-attention decoder layers, decoder.norm and corr_embed (transformer.py:185-201,110-111, cotr_model.py:34-39)
+    for ``queries`` [B,Q,2] against ``memory`` [B*512, 256] -> pred_corrs [B,Q,2].  The query encoding carries no gradient
+    (``NerfPositionalEncoding.forward`` is ``@torch.no_grad()``, COTR/models/position_encoding.py:40-45): in the cycle pass
+    ``model(img, pred)`` nothing flows back through ``pred``."""
+    from . import train_ops as T
+    tr = model.transformer
+    nheads, d = tr.nhead, tr.d_model
+    scale = float(d // nheads) ** -0.5
+    b, nq, _ = queries.shape
     query_pos = _query_encoding(queries)                                                               # cotr_model.py:34-36
     tgt = None                                                                                         # zeros, transformer.py:54
     for layer in tr.decoder.layers:                                                                    # transformer.py:185-201
@@ -291,6 +298,16 @@ def forward_train(model, img, queries, features=None):
     x = T.linear(hs, mlp[0].weight, mlp[0].bias, relu=True)
     x = T.linear(x, mlp[1].weight, mlp[1].bias, relu=True)
     return T.Head.apply(x, mlp[2].weight, mlp[2].bias, b, nq)
+
+
+def forward_train(model, img, queries, features=None):
+    """``COTR.forward`` in training mode -> pred_corrs [B,Q,2] with an autograd graph over the trainable part; every
+    operation of the graph is a HIP kernel (cotr_amd/train_ops.py).  Row layout is batch-major: row b*L + l is token / query
+    l of pair b."""
+    if features is None:
+        features = backbone_features_trainable(model, img) if _backbone_trains(model) else backbone_features(model, img)
+    memory, mem_pos = encode_train(model, features, queries.shape[0])
+    return decode_train(model, memory, mem_pos, queries)
 
 
 def forward_train_torch(model, img, queries, features=None, _query_grad=False):
@@ -353,23 +370,34 @@ def forward_train_torch(model, img, queries, features=None, _query_grad=False):
 def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=True):
     """The loss of ``COTRTrainer.train_batch`` / ``validate_batch`` (cotr_trainer.py:124-142) -> (loss, pred)."""
     # no dropout / batch statistics in the backbone: the prediction and the cycle pass see the same features
-    feats = backbone_features_trainable(model, img) if _backbone_trains(model) else backbone_features(model, img)
-    pred = forward_train(model, img, query, feats)
-    loss = F.mse_loss(pred, target)
-    if cycle_consis and bidirectional:
-        cycle = forward_train(model, img, pred, feats)
-        mask = torch.norm(cycle - query, dim=-1) < 10 / MAX_SIZE
-        if mask.sum() > 0:
-            loss = loss + F.mse_loss(cycle[mask], query[mask])
-    elif cycle_consis:
+    feat_fn = backbone_features_trainable if _backbone_trains(model) else backbone_features
+    feats = feat_fn(model, img)
+    b = img.shape[0]
+    if not cycle_consis:
+        pred = forward_train(model, img, query, feats)
+        return F.mse_loss(pred, target), pred
+    # The cycle pass decodes the FIRST pass's prediction, but its encoder does not depend on it: both passes' encoders run as
+    # ONE batch of 2B pairs (each half with its own dropout realisation, as two separate calls would have) - half the encoder
+    # launches, GEMMs of twice the rows, one gradient accumulation per encoder parameter instead of two.
+    if bidirectional:
+        feats2 = feats                                                    # same image: cycle = model(img, pred)
+    else:
         img_rev = torch.cat([img[..., MAX_SIZE:], img[..., :MAX_SIZE]], dim=-1)
+        feats2 = feat_fn(model, img_rev)
+    memory, mem_pos = encode_train(model, torch.cat([feats, feats2], dim=0), 2 * b)
+    rows = b * TOK
+    pred = decode_train(model, memory[:rows], mem_pos[:rows], query)
+    loss = F.mse_loss(pred, target)
+    if bidirectional:
+        cycle = decode_train(model, memory[rows:], mem_pos[rows:], pred)
+    else:
         q_rev = pred.clone()
         q_rev[..., 0] = q_rev[..., 0] - 0.5
-        cycle = forward_train(model, img_rev, q_rev)
+        cycle = decode_train(model, memory[rows:], mem_pos[rows:], q_rev)
         cycle = torch.stack([cycle[..., 0] - 0.5, cycle[..., 1]], dim=-1)
-        mask = torch.norm(cycle - query, dim=-1) < 10 / MAX_SIZE
-        if mask.sum() > 0:
-            loss = loss + F.mse_loss(cycle[mask], query[mask])
+    mask = torch.norm(cycle - query, dim=-1) < 10 / MAX_SIZE
+    if mask.sum() > 0:
+        loss = loss + F.mse_loss(cycle[mask], query[mask])
     return loss, pred
 
 
