@@ -272,19 +272,25 @@ def run_train(args, dev, world, rank):
     model = build_model(cotr_amd.default_args(dropout=0.1)).to(dev)
     model.load_state_dict(synth_state_dict(0))
     model.train()
-    optim = training.optimizer_for(model, learning_rate=1e-4)
+    graphed = args.graphed_train
+    optim = training.optimizer_for(model, learning_rate=1e-4, capturable=graphed)
     g = torch.Generator().manual_seed(5 + rank)
     img = torch.randn(pairs, 3, 256, 512, generator=g).to(dev)
     query, target = torch.rand(pairs, nq, 2, generator=g).to(dev), torch.rand(pairs, nq, 2, generator=g).to(dev)
+    if graphed:      # the whole step (zero_grad .. optimizer step, gradient collectives included) as ONE captured HIP graph
+        gstep = training.GraphedTrainStep(model, optim, img, query, target, warmup=max(args.warmup, 2))
+        step = lambda: gstep(img, query, target)
+    else:            # COTRTrainer.train_batch as the reference runs it: eager launches, loss.item() every step
+        step = lambda: training.train_batch(model, optim, img, query, target)
     for _ in range(args.warmup):
-        training.train_batch(model, optim, img, query, target)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        training.train_batch(model, optim, img, query, target)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -303,6 +309,7 @@ def run_train(args, dev, world, rank):
             'config': {'workload': 'BASELINE.json configs[4]: 16 pairs x 200 queries per GPU, cycle consistency + bidirectional, '
                                    'dropout 0.1, Adam lr 1e-4, frozen backbone (stage 1 of the reference recipe)',
                        'pairs_per_gpu': pairs, 'queries_per_pair': nq,
+                       'step': 'captured HIP graph (GraphedTrainStep)' if graphed else 'eager train_batch',
                        'parallelism': f'data parallel x{world}, reduce-scatter + all-gather of the gradients' if world > 1 else 'single GPU'},
         }), flush=True)
 
@@ -313,6 +320,8 @@ def main():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', choices=['headline', 'batch256', 'train'], default='headline')
+    ap.add_argument('--graphed-train', action='store_true',
+                    help='--workload train: the step as ONE captured HIP graph (training.GraphedTrainStep) instead of eager train_batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='only the timed steps (for rocprofv3 runs)')
     ap.add_argument('--traffic', choices=['auto', 'measure', 'committed', 'none'], default='auto',

@@ -1386,6 +1386,11 @@ int cotr_train_ln_bwd(const float* dy, const float* s_in, const float* stats, co
                       float* dwb, int rows, float p, uint32_t seed, cotr_stream stream) {
   return op_ret(train_ln_bwd(dy, s_in, stats, w, ds, da, part, dwb, rows, p, seed, TS));
 }
+int cotr_train_set_dropout_salt(const unsigned int* salt) {
+  train_set_salt_ptr(salt);
+  return COTR_OK;
+}
+
 int cotr_train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, cotr_stream stream) {
   return op_ret(train_dropout_fwd(x, n, p, seed, TS));
 }

@@ -29,7 +29,9 @@ __device__ __forceinline__ uint64_t mask_index(int pair, int head, int nq, int q
 __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                              int ldk, const float* __restrict__ v, int ldv, float* __restrict__ o,
                                                              int ldo, float* __restrict__ lse, int nq, float qscale,
-                                                             uint32_t thresh, float inv_keep, uint32_t seed) {
+                                                             uint32_t thresh, float inv_keep, uint32_t seed,
+                                                             const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
   constexpr int NS = 4, NBLK = ATT_KEYS / NS / 32;
   __shared__ float lds_o[NS][16][64];
   __shared__ float lds_m[NS][32];
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
                                                           int ldk, const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
                                                           int ldo, const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dq, int lddq, int nq, float qscale, uint32_t thresh,
-                                                          float inv_keep, uint32_t seed) {
+                                                          float inv_keep, uint32_t seed, const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
   constexpr int NS = 4, NBLK = ATT_KEYS / NS / 32;
   __shared__ float lds_o[NS][16][64];
   __shared__ __attribute__((aligned(16))) float lds_out[32][36];
@@ -250,7 +253,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
                                                            int ldk, const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
                                                            int ldo, const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, int nq,
-                                                           float qscale, uint32_t thresh, float inv_keep, uint32_t seed) {
+                                                           float qscale, uint32_t thresh, float inv_keep, uint32_t seed,
+                                                           const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
   constexpr int NS = 4;
   __shared__ float lds_k[NS][16][64];
   __shared__ float lds_v[NS][16][64];
@@ -355,7 +360,7 @@ int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const 
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return -1;
   dim3 grid(((nq + 31) / 32) * 8, 1, nb);
   hipLaunchKernelGGL(attn_train_fwd_kernel, grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, lse, nq, qscale, train_thresh(p),
-                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -370,9 +375,9 @@ int train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const 
   hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, o, d_o, ldo, delta, rows);
   if (hipGetLastError() != hipSuccess) return -2;
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((nq + 31) / 32) * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse,
-                     delta, dq, lddq, nq, qscale, thresh, inv_keep, seed);
+                     delta, dq, lddq, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
   if (hipGetLastError() != hipSuccess) return -2;
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(16 * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dk,
-                     lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed);
+                     lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

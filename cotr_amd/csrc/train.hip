@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
                                                               const float* __restrict__ w, const float* __restrict__ b,
                                                               float* __restrict__ s_out, float* __restrict__ y,
                                                               float* __restrict__ stats, int rows, uint32_t thresh, float inv_keep,
-                                                              uint32_t seed) {
+                                                              uint32_t seed, const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
                                                      const float* __restrict__ stats, const float* __restrict__ w,
                                                      float* __restrict__ ds, float* __restrict__ da, float* __restrict__ part,
-                                                     int rows, int rows_per_wg, uint32_t thresh, float inv_keep, uint32_t seed) {
+                                                     int rows, int rows_per_wg, uint32_t thresh, float inv_keep, uint32_t seed,
+                                                     const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
   __shared__ __attribute__((aligned(16))) float red[2][4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const f32x4 ww = *reinterpret_cast<const f32x4*>(w + lane * 4);
@@ -151,7 +154,8 @@ __global__ __launch_bounds__(256) void add_rowmod_kernel(const float* __restrict
 
 // x *= mask / (1 - p), element index = offset of the element in x
 __global__ __launch_bounds__(256) void dropout_fwd_kernel(float* __restrict__ x, size_t n4, uint32_t thresh, float inv_keep,
-                                                          uint32_t seed) {
+                                                          uint32_t seed, const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   f32x4 v = *reinterpret_cast<f32x4*>(x + i * 4);
@@ -435,11 +439,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
 
+static thread_local const uint32_t* g_salt = nullptr;   // per host thread, like the current device
+const uint32_t* train_salt_ptr() { return g_salt; }
+void train_set_salt_ptr(const uint32_t* p) { g_salt = p; }
+
 int train_add_drop_ln_fwd(const float* x, const float* a, const float* w, const float* b, float* s_out, float* y, float* stats,
                           int rows, float p, uint32_t seed, hipStream_t s) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, a, w, b, s_out, y, stats, rows,
-                     train_thresh(p), p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+                     train_thresh(p), p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
   return LAUNCH_OK();
 }
 
@@ -457,7 +465,7 @@ int train_ln_bwd(const float* dy, const float* s_in, const float* stats, const f
   per = (per + 3) / 4 * 4;
   const int nwg = (rows + per - 1) / per;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nwg), dim3(256), 0, s, dy, s_in, stats, w, ds, da, part, rows, per, train_thresh(p),
-                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed);
+                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
   if (hipGetLastError() != hipSuccess) return -2;
   return train_sum_parts(part, nwg, (size_t)512, dwb, s);
 }
@@ -478,7 +486,7 @@ int train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, hipStream_t s)
   if (n == 0 || p <= 0.f) return 0;
   if (n % 4) return -1;
   hipLaunchKernelGGL(dropout_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, n / 4, train_thresh(p),
-                     1.f / (1.f - p), seed);
+                     1.f / (1.f - p), seed, train_salt_ptr());
   return LAUNCH_OK();
 }
 

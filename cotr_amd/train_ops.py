@@ -114,6 +114,12 @@ def colsum(x, out):
 _wt_cache = {}   # id(base tensor) -> (weakref to it, {(storage offset, shape): (version, W^T)})
 
 
+def clear_weight_cache():
+    """Drop the cached W^T tensors (GraphedTrainStep: a replayed graph updates the weights without bumping their Python-side
+    version counters, so entries made before / during capture would look current to a later eager step)."""
+    _wt_cache.clear()
+
+
 def weight_t(w):
     """w[N,K] -> contiguous w^T [K,N] by the HIP transpose kernel, cached until the parameter changes (optimiser step).
     The cache hangs on the identity of the parameter object (weak reference), not on its address: torch's allocator hands

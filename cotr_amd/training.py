@@ -367,8 +367,11 @@ def forward_train_torch(model, img, queries, features=None, _query_grad=False):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=True):
-    """The loss of ``COTRTrainer.train_batch`` / ``validate_batch`` (cotr_trainer.py:124-142) -> (loss, pred)."""
+def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=True, branch_free=False):
+    """The loss of ``COTRTrainer.train_batch`` / ``validate_batch`` (cotr_trainer.py:124-142) -> (loss, pred).
+    ``branch_free`` writes the masked cycle term without the reference's ``if mask.sum() > 0`` / boolean indexing (a host
+    synchronisation and a data-dependent shape, neither of which a captured HIP graph can hold): the masked squared error
+    summed and divided by the number of selected elements, 0 when none is selected - the same value."""
     # no dropout / batch statistics in the backbone: the prediction and the cycle pass see the same features
     feat_fn = backbone_features_trainable if _backbone_trains(model) else backbone_features
     feats = feat_fn(model, img)
@@ -396,9 +399,75 @@ def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=Tru
         cycle = decode_train(model, memory[rows:], mem_pos[rows:], q_rev)
         cycle = torch.stack([cycle[..., 0] - 0.5, cycle[..., 1]], dim=-1)
     mask = torch.norm(cycle - query, dim=-1) < 10 / MAX_SIZE
-    if mask.sum() > 0:
+    if branch_free:
+        sel = mask.unsqueeze(-1).to(cycle.dtype)
+        loss = loss + (((cycle - query) ** 2) * sel).sum() / (2.0 * sel.sum()).clamp(min=1.0)
+    elif mask.sum() > 0:
         loss = loss + F.mse_loss(cycle[mask], query[mask])
     return loss, pred
+
+
+class GraphedTrainStep:
+    """One optimisation step - zero_grad, ``compute_loss``, backward, [gradient averaging], ``optim.step()`` - captured ONCE as a
+    HIP graph and replayed: the ~1000 launches of a step cost one graph launch of host time instead of ~20 ms of Python.
+
+        step = GraphedTrainStep(model, optimizer_for(model, capturable=True), img, query, target)
+        loss, pred = step(img, query, target)            # tensors; loss.item() when the value is needed
+
+    What capture needs and how it is met: static input buffers (copied into per call); no allocation or synchronisation
+    inside the library (workspace from torch's allocator, cotr_set_workspace); the loss without host branches
+    (``branch_free``); Adam with ``capturable=True``; and dropout masks that change from replay to replay although every
+    launch's seed argument is frozen in the graph - the training kernels XOR their seed with a salt word in device memory
+    (``cotr_train_set_dropout_salt``) that the captured step advances itself.
+    Difference to ``train_batch``: the reference skips backward when the loss is NaN (cotr_trainer.py:145-147); a graph cannot
+    skip, so ``__call__(..., check=True)`` raises after the fact instead (the weights have then seen the NaN step)."""
+
+    def __init__(self, model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None, warmup=3):
+        from . import train_ops as T
+        assert model.training and img.is_cuda
+        assert all(g.get('capturable', False) for g in optim.param_groups), 'build the optimiser with capturable=True'
+        self.model, self.optim, self.group = model, optim, group
+        self.args = (cycle_consis, bidirectional)
+        self.img, self.query, self.target = img.clone(), query.clone(), target.clone()
+        self.salt = torch.zeros(1, dtype=torch.int32, device=img.device)
+        lib = _lib.load_library()
+        _lib.check(lib.cotr_train_set_dropout_salt(self.salt.data_ptr()), None, 'cotr_train_set_dropout_salt')
+        side = torch.cuda.Stream(device=img.device)
+        side.wait_stream(torch.cuda.current_stream(img.device))
+        with torch.cuda.stream(side):                      # PyTorch's whole-network capture recipe: warm up on a side stream
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(img.device).wait_stream(side)
+        torch.cuda.synchronize(img.device)
+        T.clear_weight_cache()                             # transposes made during capture must live in the graph's pool
+        self.graph = torch.cuda.CUDAGraph()
+        optim.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss, self.pred = self._body()
+        T.clear_weight_cache()                             # (their Python handles may go: the pool keeps the memory for the graph)
+
+    def _body(self):
+        self.salt.add_(0x3C6EF35F)                         # a new mask family per step (int32 wrap-around is fine)
+        self.optim.zero_grad(set_to_none=True)
+        loss, pred = compute_loss(self.model, self.img, self.query, self.target, *self.args, branch_free=True)
+        loss.backward()
+        import torch.distributed as dist
+        if self.group is not None or (dist.is_available() and dist.is_initialized()):
+            sync_gradients([p for g in self.optim.param_groups for p in g['params']], self.group)
+        self.optim.step()
+        return loss.detach(), pred.detach()
+
+    def __call__(self, img, query, target, check=False):
+        self.img.copy_(img)
+        self.query.copy_(query)
+        self.target.copy_(target)
+        self.graph.replay()
+        if check and not bool(torch.isfinite(self.loss)):
+            raise FloatingPointError('loss is not finite in a captured training step (train_batch would have skipped it)')
+        return self.loss, self.pred
+
+    def close(self):
+        _lib.load_library().cotr_train_set_dropout_salt(None)
 
 
 def train_batch(model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None):
@@ -436,7 +505,7 @@ def sync_gradients(params, group=None, bucket_elems=1 << 25):
     sync_gradients_sharded(params, group, bucket_elems)
 
 
-def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0):
+def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0, capturable=False):
     """``torch.optim.Adam(optim_list)`` of train_cotr.py:49-57 - group for group, including the EMPTY ``query_proj``
     group (the encoding has no parameters), so that ``optim_state_dict`` of a reference checkpoint loads here and the
     other way round (Adam requires the same number of param groups)."""
@@ -446,7 +515,7 @@ def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0):
               {'params': list(model.input_proj.parameters()), 'lr': learning_rate}]
     if lr_backbone > 0:
         groups.append({'params': list(model.backbone.parameters()), 'lr': lr_backbone})
-    return torch.optim.Adam(groups)
+    return torch.optim.Adam(groups, capturable=capturable)
 
 
 def save_checkpoint(path, model, optim, epoch, iteration):

@@ -188,6 +188,11 @@ int cotr_train_ln_bwd_parts(int rows);
 /* ds = d loss / d s (= dx), da = ds * mask / (1-p) (may be NULL), dwb [512] = dgamma | dbeta; part: parts * 512 floats */
 int cotr_train_ln_bwd(const float* dy, const float* s_in, const float* stats, const float* w, float* ds, float* da, float* part,
                       float* dwb, int rows, float p, uint32_t seed, cotr_stream stream);
+/* Captured (hipGraph) training steps: the seed argument of a dropout launch is baked into the graph, so every training kernel that
+ * draws a mask XORs its seed with the word at `salt` (device memory, read at kernel start); the captured step advances that word
+ * itself (any device-side add), so each replay draws fresh masks and forward / backward of one step agree.  NULL (default) = the
+ * seeds alone.  Per host thread. */
+int cotr_train_set_dropout_salt(const unsigned int* salt);
 /* in place x *= mask / (1-p) (n % 4 == 0); backward of y = dropout(relu(h)): dx = y > 0 ? dy / (1-p) : 0 (p == 0: relu backward) */
 int cotr_train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, cotr_stream stream);
 int cotr_train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, float p, cotr_stream stream);
