@@ -295,6 +295,91 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The same contraction for the WIDE weights (linear1 / linear2 1024 x 256, input_proj, the packed q|k slice): 128 x 128 output
+// tile, 4 wavefronts each 64 x 64 (2 x 2 MFMA blocks: four MFMAs per pair of ds_read2_b32, against one MFMA per two ds_read_b32
+// in the 64 x 64 kernel), operands by LDS-DMA - a wave instruction moves two 128-wide tile rows (lanes 0-31 / 32-63), the tile
+// is stored unpadded (a fragment read is 32 consecutive dwords per half-wave: conflict-free at any row stride) - two stages,
+// two workgroups per CU.  Column sums of A (bias gradient) by the k-tile-0 workgroups from the landed A tile.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_tn_big_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                             float* __restrict__ part, int M, int N, int K, int rows_per_split,
+                                                             int with_colsum, const float* __restrict__ zeros) {
+  extern __shared__ __attribute__((aligned(16))) float tn_smem[];      // [2 stages][A 32 x 128 | B 32 x 128]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int tiles_k = K / 128;
+  const int n0 = (blockIdx.x / tiles_k) * 128, k0 = (blockIdx.x % tiles_k) * 128;
+  const int split = blockIdx.y;
+  const int m_begin = split * rows_per_split;
+  const int m_end = (m_begin + rows_per_split < M) ? m_begin + rows_per_split : M;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const bool do_colsum = with_colsum && k0 == 0;
+  float csum = 0.f;                                      // threads 0..127: column n0 + t of A over this split's rows
+
+  // wavefront w moves tile rows 8w .. 8w+7 of both operands: 4 DMA instructions per operand, each two rows
+  auto dma_chunk = [&](int m, int st) {
+    float* As = tn_smem + st * (2 * 32 * 128);
+    float* Bs = As + 32 * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wv * 8 + 2 * i;                      // (wave-uniform: the LDS destination)
+      const int row = m + r + hh;
+      const bool ok = row < m_end;
+      const float* sa = ok ? A + (size_t)row * N + n0 + l31 * 4 : zeros;
+      const float* sb = ok ? B + (size_t)row * K + k0 + l31 * 4 : zeros;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(As + r * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(Bs + r * 128), 16, 0, 0);
+    }
+  };
+  dma_chunk(m_begin, 0);
+  int st = 0;
+  for (int m = m_begin; m < m_end; m += 32) {
+    LDS_DMA_WAIT_ALL();
+    __syncthreads();                                     // chunk m has landed for everybody; the other stage is free
+    if (m + 32 < m_end) dma_chunk(m + 32, st ^ 1);
+    const float* As = tn_smem + st * (2 * 32 * 128);
+    const float* Bs = As + 32 * 128;
+    if (do_colsum && t < 128) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) csum += As[r * 128 + t];   // fixed order: rows ascending
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const float* ar = As + (2 * s2 + hh) * 128 + wn * 64 + l31;
+      const float* br = Bs + (2 * s2 + hh) * 128 + wk * 64 + l31;
+      const float a0 = ar[0], a1 = ar[32], b0 = br[0], b1 = br[32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    st ^= 1;
+  }
+  const size_t pstride = (size_t)N * K + (with_colsum ? N : 0);
+  float* out = part + (size_t)split * pstride;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        out[(size_t)n * K + k0 + wk * 64 + b * 32 + l31] = acc[a][b][r];
+      }
+  if (do_colsum && t < 128) out[(size_t)N * K + n0 + t] = csum;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Convolution backward of the trainable backbone stages (layer2 / layer3, COTR/models/backbone.py:66-69) by explicit
 // im2col: with col[m][(ky*k + kx)*Cin + c] = x[pixel(m) shifted by the tap][c] (zero where the tap leaves the 256-wide half:
 // the two halves of a side-by-side pair are padded separately, as in the forward kernels),
@@ -559,7 +644,19 @@ int train_transpose_batched(const float* src, float* dst, int batch, int R, int 
   return LAUNCH_OK();
 }
 
+static bool gemm_tn_use_big(int M, int N, int K) {
+  // (256 x 256 outputs measured the same on either kernel: four 128 x 128 tiles need 64 splits to fill the chip)
+  return N % 128 == 0 && K % 128 == 0 && (size_t)N * K >= (size_t)512 * 256 && M >= 2048;
+}
+
 int train_gemm_tn_splits(int M, int N, int K) {
+  if (gemm_tn_use_big(M, N, K)) {
+    const int tiles = (N / 128) * (K / 128);
+    int splits = (512 + tiles - 1) / tiles;               // two workgroups per CU
+    const int max_splits = (M + 255) / 256;               // at least 256 rows (8 chunks) per split
+    if (splits > max_splits) splits = max_splits;
+    return splits < 1 ? 1 : splits;
+  }
   const int tiles = (N / 64) * (K / 64);
   int splits = (512 + tiles - 1) / tiles;                 // about two workgroups per CU: more splits = more partial traffic
   const int max_splits = (M + 127) / 128;                 // at least 128 rows per split
@@ -579,8 +676,22 @@ int train_gemm_tn(const float* A, const float* B, float* part, float* out, float
   int per = (M + splits - 1) / splits;
   per = (per + 31) / 32 * 32;
   const int nsplit = (M + per - 1) / per;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((N / 64) * (K / 64), nsplit), dim3(256), 0, s, A, B, part, M, N, K, per,
-                     colsum != nullptr ? 1 : 0);
+  if (gemm_tn_use_big(M, N, K)) {
+    const float* zeros = gemm_zero_buffer();
+    if (zeros == nullptr) return -2;
+    static PerDeviceFlag attr_set;
+    constexpr size_t smem = 2 * 2 * 32 * 128 * sizeof(float);
+    if (!attr_set.get()) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem) != hipSuccess)
+        return -2;
+      attr_set.set();
+    }
+    hipLaunchKernelGGL(gemm_tn_big_kernel, dim3((N / 128) * (K / 128), nsplit), dim3(256), smem, s, A, B, part, M, N, K, per,
+                       colsum != nullptr ? 1 : 0, zeros);
+  } else
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((N / 64) * (K / 64), nsplit), dim3(256), 0, s, A, B, part, M, N, K, per,
+                       colsum != nullptr ? 1 : 0);
   if (hipGetLastError() != hipSuccess) return -2;
   return train_sum_parts(part, nsplit, (size_t)N * K + (colsum ? N : 0), out, s);
 }

@@ -51,7 +51,8 @@ def test_residual_layernorm_forward_backward(rows, with_x):
 
 
 @pytest.mark.parametrize('M,N,K,relu', [(1000, 256, 256, False), (8192, 1024, 256, True), (48, 256, 1024, False),
-                                        (1030, 512, 256, True), (200, 256, 1024, False)])
+                                        (1030, 512, 256, True), (200, 256, 1024, False),
+                                        (2100, 256, 1024, False), (4096, 512, 256, True), (16384, 1024, 256, True)])   # (the 128 x 128 TN kernel)
 def test_linear_forward_backward(M, N, K, relu):
     """Proj with one slice = nn.Linear (+ ReLU): dX on the cached W^T, dW by the transpose-free split-M kernel, db column sums."""
     g = _g(M + N + K)
