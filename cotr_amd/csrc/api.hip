@@ -1346,6 +1346,19 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
   return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
 }
 
+// the configuration the library would pick for this convolution (tools)
+int cotr_gemm_pick_conv(int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride) {
+  GemmParams p = base_params();
+  const int pad = ksize / 2;
+  p.Hin = Hin; p.Win = Win; p.Cin = Cin;
+  p.Hout = (Hin + 2 * pad - ksize) / stride + 1;
+  p.Wout = (Win + 2 * pad - ksize) / stride + 1;
+  p.ksize = ksize; p.stride = stride; p.pad = pad;
+  p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
+  p.lda = Cin; p.ldc = Cout; p.ldr = Cout;
+  return gemm_pick_config(GEMM_CONV, p);
+}
+
 // one convolution launch with the k-split kernels' phase timestamps written to `times` (device, [workgroups][8] uint64, 100 MHz
 // wall clock; slots 0..4 = entry, loads issued, first data usable, K loop done, stored): tools/conv_phases.py
 int cotr_debug_conv_times(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int Hin, int Win,

@@ -941,7 +941,8 @@ int gemm_pick_config(int mode, const GemmParams& p) {
   const int cfg = gemm_pick_config_table(mode, p);
   // few workgroups per CU (one pair): the three-stage form hides the DMA latency the two-stage one exposes at every K step
   if (mode == GEMM_CONV && g_patch && (cfg == 24 || cfg == 30) && cfg_fits(31, p)) return 31;
-  if (cfg == 24 && g_ks3 && p.K >= 3 * 256 && cfg_fits(30, p)) return 30;
+  // (not for the stride-2 3x3: measured 14.2 us on the two-stage form against 15.3 on the three-stage one, tools/conv_cfgs_in_situ.py)
+  if (cfg == 24 && g_ks3 && p.K >= 3 * 256 && !(mode == GEMM_CONV && p.stride == 2 && p.ksize == 3) && cfg_fits(30, p)) return 30;
   return cfg;
 }
 

@@ -334,6 +334,8 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
                      int relu, float* y, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride, int cfg,
                      cotr_stream stream);
 
+/* the launch configuration the library picks for this convolution (tools) */
+int cotr_gemm_pick_conv(int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride);
 /* one convolution launch whose k-split kernel writes phase timestamps (100 MHz wall clock) of every workgroup to `times`
  * (device memory, [workgroups][8] uint64; slots 0..4 = entry, loads issued, first data usable, K loop done, stored) */
 int cotr_debug_conv_times(const float* x, const float* w, const float* scale, const float* bias, float* y, int B, int Hin, int Win,
