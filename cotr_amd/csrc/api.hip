@@ -769,7 +769,9 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     prof_mark(h, "encoder", s);
     // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195)
     float* kv_c = kv + (size_t)b0 * TOK * KVLD;
-    if (M >= g_pos_table_min_rows) {
+    // (the hoisted K/V projection takes the table at any row count: 3072 columns fill the chip with large tiles even at one pair -
+    // 18 -> 14 us there; the encoder in-projections only from g_pos_table_min_rows on)
+    if (g_pos_table_min_rows < (1 << 30)) {
       if ((r = linear(h, mem_c, nullptr, 0, 1, 0, h->kv_w, h->kv_b, h->tab_kv, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s, 0, TOK))) return r;
     } else if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
     prof_mark(h, "dec_kv", s);

@@ -313,7 +313,8 @@ int cotr_set_attention_fused_splits(int ns);
 int cotr_set_conv_patch(int enable);
 /* encoder in-projections and the hoisted decoder K/V projection over at least this many token rows take the pos . W^T term
  * from tables computed at cotr_load_weights (a row-periodic residual of a plain GEMM on the LDS-DMA large-tile kernel) instead of
- * adding pos to the activations in a register prologue; default 8192 (16 pairs) */
+ * adding pos to the activations in a register prologue; default 8192 (16 pairs).  The K/V projection (3072 columns) takes its table
+ * at any row count unless rows >= 2^30 is set here (= tables off) */
 int cotr_set_pos_table_min_rows(int rows);
 /* launches with at least this many query rows (pairs x queries) use the 64-queries-per-workgroup attention kernel (two query
  * tiles per wavefront share every K/V fragment); bit-identical results; default 4096; only when attention_splits is automatic */
