@@ -29,6 +29,7 @@
 int init_attention_attributes();
 void set_attention_splits(int ns);
 void set_attention_fused_splits(int v);
+void set_ffn_debug_times(unsigned long long* p);  // ffn.hip
 void set_attention_wide_min_rows(long v);
 void set_attention_wide_occupancy(int v);
 
@@ -1346,6 +1347,14 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
   p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout;
   p.scale = scale; p.bias = bias; p.residual = residual; p.ldr = Cout; p.relu = relu;
   return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
+}
+
+// phase timestamps of the fused FFN launches that follow (device memory [workgroups][8], 100 MHz wall clock; slots: entry, loads
+// issued, first tile usable, H of sub-chunk 0 complete, phase 2 of sub-chunk 0 issued, second W1 usable, loop done, stored);
+// nullptr = off.  tools/ffn_phases.py
+int cotr_debug_ffn_times(unsigned long long* times) {
+  set_ffn_debug_times(times);
+  return COTR_OK;
 }
 
 // the configuration the library would pick for this convolution (tools)

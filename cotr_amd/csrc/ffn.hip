@@ -41,6 +41,7 @@ struct FfnParams {
   const float* ln_w;
   const float* ln_b;
   float* Y;          // [M][256]
+  unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock), cotr_debug_ffn_times
 };
 
 __device__ __forceinline__ float ffn_wave_sum(float v) {
@@ -58,6 +59,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
+#define FFN_STAMP(slot)                                                                      \
+  do {                                                                                       \
+    if (p.dbg != nullptr && t == 0) p.dbg[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+  FFN_STAMP(0);
   // chunk_major: chunk index fastest over consecutive workgroups (= consecutive XCDs): an XCD works on 1/8 of the hidden
   // units, so W1/W2 (2 MB per block) cross the fabric once chip-wide instead of once per XCD; X (<= 1 MB) is replicated
   const int tiles = gridDim.x / p.nch;
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
     }
   };
   dma_w1(0);
+  FFN_STAMP(1);
 
   if (p.pre_w != nullptr) {
     LDS_DMA_WAIT_ALL();
@@ -117,6 +124,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
     // W2[32*wave + l31][h0 + sub*64 + j*8 + hh*4 .. +3], j = 0..7
     LDS_DMA_WAIT_ALL();
     __syncthreads();  // X and W1_sub have landed, previous phase 2 is done with Hs
+    if (sub == 0) FFN_STAMP(2);
+    else if (sub == 1) FFN_STAMP(5);
     f32x4 w2f[8];     // issued after the barrier (which drains vmcnt), in flight under phase 1
     const float* w2g = p.W2 + (size_t)(32 * wave + l31) * FF_H + h0 + sub * 64 + hh * 4;
 #pragma unroll
@@ -153,6 +162,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
       }
     }
     __syncthreads();  // H complete
+    if (sub == 0) FFN_STAMP(3);
     if (sub + 1 < nsub) dma_w1(sub + 1);  // next W1 sub-chunk streams in under phase 2 (drained by the next barrier)
 
     // ---- phase 2 ---------------------------------------------------------------------------------
@@ -162,8 +172,10 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], w2f[j][e], acc2, 0, 0, 0);
     }
+    if (sub == 0) FFN_STAMP(4);
   }
 
+  FFN_STAMP(6);
   // partial output block of this wave: rows m0 + (r&3) + 8*(r>>2) + 4*hh, columns 32*wave + l31
   float* out = p.P + (size_t)chunk * p.M * FF_D;
   if (p.counters == nullptr) {
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
       const f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * 36 + sc]);
       if (m0 + row < p.M) store_f32x4(out + (size_t)(m0 + row) * FF_D + 32 * wave + sc, val, p.wt_partials != 0);
     }
+    FFN_STAMP(7);
     return;
   }
 #pragma unroll
@@ -239,6 +252,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
 
 static const size_t kFfnSmem = (size_t)(32 * FF_LD + 64 * FF_LD + 8 * 16 * 64 + 32 * FF_HLD) * sizeof(float);
 
+static thread_local unsigned long long* g_ffn_dbg = nullptr;   // set_ffn_debug_times: phase stamps of the next launches
+void set_ffn_debug_times(unsigned long long* p) { g_ffn_dbg = p; }
 static int g_ffn_wt = 1;  // cotr_set_xcd_mapping bit 4 clears it
 void set_ffn_write_through(int v) { g_ffn_wt = v; }
 static int g_ffn_chunk_major = 0;  // measured: -112 MB of fabric traffic per forward but +2 % time -> off (cotr_set_xcd_mapping bit 2)
@@ -304,6 +319,7 @@ static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_
   p.counters = nullptr; p.b2 = b2; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y;
   p.pre_w = pre_w; p.pre_b = pre_b;
   p.wt_partials = g_ffn_wt;
+  p.dbg = g_ffn_dbg;
   if (b2 != nullptr) {
     if (!residual || !ln_w || !ln_b || !Y || (M + 31) / 32 > 1024) return -1;
     p.counters = ffn_counters();
