@@ -7,8 +7,8 @@
 //
 // Grid: (rows/32) x NCH workgroups of 8 wavefronts; a workgroup owns 32 rows and 1024/NCH hidden units, walked in
 // sub-chunks of 64.  Per sub-chunk:
-//   phase 1  H[32 x 64] = X[32 x 256] . W1_sub[64 x 256]^T: wave w -> 32x32 block (w&1), K quarter (w>>1): 32 MFMAs,
-//            the 4 K-quarters summed through LDS in a fixed order, + b1, ReLU -> H in LDS
+//   phase 1  H[32 x 64] = X[32 x 256] . W1_sub[64 x 256]^T as 2 x 4 tiles of 16 x 16 (v_mfma_f32_16x16x4_f32): wave w -> ONE tile
+//            over the whole K = 256 (64 MFMAs), + b1, ReLU -> H in LDS; no cross-wave reduction
 //   phase 2  out[32 x 256] += H . W2[:, sub]^T: wave w -> output columns 32w..32w+31, K = 64: 32 MFMAs; the W2 operand
 //            goes global -> registers in MFMA layout (each element is used once per workgroup), prefetched under phase 1
 // X and W1 sub-chunks arrive by LDS-DMA (one wave instruction = one padded 1040-B row).
@@ -54,8 +54,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                       // [32][260]
   float* W1s = Xs + 32 * FF_LD;           // [64][260]
-  float* red = W1s + 64 * FF_LD;          // [8 waves][16][64]
-  float* Hs = red + 8 * 16 * 64;          // [32][68]
+  float* Hs = W1s + 64 * FF_LD;           // [32][68]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -117,7 +116,6 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   f32x16 acc2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-  const int blk = wave & 1, kq = wave >> 1;
 
   for (int sub = 0; sub < nsub; ++sub) {
     // W2 fragment of this sub-chunk for this wave's 32 output columns: lane (n = l31, half hh) holds
@@ -132,33 +130,33 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
     for (int j = 0; j < 8; ++j) w2f[j] = *reinterpret_cast<const f32x4*>(w2g + j * 8);
 
     // ---- phase 1 ---------------------------------------------------------------------------------
-    f32x16 acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ko = kq * 64 + j * 8 + hh * 4;
-      const f32x4 af = *reinterpret_cast<const f32x4*>(&Xs[l31 * FF_LD + ko]);
-      const f32x4 bf = *reinterpret_cast<const f32x4*>(&W1s[(blk * 32 + l31) * FF_LD + ko]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc1[r];
-    __syncthreads();  // partials visible; every wave is done reading W1s
+    // H[32 x 64] as 2 x 4 tiles of 16 x 16 on v_mfma_f32_16x16x4_f32: each of the 8 wavefronts owns ONE tile over the whole
+    // K = 256 (64 MFMAs = the matrix-pipe time of the former 32 x 32 blocks with K split four ways), so there is no cross-wave
+    // reduction: no 32 KB of partial accumulators through LDS, one barrier less (phase stamps: 4.1 us of which 1.9 were MFMA).
+    // Two accumulators (even / odd k groups) keep the MFMAs from waiting on their own result.
     {
-      // wave w finishes block (w&1), accumulator rows 4*(w>>1) .. +3: sum of the 4 K-quarters, + b1, ReLU -> Hs
-      const float b1v = p.b1[h0 + sub * 64 + blk * 32 + l31];
+      const int l15 = lane & 15, q4 = lane >> 4;
+      const int rb = wave & 1, cb = wave >> 1;
+      f32x4 ae = {0.f, 0.f, 0.f, 0.f}, ao = {0.f, 0.f, 0.f, 0.f};
+      const float* xr = &Xs[(rb * 16 + l15) * FF_LD + q4 * 4];
+      const float* wr = &W1s[(cb * 16 + l15) * FF_LD + q4 * 4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = kq * 4 + i;
-        float v = 0.f;
+      for (int kk = 0; kk < 16; kk += 2) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(xr + kk * 16), b0 = *reinterpret_cast<const f32x4*>(wr + kk * 16);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(xr + kk * 16 + 16), b1 = *reinterpret_cast<const f32x4*>(wr + kk * 16 + 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v += red[((blk + 2 * q) * 16 + r) * 64 + lane];
-        v += b1v;
+        for (int e = 0; e < 4; ++e) {
+          ae = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b0[e], ae, 0, 0, 0);
+          ao = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b1[e], ao, 0, 0, 0);
+        }
+      }
+      // D of 16x16x4: column = lane & 15 (hidden unit), row = (lane >> 4) * 4 + reg
+      const float b1v = p.b1[h0 + sub * 64 + cb * 16 + l15];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = ae[r] + ao[r] + b1v;
         v = (v < 0.f) ? 0.f : v;
-        const int m = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        Hs[m * FF_HLD + blk * 32 + l31] = v;
+        Hs[(rb * 16 + q4 * 4 + r) * FF_HLD + cb * 16 + l15] = v;
       }
     }
     __syncthreads();  // H complete
@@ -250,7 +248,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   if (t == 0) p.counters[tile] = 0;                  // everybody has arrived: ready for the next launch
 }
 
-static const size_t kFfnSmem = (size_t)(32 * FF_LD + 64 * FF_LD + 8 * 16 * 64 + 32 * FF_HLD) * sizeof(float);
+static const size_t kFfnSmem = (size_t)(32 * FF_LD + 64 * FF_LD + 32 * FF_HLD) * sizeof(float);
 
 static thread_local unsigned long long* g_ffn_dbg = nullptr;   // set_ffn_debug_times: phase stamps of the next launches
 void set_ffn_debug_times(unsigned long long* p) { g_ffn_dbg = p; }

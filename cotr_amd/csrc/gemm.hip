@@ -263,7 +263,6 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   // of 1 KB instead of 9 x 32) and the taps read their A fragments from the patch at the tap's offset; the weights go straight
   // to registers.  Everything the workgroup needs is requested up front: one memory round trip instead of nine half ones.
   constexpr bool PATCH = (DB == 4);
-  constexpr int PROWS = 2 * 3 * 18;   // most patch rows: two 16-pixel segments (3 x 18 each); one 32-pixel segment is 3 x 34
   static_assert(!PATCH || (MODE == GEMM_CONV && N16 && NWK == 8), "the patch variant is the 32 x 16 tile, 8 wavefronts, convolution");
   constexpr int TILE = PATCH ? BN * LD : (BM + BN) * LD;  // floats per LDS stage (A rows then W rows; PATCH: W rows only)
   extern __shared__ __attribute__((aligned(16))) float smem[];
