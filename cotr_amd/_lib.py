@@ -120,6 +120,7 @@ _PROTOS = {
     'cotr_op_conv_cfg': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p] +
                          [ctypes.c_int] * 8 + [ctypes.c_void_p]),
     'cotr_debug_ffn_times': (ctypes.c_int, [ctypes.c_void_p]),
+    'cotr_debug_attention_times': (ctypes.c_int, [ctypes.c_void_p]),
     'cotr_gemm_pick_conv': (ctypes.c_int, [ctypes.c_int] * 7),
     'cotr_debug_conv_times': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 8 +
                               [ctypes.c_void_p, ctypes.c_void_p]),

@@ -30,6 +30,7 @@ int init_attention_attributes();
 void set_attention_splits(int ns);
 void set_attention_fused_splits(int v);
 void set_ffn_debug_times(unsigned long long* p);  // ffn.hip
+void set_attention_debug_times(unsigned long long* p);  // attention.hip
 void set_attention_wide_min_rows(long v);
 void set_attention_wide_occupancy(int v);
 
@@ -1271,7 +1272,7 @@ int cotr_set_xcd_mapping(int policy) {
 }
 
 int cotr_set_attention_fused_splits(int ns) {
-  if (ns != 0 && ns != 4 && ns != 8) return COTR_ERR_ARG;
+  if (ns != 0 && ns != 4 && ns != 8 && ns != 48 && ns != 84) return COTR_ERR_ARG;
   set_attention_fused_splits(ns);
   return COTR_OK;
 }
@@ -1354,6 +1355,12 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
 // nullptr = off.  tools/ffn_phases.py
 int cotr_debug_ffn_times(unsigned long long* times) {
   set_ffn_debug_times(times);
+  return COTR_OK;
+}
+
+// the same for the fused attention launches (slots: entry, q projected, key loop done, merged, out projection staged, stored)
+int cotr_debug_attention_times(unsigned long long* times) {
+  set_attention_debug_times(times);
   return COTR_OK;
 }
 

@@ -43,6 +43,7 @@ struct AttnFuse {
   float* part;         // OP: [8][rows_total][256]
   int rows_total;      // OP: rows of one partial
   int wt;              // OP: write-through (sc1) stores for the partials (read once, by every XCD)
+  unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock): cotr_debug_attention_times
 };
 
 template <int NS, int QP, bool OP>   // QP: 0 = q given, 1 = project x, 2 = project x + x2
@@ -68,6 +69,11 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
+#define ATT_STAMP(slot)                                                                                                        \
+  do {                                                                                                                         \
+    if (fz.dbg != nullptr && t == 0) fz.dbg[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64();      \
+  } while (0)
+  ATT_STAMP(0);
   // head_major: head index fastest over consecutive workgroups (8 heads <-> 8 XCDs), so K_h/V_h of a pair cross the
   // fabric once chip-wide instead of once per XCD
   const int qtiles = gridDim.x >> 3;
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
         qf[j][e] = sum * fz.qscale * 1.44269504088896340736f;
       }
     __syncthreads();   // lds_o is reused by the key-split merge below
+    ATT_STAMP(1);
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
     __builtin_amdgcn_s_setprio(0);
   }
   l_run += __shfl_xor(l_run, 32);
+  ATT_STAMP(2);
 
   // ---- merge the NS key splits -----------------------------------------------------------------
 #pragma unroll
@@ -233,6 +241,7 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
     lds_out[l31][(r & 3) + 8 * (r >> 2) + 4 * hh] = acc * inv;
   }
   __syncthreads();
+  ATT_STAMP(3);
   if constexpr (OP) {
     // partial[head][row][n] = sum_d O[row][d] * Wo[n][head*32 + d]: wave w -> output columns [64w, 64w + 64).  The accumulators
     // go through a wave-private LDS tile so that the partial rows leave as float4 (one instruction = 4 rows x 256 B) instead of
@@ -253,6 +262,7 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * hh) * SLD + nb * 32 + l31] = pacc[r];
     }
+    ATT_STAMP(4);
     float* pbase = fz.part + ((size_t)head * fz.rows_total + (size_t)pair * nq) * 256 + wave * (32 * NBO);
     constexpr int LPR = 8 * NBO;                  // lanes (float4) per staged row
     constexpr int RPI = 64 / LPR;                 // rows per wave instruction
@@ -264,6 +274,7 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
       const f32x4 val = *reinterpret_cast<const f32x4*>(&stage[row * SLD + sc]);
       if (qo < nq) store_f32x4(pbase + (size_t)qo * 256 + sc, val, fz.wt != 0);
     }
+    ATT_STAMP(5);
     if (o == nullptr) return;
   }
   for (int i = t; i < 256; i += NS * 64) {  // 32 rows x 128 B, one float4 per thread: coalesced row stores
@@ -447,9 +458,11 @@ void set_attention_wide_head_major(int v) { g_att_wide_head_major = v != 0; }
 static long g_att_wide_min_rows = 4096;  // query rows of a launch from which the 64-query kernel is used (set_attention_wide_min_rows)
 void set_attention_wide_min_rows(long v) { g_att_wide_min_rows = v < 0 ? 0 : v; }
 
+static thread_local unsigned long long* g_att_dbg = nullptr;   // set_attention_debug_times
+void set_attention_debug_times(unsigned long long* p) { g_att_dbg = p; }
 static int g_att_splits = 0;  // 0 = automatic
 static int g_att_fused_splits = 0;  // 0 = default (4); set_attention_fused_splits
-void set_attention_fused_splits(int v) { g_att_fused_splits = (v == 4 || v == 8) ? v : 0; }
+void set_attention_fused_splits(int v) { g_att_fused_splits = (v == 4 || v == 8 || v == 48 || v == 84) ? v : 0; }  // 48 / 84: encoder (q given) / decoder (q projected) separately
 static int g_att_part_wt = 1;  // write-through stores for the out-projection partials (set_attention_part_wt)
 void set_attention_part_wt(int v) { g_att_part_wt = v; }
 static int g_att_head_major = 0;  // measured: -88 MB of fabric traffic per forward, +0.4 % time -> off (cotr_set_xcd_mapping bit 3)
@@ -513,11 +526,12 @@ int launch_attention_fused(const float* q, int ldq, const float* x, const float*
   AttnFuse fz = {};
   fz.x = x ? x : x2; fz.x2 = x ? x2 : nullptr; fz.wq = wq; fz.bq = bq; fz.qscale = qscale;
   fz.wo = wo; fz.part = part; fz.rows_total = nb * nq; fz.wt = g_att_part_wt;
+  fz.dbg = g_att_dbg;
   const int qmode = !qp ? 0 : (fz.x2 ? 2 : 1);
   // 8 key splits (8 wavefronts per workgroup) were tried where 4 leave CUs without a workgroup (the encoder of one pair is
   // 16 query tiles x 8 heads = 128 workgroups on 256 CUs): measured 0.978 vs 0.973 ms per forward, the merge of 8 partial
   // softmaxes and the narrower out-projection blocks cost more than the idle CUs -- kept as a knob only
-  const int ns = g_att_fused_splits ? g_att_fused_splits : 4;
+  const int ns = g_att_fused_splits == 48 ? (qp ? 8 : 4) : g_att_fused_splits == 84 ? (qp ? 4 : 8) : g_att_fused_splits ? g_att_fused_splits : 4;
 #define ATT_LAUNCH(NSV, QPV, OPV)                                                                                         \
   hipLaunchKernelGGL((attention_kernel<NSV, QPV, OPV>), grid, dim3(NSV * 64), 0, s, q, ldq, k, v, ldkv, o, ldo, nq, g_att_head_major, fz)
 #define ATT_PICK(NSV)                              \

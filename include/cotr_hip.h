@@ -337,6 +337,8 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
 
 /* phase timestamps of the fused FFN launches that follow into `times` (device, [workgroups][8] uint64, 100 MHz wall clock); NULL = off */
 int cotr_debug_ffn_times(unsigned long long* times);
+/* the same for the fused attention launches (cotr_op_attention_fused / the forward's small-row path) */
+int cotr_debug_attention_times(unsigned long long* times);
 /* the launch configuration the library picks for this convolution (tools) */
 int cotr_gemm_pick_conv(int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride);
 /* one convolution launch whose k-split kernel writes phase timestamps (100 MHz wall clock) of every workgroup to `times`
