@@ -467,7 +467,17 @@ class GraphedTrainStep:
         return self.loss, self.pred
 
     def close(self):
-        _lib.load_library().cotr_train_set_dropout_salt(None)
+        """Detach the salt word from the training kernels (eager steps afterwards use their seeds alone).  Also run when the
+        object is collected: the kernels must not keep reading a word whose tensor is gone."""
+        if getattr(self, 'salt', None) is not None:
+            try:
+                _lib.load_library().cotr_train_set_dropout_salt(None)
+            except Exception:
+                pass
+            self.salt = None
+
+    def __del__(self):
+        self.close()
 
 
 def train_batch(model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None):
