@@ -458,6 +458,7 @@ class GraphedTrainStep:
         return loss.detach(), pred.detach()
 
     def __call__(self, img, query, target, check=False):
+        assert self.graph is not None, 'GraphedTrainStep was closed'
         self.img.copy_(img)
         self.query.copy_(query)
         self.target.copy_(target)
@@ -475,6 +476,7 @@ class GraphedTrainStep:
             except Exception:
                 pass
             self.salt = None
+            self.graph = None          # (the captured step writes the salt word: it must not be replayed after this)
 
     def __del__(self):
         self.close()
