@@ -77,3 +77,17 @@ if '--config2' in sys.argv:
     dt = time.perf_counter() - t
     print(f'config 2 (dense pass + 4 zoom levels, converge_iters 3, 10000 forced queries, 512x512 pair): {dt:.2f} s, '
           f'{len(corrs)} correspondences = {len(corrs) / dt:.0f} corr/s, {eng.total_tasks} crops through the model', flush=True)
+    # the same call on the reference's FasterSparseEngine algorithm (squads of up to max_load + 1 queries per pilot crop), as
+    # SURVEY 8(d) config 2 names it
+    from cotr_amd.inference import FasterSparseEngine
+    feng = FasterSparseEngine(m, 32, 'tile', max_load=256)
+    np.random.seed(0)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    fc = feng.cotr_corr_multiscale(ia, ib, zooms, 3, max_corrs=10000, queries_a=q10k, force=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    print(f'config 2 on FasterSparseEngine(32, tile, max_load=256): {dt:.2f} s, {len(fc)} correspondences = {len(fc) / dt:.0f} corr/s '
+          f'(with RANDOM weights the predictions are incoherent, squads of nearby tasks never form, and the reference algorithm - which '
+          f'this class reproduces bit for bit on its goldens - leaves its grouped loop after one invocation per zoom level and its '
+          f'roll-back loop only steps tasks already at the last zoom level: sparse_engine.py:383-410)', flush=True)
