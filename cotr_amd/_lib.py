@@ -110,6 +110,12 @@ _PROTOS = {
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_set_ffn_tail': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_conv1x1_dense': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_knob_count': (ctypes.c_int, []),
+    'cotr_knob_name': (ctypes.c_char_p, [ctypes.c_int]),
+    'cotr_get_knob': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    'cotr_set_knob': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    'cotr_reset_knobs': (ctypes.c_int, []),
     'cotr_set_ffn_preln': (ctypes.c_int, [ctypes.c_int]),
     'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
@@ -170,3 +176,25 @@ def current_stream_ptr():
     if _raw_stream is not None:
         return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def knobs():
+    """{name: (current, default)} of every process-wide tuning switch of the library (cotr_set_<name>)."""
+    lib = load_library()
+    out = {}
+    for i in range(lib.cotr_knob_count()):
+        name = lib.cotr_knob_name(i)
+        cur, dflt = ctypes.c_int(), ctypes.c_int()
+        check(lib.cotr_get_knob(name, ctypes.byref(cur), ctypes.byref(dflt)), None, 'cotr_get_knob')
+        out[name.decode()] = (cur.value, dflt.value)
+    return out
+
+
+def set_knob(name, value):
+    check(load_library().cotr_set_knob(name.encode(), int(value)), None, f'cotr_set_knob({name}, {value})')
+
+
+def reset_knobs():
+    """Every tuning switch back to its shipped default (tests call this after each test that touched one)."""
+    check(load_library().cotr_reset_knobs(), None, 'cotr_reset_knobs')
+

@@ -1209,26 +1209,45 @@ static int bench_launches(int mode, int cfg, const GemmParams& p, int iters, flo
   return rc;
 }
 
+// ---- process-wide tuning knobs: one registry, so that a caller (tests, tools/ab_knobs.sh) can read a knob back, snapshot all of
+// them and put every one back to its shipped default (cotr_reset_knobs) instead of hand-written "restore" constants ----
+struct Knob {
+  const char* name;
+  int (*set)(int);
+  int def, cur;
+};
+Knob* knob_table(int* n);
+static void knob_record(const char* name, int v) {
+  int n = 0;
+  Knob* k = knob_table(&n);
+  for (int i = 0; i < n; ++i)
+    if (strcmp(k[i].name, name) == 0) k[i].cur = v;
+}
+
 int cotr_gemm_num_configs(void) { return gemm_num_configs(); }
 
 int cotr_set_encode_chunk(int pairs) {
   if (pairs < 1 || pairs > ENC_CHUNK_MAX) return COTR_ERR_ARG;
   g_enc_chunk = pairs;
+  knob_record("encode_chunk", pairs);
   return COTR_OK;
 }
 
 int cotr_set_head_fusion_max_rows(int rows) {
   g_head_fuse_max_rows = rows < 0 ? 0 : rows;
+  knob_record("head_fusion_max_rows", rows);
   return COTR_OK;
 }
 
 int cotr_set_attention_fusion_max_rows(int rows) {
   g_attn_fuse_max_rows = rows < 0 ? 0 : rows;
+  knob_record("attention_fusion_max_rows", rows);
   return COTR_OK;
 }
 
 int cotr_set_ffn_fusion_max_rows(int rows) {
   g_ffn_fuse_max_rows = rows < 0 ? 0 : rows;
+  knob_record("ffn_fusion_max_rows", rows);
   return COTR_OK;
 }
 
@@ -1239,26 +1258,31 @@ void set_ffn_write_through(int v);     // ffn.hip
 extern "C" {
 int cotr_set_ffn_preln(int enable) {
   g_ffn_preln = enable != 0;
+  knob_record("ffn_preln", enable);
   return COTR_OK;
 }
 
 int cotr_set_ffn_tail(int enable) {
   g_ffn_tail = enable != 0;
+  knob_record("ffn_tail", enable);
   return COTR_OK;
 }
 
 int cotr_set_ks3(int enable) {
   gemm_set_ks3(enable != 0);
+  knob_record("ks3", enable);
   return COTR_OK;
 }
 
 int cotr_set_dual_conv(int enable) {
   g_dual_conv = enable != 0;
+  knob_record("dual_conv", enable);
   return COTR_OK;
 }
 
 int cotr_set_fused_stem(int enable) {
   g_fused_stem = enable != 0;
+  knob_record("fused_stem", enable);
   return COTR_OK;
 }
 
@@ -1268,40 +1292,116 @@ int cotr_set_xcd_mapping(int policy) {
   set_ffn_chunk_major((policy >> 2) & 1);
   set_attention_head_major((policy >> 3) & 1);
   set_ffn_write_through(((policy >> 4) & 1) == 0);   // bit 4 set = plain (write-back) stores for the FFN partial outputs
+  knob_record("xcd_mapping", policy);
   return COTR_OK;
 }
 
 int cotr_set_attention_fused_splits(int ns) {
   if (ns != 0 && ns != 4 && ns != 8 && ns != 48 && ns != 84) return COTR_ERR_ARG;
   set_attention_fused_splits(ns);
+  knob_record("attention_fused_splits", ns);
   return COTR_OK;
 }
 
 int cotr_set_conv_patch(int enable) {
   gemm_set_patch(enable != 0);
+  knob_record("conv_patch", enable);
+  return COTR_OK;
+}
+
+int cotr_set_conv1x1_dense(int enable) {
+  gemm_set_conv1x1_dense(enable != 0);
+  knob_record("conv1x1_dense", enable != 0);
   return COTR_OK;
 }
 
 int cotr_set_pos_table_min_rows(int rows) {
   g_pos_table_min_rows = rows < 0 ? 0 : rows;
+  knob_record("pos_table_min_rows", rows);
   return COTR_OK;
 }
 
 int cotr_set_attention_wide_occupancy(int waves_per_simd) {
   if (waves_per_simd != 2 && waves_per_simd != 3) return COTR_ERR_ARG;
   set_attention_wide_occupancy(waves_per_simd);
+  knob_record("attention_wide_occupancy", waves_per_simd);
   return COTR_OK;
 }
 
 int cotr_set_attention_wide_min_rows(int rows) {
   set_attention_wide_min_rows(rows);
+  knob_record("attention_wide_min_rows", rows);
   return COTR_OK;
 }
 
 int cotr_set_attention_splits(int ns) {
   if (ns != 0 && ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16) return COTR_ERR_ARG;
   set_attention_splits(ns);
+  knob_record("attention_splits", ns);
   return COTR_OK;
+}
+
+}  // extern "C"
+Knob* knob_table(int* n) {
+  static Knob knobs[] = {
+      {"encode_chunk", cotr_set_encode_chunk, 32, 32},
+      {"head_fusion_max_rows", cotr_set_head_fusion_max_rows, 0, 0},
+      {"attention_fusion_max_rows", cotr_set_attention_fusion_max_rows, 1024, 1024},
+      {"ffn_fusion_max_rows", cotr_set_ffn_fusion_max_rows, 1024, 1024},
+      {"ffn_preln", cotr_set_ffn_preln, 0, 0},
+      {"ffn_tail", cotr_set_ffn_tail, 0, 0},
+      {"ks3", cotr_set_ks3, 1, 1},
+      {"dual_conv", cotr_set_dual_conv, 1, 1},
+      {"fused_stem", cotr_set_fused_stem, 1, 1},
+      {"xcd_mapping", cotr_set_xcd_mapping, 1, 1},
+      {"attention_fused_splits", cotr_set_attention_fused_splits, 0, 0},
+      {"conv_patch", cotr_set_conv_patch, 1, 1},
+      {"pos_table_min_rows", cotr_set_pos_table_min_rows, 8192, 8192},
+      {"attention_wide_occupancy", cotr_set_attention_wide_occupancy, 3, 3},
+      {"attention_wide_min_rows", cotr_set_attention_wide_min_rows, 4096, 4096},
+      {"attention_splits", cotr_set_attention_splits, 0, 0},
+      {"conv1x1_dense", cotr_set_conv1x1_dense, 1, 1},
+  };
+  *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
+  return knobs;
+}
+extern "C" {
+int cotr_knob_count(void) {
+  int n = 0;
+  (void)knob_table(&n);
+  return n;
+}
+const char* cotr_knob_name(int i) {
+  int n = 0;
+  Knob* k = knob_table(&n);
+  return (i >= 0 && i < n) ? k[i].name : nullptr;
+}
+int cotr_get_knob(const char* name, int* value, int* default_value) {
+  if (!name) return COTR_ERR_ARG;
+  int n = 0;
+  Knob* k = knob_table(&n);
+  for (int i = 0; i < n; ++i)
+    if (strcmp(k[i].name, name) == 0) {
+      if (value) *value = k[i].cur;
+      if (default_value) *default_value = k[i].def;
+      return COTR_OK;
+    }
+  return COTR_ERR_ARG;
+}
+int cotr_set_knob(const char* name, int value) {
+  if (!name) return COTR_ERR_ARG;
+  int n = 0;
+  Knob* k = knob_table(&n);
+  for (int i = 0; i < n; ++i)
+    if (strcmp(k[i].name, name) == 0) return k[i].set(value);
+  return COTR_ERR_ARG;
+}
+int cotr_reset_knobs(void) {
+  int n = 0, rc = COTR_OK;
+  Knob* k = knob_table(&n);
+  for (int i = 0; i < n; ++i)
+    if (int r = k[i].set(k[i].def)) rc = r;
+  return rc;
 }
 
 int cotr_bench_linear(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int cfg,

@@ -59,6 +59,33 @@ struct PerDeviceFlag {
 // ---------------------------------------------------------------------------------------------
 enum { GEMM_DENSE = 0, GEMM_CONV = 1, GEMM_STEM = 2 };
 
+// Division by a launch-time constant without a hardware divide.  hipcc expands `n / d` with a runtime d into ~25 dependent
+// instructions (v_rcp_iflag + a Newton step + two corrections); the convolution kernels did a dozen of them per row before
+// their first load could be issued - 500 of the ~800 instructions (1.7 us) between workgroup entry and "loads issued" in the
+// phase stamps of round 2.  Every divisor here is known on the host: q = umulhi(n, m) with m = 2^32 / d for a power of two
+// (all of COTR's geometry; exact), floor(2^32 / d) + 1 otherwise (exact for n * d < 2^32; the launch helpers check the range).
+struct FastDiv {
+  unsigned mul;  // q = umulhi(n, mul) + n * one
+  int one;       // 1 only for d == 1 (the multiplier would be 2^32)
+  int d;
+};
+static inline FastDiv fastdiv_make(int d) {
+  FastDiv f;
+  f.d = d > 0 ? d : 1;
+  f.one = f.d == 1;
+  if (f.d == 1) f.mul = 0;
+  else if ((f.d & (f.d - 1)) == 0) f.mul = (unsigned)(0x100000000ull / (unsigned)f.d);        // exact for every n
+  else f.mul = (unsigned)(0x100000000ull / (unsigned)f.d) + 1u;                                // exact for n * d < 2^32
+  return f;
+}
+// largest n for which fastdiv is exact (n * e < 2^32 with e = d - 2^32 mod d <= d)
+static inline long long fastdiv_max_n(const FastDiv& f) {
+  return (f.d & (f.d - 1)) == 0 ? 0x7fffffffll : (long long)(0x100000000ull / (unsigned)f.d) - 1;
+}
+__device__ __forceinline__ int fastdiv(int n, const FastDiv& f) {   // n >= 0; branch-free: multiply-high, multiply, add
+  return (int)(__umulhi((unsigned)n, f.mul) + (unsigned)n * (unsigned)f.one);
+}
+
 struct GemmParams {
   int M, N, K;
   const float* A;
@@ -81,6 +108,10 @@ struct GemmParams {
   int colscale_n;
   const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
   int xcd_msplit;      // workgroup -> tile mapping, see gemm_tile_coords
+  // launch-time divisors (gemm_fill_divs, called by every launch helper): column tiles of the launch's tile shape; the
+  // convolution's pixel decomposition (Hout * 2*Wout, 2*Wout, Wout), channel tiles per tap (Cin / 32), ksize; the x + pos
+  // prologue's row period and column period; the row period of a table residual
+  FastDiv fd_tiles_n, fd_hw, fd_w2o, fd_wout, fd_tpt, fd_ks, fd_a2row, fd_a2per, fd_resrow;
   unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock) written by wavefront 0 of the
                             // k-split kernels: entry, loads issued, first data usable, K loop done, stored (cotr_debug_conv_times)
 };
@@ -94,22 +125,64 @@ struct GemmParams {
 //            (right when the activation operand is the larger one: layer1/layer2 at any batch, everything when batched)
 // Time-neutral at one pair (the path is latency-bound there); it is what the L2<->fabric byte counters see.
 __device__ __forceinline__ bool gemm_tile_coords(const GemmParams& p, int bm, int bn, int bid, int& m0, int& n0) {
-  const int tiles_n = p.N / bn;
+  const int tiles_n = p.fd_tiles_n.d;   // == p.N / bn (gemm_fill_divs)
   if (p.xcd_msplit) {
-    const int tiles_m = (p.M + bm - 1) / bm;
-    const int mt = (bid / (8 * tiles_n)) * 8 + (bid & 7);
+    const int tiles_m = (p.M + bm - 1) / bm;   // bm is a power of two at every call site
+    const int a = bid >> 3;
+    const int q = fastdiv(a, p.fd_tiles_n);    // bid / (8 * tiles_n)
+    const int mt = q * 8 + (bid & 7);
     if (mt >= tiles_m) return false;
     m0 = mt * bm;
-    n0 = ((bid >> 3) % tiles_n) * bn;
+    n0 = (a - q * tiles_n) * bn;
   } else {
-    m0 = (bid / tiles_n) * bm;
-    n0 = (bid % tiles_n) * bn;
+    const int q = fastdiv(bid, p.fd_tiles_n);
+    m0 = q * bm;
+    n0 = (bid - q * tiles_n) * bn;
   }
   return true;
+}
+__device__ __forceinline__ int fastmod(int n, const FastDiv& f) { return n - fastdiv(n, f) * f.d; }
+// output row mm of a convolution -> (pair b, output row ho, half `side`, column wl inside the half)
+__device__ __forceinline__ void conv_row_decompose(const GemmParams& p, int mm, int& b, int& ho, int& side, int& wl) {
+  b = fastdiv(mm, p.fd_hw);
+  const int rem = mm - b * p.fd_hw.d;
+  ho = fastdiv(rem, p.fd_w2o);
+  const int wo = rem - ho * p.fd_w2o.d;
+  side = fastdiv(wo, p.fd_wout);
+  wl = wo - side * p.fd_wout.d;
+}
+// K tile kt of a convolution -> (ky, kx, first channel c0)
+__device__ __forceinline__ void conv_ktile_decompose(const GemmParams& p, int kt, int& ky, int& kx, int& c0) {
+  const int tap = fastdiv(kt, p.fd_tpt);
+  c0 = (kt - tap * p.fd_tpt.d) * 32;
+  ky = fastdiv(tap, p.fd_ks);
+  kx = tap - ky * p.fd_ks.d;
 }
 static inline int gemm_grid_tiles(const GemmParams& p, int bm, int bn) {
   const int tiles_m = (p.M + bm - 1) / bm;
   return (p.xcd_msplit ? (tiles_m + 7) / 8 * 8 : tiles_m) * (p.N / bn);
+}
+// fills the launch-time divisors for a launch with column tiles of bn; false if a quotient would leave fastdiv's exact range
+static inline bool gemm_fill_divs(GemmParams& p, int mode, int bm, int bn) {
+  p.fd_tiles_n = fastdiv_make(p.N / bn);
+  const long long grid = gemm_grid_tiles(p, bm, bn);
+  bool ok = grid <= fastdiv_max_n(p.fd_tiles_n);
+  p.fd_a2row = fastdiv_make(p.a2_row_mod > 0 ? p.a2_row_mod : 1);
+  p.fd_a2per = fastdiv_make(p.a2_period > 0 ? p.a2_period : 1);
+  p.fd_resrow = fastdiv_make(p.res_row_mod > 0 ? p.res_row_mod : 1);
+  ok = ok && p.M <= fastdiv_max_n(p.fd_a2row) && p.N <= fastdiv_max_n(p.fd_a2per) && p.M <= fastdiv_max_n(p.fd_resrow);
+  if (mode == GEMM_CONV) {
+    p.fd_hw = fastdiv_make(p.Hout * 2 * p.Wout);
+    p.fd_w2o = fastdiv_make(2 * p.Wout);
+    p.fd_wout = fastdiv_make(p.Wout);
+    p.fd_tpt = fastdiv_make(p.Cin / 32);
+    p.fd_ks = fastdiv_make(p.ksize);
+    ok = ok && p.M <= fastdiv_max_n(p.fd_hw) && p.Hout * 2 * p.Wout <= fastdiv_max_n(p.fd_w2o) &&
+         2 * p.Wout <= fastdiv_max_n(p.fd_wout) && p.K / 32 <= fastdiv_max_n(p.fd_tpt) && p.ksize * p.ksize <= fastdiv_max_n(p.fd_ks);
+  } else {
+    p.fd_hw = p.fd_w2o = p.fd_wout = p.fd_tpt = p.fd_ks = fastdiv_make(1);
+  }
+  return ok;
 }
 
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s);            // tuned / modelled config
@@ -126,7 +199,8 @@ int gemm_num_configs();
 void gemm_set_xcd_policy(int v);  // 0 column tiles over XCDs, 1 by operand size (default), 2 row tiles over XCDs
 bool gemm_cfg_supports_ln(int cfg);
 void gemm_set_ks3(int v);
-void gemm_set_patch(int v);  // 1 (default): three-stage LDS-DMA k-split instead of the two-stage one where K >= 768
+void gemm_set_patch(int v);
+void gemm_set_conv1x1_dense(int v);  // 1 (default): 1x1 stride-1 convolutions run the dense instantiation of their configuration  // 1 (default): three-stage LDS-DMA k-split instead of the two-stage one where K >= 768
 const float* gemm_zero_buffer();  // per-DEVICE buffer of zeros (LDS-DMA padding source), on the current device
 
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]

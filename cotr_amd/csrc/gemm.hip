@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   // branch (hipcc then waits for every load before the next one: measured 4 dependent L2 round trips per K step), so a launch
   // with an A2 operand ALWAYS loads it - tiles that do not use it read a zero row with stride 0 - and adds it at the LDS store
   const bool has_a2 = (MODE == GEMM_DENSE) && p.A2 != nullptr;
-  const bool use_a2 = has_a2 && (n0 % p.a2_period) < p.a2_width;
+  const bool use_a2 = has_a2 && fastmod(n0, p.fd_a2per) < p.a2_width;
   const int a2_step = use_a2 ? BK : 0;
   // stem bookkeeping (MODE == GEMM_STEM): one output pixel per thread, 16 k's per tile
   int s_hi0 = 0, s_wi0 = 0;
@@ -61,21 +61,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       a_ok[i] = m < p.M;
       const int mm = a_ok[i] ? m : 0;
       a_ptr[i] = p.A + (size_t)mm * p.lda + lc;
-      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? mm % p.a2_row_mod : mm) * p.lda2 + lc : p.zeros;
+      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? fastmod(mm, p.fd_a2row) : mm) * p.lda2 + lc : p.zeros;
     }
   } else if constexpr (MODE == GEMM_CONV) {
-    const int W2o = 2 * p.Wout;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int m = m0 + lr + 32 * i;
       a_ok[i] = m < p.M;
       const int mm = a_ok[i] ? m : 0;
-      const int b = mm / (p.Hout * W2o);
-      const int rem = mm - b * (p.Hout * W2o);
-      const int ho = rem / W2o;
-      const int wo = rem - ho * W2o;
-      const int side = wo / p.Wout;
-      const int wl = wo - side * p.Wout;
+      int b, ho, side, wl;
+      conv_row_decompose(p, mm, b, ho, side, wl);
       c_hi0[i] = ho * p.stride - p.pad;
       c_wi0[i] = wl * p.stride - p.pad;
       // pixel (b, 0, side*Win + 0), channel lc
@@ -119,11 +114,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < RA; ++i) ra2[i] = *reinterpret_cast<const f32x4*>(a2_ptr[i] + kt * a2_step);
       }
     } else if constexpr (MODE == GEMM_CONV) {
-      const int tiles_per_tap = p.Cin / BK;
-      const int tap = kt / tiles_per_tap;
-      const int c0 = (kt - tap * tiles_per_tap) * BK;
-      const int ky = tap / p.ksize;
-      const int kx = tap - ky * p.ksize;
+      int ky, kx, c0;
+      conv_ktile_decompose(p, kt, ky, kx, c0);
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int hi = c_hi0[i] + ky, wi = c_wi0[i] + kx;
@@ -291,7 +283,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   int c_hi0[PA], c_wi0[PA];
   // see gemm_kernel: with an A2 operand every tile loads it (zero row, stride 0 where unused), no per-element uniform branch
   const bool has_a2 = (MODE == GEMM_DENSE) && p.A2 != nullptr;
-  const bool use_a2 = has_a2 && (n0 % p.a2_period) < p.a2_width;
+  const bool use_a2 = has_a2 && fastmod(n0, p.fd_a2per) < p.a2_width;
   const int a2_step = use_a2 ? KS : 0;
   if constexpr (MODE == GEMM_DENSE) {
 #pragma unroll
@@ -300,21 +292,16 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
       a_ok[i] = m < p.M;
       const int mm = a_ok[i] ? m : 0;
       a_ptr[i] = p.A + (size_t)mm * p.lda + lc4 * 4;
-      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? mm % p.a2_row_mod : mm) * p.lda2 + lc4 * 4 : p.zeros;
+      a2_ptr[i] = use_a2 ? p.A2 + (size_t)(p.a2_row_mod ? fastmod(mm, p.fd_a2row) : mm) * p.lda2 + lc4 * 4 : p.zeros;
     }
   } else {
-    const int W2o = 2 * p.Wout;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int m = m0 + lr + 8 * i;
       a_ok[i] = m < p.M;
       const int mm = a_ok[i] ? m : 0;
-      const int b = mm / (p.Hout * W2o);
-      const int rem = mm - b * (p.Hout * W2o);
-      const int ho = rem / W2o;
-      const int wo = rem - ho * W2o;
-      const int side = wo / p.Wout;
-      const int wl = wo - side * p.Wout;
+      int b, ho, side, wl;
+      conv_row_decompose(p, mm, b, ho, side, wl);
       c_hi0[i] = ho * p.stride - p.pad;
       c_wi0[i] = wl * p.stride - p.pad;
       a_ptr[i] = p.A + ((size_t)b * p.Hin * (2 * p.Win) + (size_t)side * p.Win) * p.Cin + lcc;
@@ -326,7 +313,6 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
   for (int i = 0; i < PW; ++i) w_ptr[i] = p.W + (size_t)(n0 + lr + 8 * i) * p.K + lc4 * 4;
 
   f32x4 ra[PA], ra2[PA], rw[PW];
-  const int tiles_per_tap = (MODE == GEMM_CONV) ? p.Cin / BK : 1;
 
   auto load_tile = [&](int st) {
 #if defined(COTR_ABL) && COTR_ABL == 1  // ablation: only the first global load
@@ -350,10 +336,8 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
         }
       }
     } else {
-      const int tap = kt / tiles_per_tap;
-      const int c0 = (kt - tap * tiles_per_tap) * BK;
-      const int ky = tap / p.ksize;
-      const int kx = tap - ky * p.ksize;
+      int ky, kx, c0;
+      conv_ktile_decompose(p, kt, ky, kx, c0);
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int hi = c_hi0[i] + ky, wi = c_wi0[i] + kx;
@@ -452,10 +436,8 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
                                          (__attribute__((address_space(3))) void*)(As + (lr + 8 * i) * LD), 16, 0, 0);
       }
     } else {
-      const int tap = kt / tiles_per_tap;
-      const int c0 = (kt - tap * tiles_per_tap) * BK;
-      const int ky = tap / p.ksize;
-      const int kx = tap - ky * p.ksize;
+      int ky, kx, c0;
+      conv_ktile_decompose(p, kt, ky, kx, c0);
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int hi = c_hi0[i] + ky, wi = c_wi0[i] + kx;
@@ -486,13 +468,8 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
     // exactly 5 patch DMAs + 6 weight loads per phase, idle DMA slots go to a dummy row).
     f32x4 wreg[9][2];
     {
-      const int W2o = 2 * p.Wout;
-      const int b = m0 / (p.Hout * W2o);
-      const int rem = m0 - b * (p.Hout * W2o);
-      const int ho = rem / W2o;
-      const int wo = rem - ho * W2o;
-      const int side0 = wo / p.Wout;
-      const int wl0 = wo - side0 * p.Wout;
+      int b, ho, side0, wl0;
+      conv_row_decompose(p, m0, b, ho, side0, wl0);
       // all of the patch addressing is wave-uniform (a wave instruction moves one pixel): kept on the scalar unit by taking the
       // wavefront index through readfirstlane - per-lane integer divisions and exec-masked branches around every DMA were 4 us
       const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -750,8 +727,10 @@ template <int WM, int WN, int TM, int TN, int MODE>
 static int launch_t(const GemmParams& p, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0) return -1;
-  const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, MODE>), dim3(tiles), dim3(256), 0, s, p);
+  GemmParams q = p;
+  if (!gemm_fill_divs(q, MODE, BM, BN)) return -1;
+  const int tiles = gemm_grid_tiles(q, BM, BN);
+  hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, MODE>), dim3(tiles), dim3(256), 0, s, q);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -776,8 +755,10 @@ static int launch_ks_impl(const GemmParams& p, hipStream_t s) {
       return -2;
     attr_set.set();
   }
-  const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles), dim3(NWK * 64), smem, s, p);
+  GemmParams q = p;
+  if (!gemm_fill_divs(q, MODE, BM, BN)) return -1;
+  const int tiles = gemm_grid_tiles(q, BM, BN);
+  hipLaunchKernelGGL((gemm_ks_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles), dim3(NWK * 64), smem, s, q);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -794,8 +775,10 @@ static int launch_ks_dual(const GemmParams& p0, const GemmParams& p1, hipStream_
       return -2;
     attr_set.set();
   }
-  const int tiles0 = gemm_grid_tiles(p0, BM, BN), tiles1 = gemm_grid_tiles(p1, BM, BN);
-  hipLaunchKernelGGL((gemm_ks_dual_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles0 + tiles1), dim3(NWK * 64), smem, s, p0, p1, tiles0);
+  GemmParams q0 = p0, q1 = p1;
+  if (!gemm_fill_divs(q0, MODE, BM, BN) || !gemm_fill_divs(q1, MODE, BM, BN)) return -1;
+  const int tiles0 = gemm_grid_tiles(q0, BM, BN), tiles1 = gemm_grid_tiles(q1, BM, BN);
+  hipLaunchKernelGGL((gemm_ks_dual_kernel<NWK, TM, TN, MODE, DB>), dim3(tiles0 + tiles1), dim3(NWK * 64), smem, s, q0, q1, tiles0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -978,6 +961,8 @@ static int gemm_pick_config_table(int mode, const GemmParams& p) {
   return best;
 }
 
+static int g_conv1x1_dense = 1;  // gemm_set_conv1x1_dense
+void gemm_set_conv1x1_dense(int v) { g_conv1x1_dense = v; }
 static int g_xcd_policy = 1;  // 0 = column tiles over XCDs always, 1 = by operand size, 2 = row tiles over XCDs always
 void gemm_set_xcd_policy(int v) { g_xcd_policy = v; }
 
@@ -1016,6 +1001,11 @@ int launch_gemm_cfg(int mode, int cfg, const GemmParams& p0, hipStream_t s) {
       return launch_cfg<GEMM_DENSE>(cfg, p, s);
     case GEMM_CONV:
       if (p.Cin % BK != 0 || p.K != p.ksize * p.ksize * p.Cin) return -1;
+      // a 1x1 stride-1 convolution IS the dense product of the pixel rows (row m = pixel m, lda = Cin, no padding): the
+      // dense instantiation of the same configuration computes the same sums in the same order without the per-row pixel
+      // decomposition - ~640 fewer instructions between workgroup entry and the first load (profiles/r3_prologue_*.txt)
+      if (g_conv1x1_dense && p.ksize == 1 && p.stride == 1 && p.pad == 0 && p.lda == p.Cin && p.lda % 4 == 0)
+        return launch_cfg<GEMM_DENSE>(cfg, p, s);
       return launch_cfg<GEMM_CONV>(cfg, p, s);
     case GEMM_STEM:
       if (p.N != 64 || p.K != 160) return -1;

@@ -51,13 +51,8 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
       a_ptr[q] = p.A + (size_t)mm * p.lda + lch * 4;
       c_hi0[q] = c_wi0[q] = 0;
     } else {
-      const int W2o = 2 * p.Wout;
-      const int b = mm / (p.Hout * W2o);
-      const int rem = mm - b * (p.Hout * W2o);
-      const int ho = rem / W2o;
-      const int wo = rem - ho * W2o;
-      const int side = wo / p.Wout;
-      const int wl = wo - side * p.Wout;
+      int b, ho, side, wl;
+      conv_row_decompose(p, mm, b, ho, side, wl);
       c_hi0[q] = ho * p.stride - p.pad;
       c_wi0[q] = wl * p.stride - p.pad;
       a_ptr[q] = p.A + ((size_t)b * p.Hin * (2 * p.Win) + (size_t)side * p.Win) * p.Cin + lch * 4;
@@ -70,7 +65,6 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
     const int lch = pch ^ ((row >> 1) & 7);
     w_ptr[q] = p.W + (size_t)(n0 + row) * p.K + lch * 4;
   }
-  const int tiles_per_tap = (MODE == GEMM_CONV) ? p.Cin / BK : 1;
 
   auto dma_tile = [&](int kt, int buf) {
     float* As = smem + buf * STAGE;
@@ -83,10 +77,8 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
                                          (__attribute__((address_space(3))) void*)(As + (wave * 32 + q * 8) * BK), 16, 0, 0);
       }
     } else {
-      const int tap = kt / tiles_per_tap;
-      const int c0 = (kt - tap * tiles_per_tap) * BK;
-      const int ky = tap / p.ksize;
-      const int kx = tap - ky * p.ksize;
+      int ky, kx, c0;
+      conv_ktile_decompose(p, kt, ky, kx, c0);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int hi = c_hi0[q] + ky, wi = c_wi0[q] + kx;
@@ -130,7 +122,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int m = m0 + wm * 64 + a * 32 + it * RPI + er;
-        const int mr = m < p.M ? (p.res_row_mod > 0 ? m % p.res_row_mod : m) : 0;
+        const int mr = m < p.M ? (p.res_row_mod > 0 ? fastmod(m, p.fd_resrow) : m) : 0;
         res[a][it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mr * p.ldr + ncol);
       }
   }
@@ -247,6 +239,7 @@ static int launch_big_dual_t(const GemmParams& a, const GemmParams& b, hipStream
       return -2;
     attr_set.set();
   }
+  if (!gemm_fill_divs(p0, GEMM_CONV, BM, BN) || !gemm_fill_divs(p1, GEMM_CONV, BM, BN)) return -1;
   const int tiles0 = gemm_grid_tiles(p0, BM, BN), tiles1 = gemm_grid_tiles(p1, BM, BN);
   hipLaunchKernelGGL((gemm_big_dual_kernel<TN, GEMM_CONV, 2>), dim3(tiles0 + tiles1), dim3(256), smem, s, p0, p1, tiles0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -275,6 +268,7 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
       return -2;
     attr_set.set();
   }
+  if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
   const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST>), dim3(tiles), dim3(256), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -323,6 +323,17 @@ int cotr_set_attention_wide_min_rows(int rows);
 int cotr_set_attention_wide_occupancy(int waves_per_simd);
 /* key splits (wavefronts per workgroup) of the attention kernel: 1, 2, 4, 8, 16, or 0 = automatic */
 int cotr_set_attention_splits(int ns);
+/* 1 (default): a 1x1 stride-1 convolution is launched as the dense product of its pixel rows (same configuration, same
+ * summation order, bit-identical) - the dense kernels skip the per-row pixel decomposition of the convolution prologue */
+int cotr_set_conv1x1_dense(int enable);
+/* The process-wide switches above as a registry (name = the part after cotr_set_): count / name enumerate them, get returns
+ * the current and the shipped default value, set is cotr_set_<name>(value), reset puts EVERY switch back to its default.
+ * Tests and A/B tools snapshot and restore through these instead of hand-written constants. */
+int cotr_knob_count(void);
+const char* cotr_knob_name(int i);
+int cotr_get_knob(const char* name, int* value, int* default_value);
+int cotr_set_knob(const char* name, int value);
+int cotr_reset_knobs(void);
 /* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured
  * with HIP events around a captured graph of `iters` launches on a private stream */
 int cotr_bench_linear(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int cfg,
