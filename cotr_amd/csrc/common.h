@@ -189,6 +189,9 @@ int launch_gemm(int mode, const GemmParams& p, hipStream_t s);            // tun
 int launch_gemm_cfg(int mode, int cfg, const GemmParams& p, hipStream_t s);  // explicit config (tuning, tests)
 int gemm_pick_config(int mode, const GemmParams& p);
 int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s);  // gemm_big.hip: 0 = 128x128, 1 = 128x64
+int launch_gemm_wp(int mode, int variant, const GemmParams& p, hipStream_t s);   // gemm_wp.hip: wave-private K chunks
+int launch_gemm_wp_dual(int mode, int variant, const GemmParams& p0, const GemmParams& p1, hipStream_t s);
+int wp_variant_tile(int variant, int* bm, int* bn, size_t* lds);
 // Two INDEPENDENT problems of the same mode in ONE launch (grid = tiles of p0 followed by tiles of p1, same kernel
 // configuration): the downsample branch of a bottleneck next to its conv1 (torchvision Bottleneck.forward: both read the block
 // input).  Supported configurations: the k-split ones without LDS-DMA (kinds 1, 2) and the large tiles (kind 4).

@@ -719,6 +719,16 @@ static const GemmCfg kCfgs[] = {
     {5, 0, 2, 1},   // 29 large tile 128x64, three LDS stages
     {6, 8, 1, 0},   // 30 k-split 8 waves, 32x16, LDS-DMA with THREE stages (two tiles in flight, counted vmcnt)
     {7, 8, 1, 0},   // 31 the same for 3x3 stride-1 convolutions over 256 channels with the input patch loaded once (DB == 4)
+    // kind 8: wave-private K chunks (gemm_wp.hip): every wavefront requests and reads its own run of 32-wide K chunks through
+    // its own ring of LDS slots - no barrier in the K loop, everything (or NSLOT chunks) requested up front; a = variant
+    {8, 0, 1, 1},   // 32 wave-private, 8 waves, 32x32, 2 slots
+    {8, 1, 1, 0},   // 33 wave-private, 8 waves, 32x16, 3 slots
+    {8, 2, 1, 1},   // 34 wave-private, 4 waves, 32x32, 2 slots (two workgroups per CU)
+    {8, 3, 1, 2},   // 35 wave-private, 8 waves, 32x64, 1 slot
+    {8, 4, 1, 1},   // 36 wave-private, 4 waves, 32x32, 1 slot (four workgroups per CU)
+    {8, 5, 2, 1},   // 37 wave-private, 8 waves, 64x32, 1 slot
+    {8, 6, 1, 1},   // 38 wave-private, 4 waves, 32x32, 4 slots
+    {8, 7, 1, 0},   // 39 wave-private, 8 waves, 32x16, 2 slots
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -833,6 +843,7 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 29: return launch_gemm_big(MODE, 3, p, s);
     case 30: return launch_ks<8, 1, 0, MODE, 3>(p, s);
     case 31: return launch_ks<8, 1, 0, MODE, 4>(p, s);
+    case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: return launch_gemm_wp(MODE, kCfgs[cfg].a, p, s);
     default: return -1;
   }
 }
@@ -841,7 +852,8 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
 // the bottleneck entry blocks uses (measured table): k-split 4 waves 32x32 (4), 8 waves 32x64 (10), their double-buffered
 // forms (14, 16), 8 waves 32x32 (3, 13) and the large tiles (26, 27)
 bool gemm_cfg_supports_dual(int cfg) {
-  return cfg == 3 || cfg == 4 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 16 || cfg == 26 || cfg == 27;
+  return cfg == 3 || cfg == 4 || cfg == 10 || cfg == 13 || cfg == 14 || cfg == 16 || cfg == 26 || cfg == 27 ||
+         cfg == 32 || cfg == 34 || cfg == 35 || cfg == 36;
 }
 
 static int launch_dual_conv(int cfg, const GemmParams& p0, const GemmParams& p1, hipStream_t s) {
@@ -854,6 +866,7 @@ static int launch_dual_conv(int cfg, const GemmParams& p0, const GemmParams& p1,
     case 16: return launch_ks_dual<8, 1, 2, GEMM_CONV, 1>(p0, p1, s);
     case 26: return launch_gemm_big_dual(GEMM_CONV, 0, p0, p1, s);
     case 27: return launch_gemm_big_dual(GEMM_CONV, 1, p0, p1, s);
+    case 32: case 34: case 35: case 36: return launch_gemm_wp_dual(GEMM_CONV, kCfgs[cfg].a, p0, p1, s);
     default: return -1;
   }
 }
@@ -874,7 +887,13 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
     if (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15))) return false;
     return p.N % (64 * c.tn) == 0;
   }
-  if (p.res_row_mod > 0) return false;  // row-periodic residual tables: large-tile kernels only
+  if (c.kind == 8) {  // wave-private chunks: LDS-DMA operands (no x + pos prologue); row-periodic residual supported
+    int bm, bn;
+    size_t lds;
+    if (wp_variant_tile(c.a, &bm, &bn, &lds) != 0) return false;
+    return p.A2 == nullptr && p.N % bn == 0 && p.K % BK == 0;
+  }
+  if (p.res_row_mod > 0) return false;  // row-periodic residual tables: large-tile and wave-private kernels only
   if (c.kind == 7)
     return p.A2 == nullptr && p.ksize == 3 && p.stride == 1 && p.Cin == 256 && (p.Wout == 16 || p.Wout % 32 == 0) && p.M % 32 == 0 && p.N % 16 == 0;
   const int bn = c.tn == 0 ? 16 : (c.kind == 0 ? 2 : 1) * c.tn * 32;
@@ -890,6 +909,7 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
 
 // rough cost model (cycles) for shapes outside the tuned table
 static double model_cost(const GemmCfg& c, const GemmParams& p) {
+  if (c.kind == 8) return 1e30;   // wave-private configurations enter through the measured table only
   if (c.kind == 4 || c.kind == 5) {  // pays off once the chip is covered several times over
     const int bm = 128, bn = 64 * c.tn;
     const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);

@@ -12,10 +12,13 @@ dev = torch.device('cuda:0')
 P = lambda t: None if t is None else t.data_ptr()
 sp = _lib.current_stream_ptr()
 # (name, B, H, W(per half), Cin, Cout, k, stride, configs)
-shapes = [('layer3 conv2 3x3', 1, 16, 16, 256, 256, 3, 1, (24, 30, 31)),
-          ('layer3 conv1 1x1 1024->256', 1, 16, 16, 1024, 256, 1, 1, (24, 30)),
-          ('layer3 conv3 1x1 256->1024', 1, 16, 16, 256, 1024, 1, 1, (4, 14)),
-          ('layer2 conv2 3x3', 1, 32, 32, 128, 128, 3, 1, (19, 3, 13))]
+shapes = [('layer3 conv2 3x3', 1, 16, 16, 256, 256, 3, 1, (24, 30, 31, 33, 39, 32)),
+          ('layer3 conv1 1x1 1024->256', 1, 16, 16, 1024, 256, 1, 1, (24, 30, 33, 39, 32)),
+          ('layer3 conv3 1x1 256->1024', 1, 16, 16, 256, 1024, 1, 1, (4, 14, 34, 36, 32)),
+          ('layer2 conv2 3x3', 1, 32, 32, 128, 128, 3, 1, (19, 3, 13, 32, 34, 38)),
+          ('layer2 conv1 1x1 512->128', 1, 32, 32, 512, 128, 1, 1, (19, 32, 34, 38)),
+          ('layer1 conv2 3x3', 1, 64, 64, 64, 64, 3, 1, (14, 34, 38, 32, 35, 37)),
+          ('layer1 conv1 1x1 256->64', 1, 64, 64, 256, 64, 1, 1, (10, 35, 32, 34))]
 for name, B, H, W, cin, cout, k, st, cfgs in shapes:
     x = torch.randn(B, H, 2 * W, cin, device=dev)
     w = torch.randn(cout, k * k * cin, device=dev) / (k * k * cin) ** 0.5

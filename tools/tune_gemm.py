@@ -21,7 +21,7 @@ from cotr_amd import _lib  # noqa: E402
 from cotr_amd.models.spec import conv_bn_list  # noqa: E402
 
 GEMM_DENSE, GEMM_CONV = 0, 1
-DMA_CFGS = (19, 20, 21, 24, 26, 27, 28, 29)  # LDS-DMA configurations: no x+pos prologue
+DMA_CFGS = (19, 20, 21, 24, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39)  # LDS-DMA configurations: no x+pos prologue
 
 
 def P(t):
