@@ -62,6 +62,7 @@ _PROTOS = {
     'cotr_train_ln_bwd_parts': (ctypes.c_int, [ctypes.c_int]),
     'cotr_train_ln_bwd': (ctypes.c_int, [c_float_p] * 8 + [ctypes.c_int, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]),
     'cotr_train_set_dropout_salt': (ctypes.c_int, [ctypes.c_void_p]),
+    'cotr_train_clear_dropout_salt': (ctypes.c_int, [ctypes.c_void_p]),
     'cotr_train_dropout_fwd': (ctypes.c_int, [c_float_p, ctypes.c_size_t, ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]),
     'cotr_train_relu_drop_bwd': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_size_t, ctypes.c_float, ctypes.c_void_p]),
     'cotr_train_colsum_parts': (ctypes.c_int, [ctypes.c_int]),

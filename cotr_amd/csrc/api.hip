@@ -1521,6 +1521,7 @@ int cotr_train_set_dropout_salt(const unsigned int* salt) {
   train_set_salt_ptr(salt);
   return COTR_OK;
 }
+int cotr_train_clear_dropout_salt(const unsigned int* salt) { return train_clear_salt_ptr_if(salt) ? COTR_OK : COTR_ERR_STATE; }
 
 int cotr_train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, cotr_stream stream) {
   return op_ret(train_dropout_fwd(x, n, p, seed, TS));

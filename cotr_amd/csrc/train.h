@@ -20,6 +20,7 @@ __device__ __forceinline__ bool train_keep(uint32_t seed, uint64_t idx, uint32_t
 // Step salt for captured (hipGraph) training steps: a launch's seed is baked into the graph, so the kernels XOR it with a word
 // read from device memory that the captured step itself advances (cotr_train_set_dropout_salt; nullptr = plain seeds)
 const uint32_t* train_salt_ptr();
+bool train_clear_salt_ptr_if(const uint32_t* expected);
 void train_set_salt_ptr(const uint32_t* p);
 __device__ __forceinline__ uint32_t train_salted(uint32_t seed, const uint32_t* salt) { return salt ? seed ^ *salt : seed; }
 static inline uint32_t train_thresh(float p) {

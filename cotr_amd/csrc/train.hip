@@ -15,6 +15,8 @@
 // Dropout masks are counter-based: keep(element) = hash(seed, element index) >= p * 2^32.  The backward kernels recompute
 // them from the same (seed, index), nothing is stored.  The masks are not torch's (no parity requirement on a random mask;
 // with p = 0 every kernel is exact and that is what the goldens pin).
+#include <atomic>
+
 #include "common.h"
 #include "train.h"
 
@@ -442,8 +444,9 @@ __global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ d
 }
 
 // out[r][c] = w[r][c] * scale[r]   (FrozenBN folded into the weights for the backward: conv(x, W) * scale = conv(x, W * scale))
-__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ w, const float* __restrict__ scale,
-                                                         float* __restrict__ out, int rows, int cols4) {
+// (w and out may be the SAME buffer - ConvBN.backward scales in place - so neither is __restrict__)
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* w, const float* __restrict__ scale, float* out, int rows,
+                                                         int cols4) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)rows * cols4) return;
   const float sc = scale[i / cols4];
@@ -524,9 +527,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -2)
 
-static thread_local const uint32_t* g_salt = nullptr;   // per host thread, like the current device
-const uint32_t* train_salt_ptr() { return g_salt; }
-void train_set_salt_ptr(const uint32_t* p) { g_salt = p; }
+// The salt word is per DEVICE and process-wide, not per host thread: PyTorch runs the backward of a CUDA autograd Function on
+// the autograd engine's per-device worker thread, and the kernels that RECOMPUTE a dropout mask there (ln_bwd, attn_bwd_dq,
+// attn_bwd_dkv) must see the salt the forward kernels drew it with on the Python thread.  (Round 2 had it thread_local: with a
+// salt registered, forward masks came from seed ^ salt and backward masks from seed alone.)
+static std::atomic<const uint32_t*> g_salt[COTR_MAX_DEVICES];
+const uint32_t* train_salt_ptr() { return g_salt[cotr_current_device()].load(std::memory_order_acquire); }
+void train_set_salt_ptr(const uint32_t* p) { g_salt[cotr_current_device()].store(p, std::memory_order_release); }
+// clear the registration only if it is still `expected` (a closing GraphedTrainStep must not unregister another one's salt)
+bool train_clear_salt_ptr_if(const uint32_t* expected) {
+  const uint32_t* e = expected;
+  return g_salt[cotr_current_device()].compare_exchange_strong(e, nullptr, std::memory_order_acq_rel);
+}
 
 int train_add_drop_ln_fwd(const float* x, const float* a, const float* w, const float* b, float* s_out, float* y, float* stats,
                           int rows, float p, uint32_t seed, hipStream_t s) {
@@ -669,9 +681,11 @@ int train_gemm_tn_splits(int M, int N, int K) {
 // pass over dY); part holds train_gemm_tn_splits(M, N, K) * (N * K + N) floats; out and colsum must be ONE contiguous
 // [N*K + N] buffer when both are wanted (colsum == out + N*K): the partials are then finished by a single launch
 int train_gemm_tn(const float* A, const float* B, float* part, float* out, float* colsum, int M, int N, int K, hipStream_t s) {
-  if (M <= 0) return -1;
-  if (N % 64 || K % 64) return -1;
+  if (N % 64 || K % 64 || M < 0) return -1;
   if (colsum != nullptr && colsum != out + (size_t)N * K) return -1;
+  if (M == 0) {   // an empty batch (no queries) contributes zero gradients: dW = 0, db = 0, like the other wrappers' no-ops
+    return hipMemsetAsync(out, 0, ((size_t)N * K + (colsum != nullptr ? N : 0)) * sizeof(float), s) == hipSuccess ? 0 : -2;
+  }
   const int splits = train_gemm_tn_splits(M, N, K);
   int per = (M + splits - 1) / splits;
   per = (per + 31) / 32 * 32;

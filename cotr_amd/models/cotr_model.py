@@ -165,6 +165,7 @@ class COTR(nn.Module):
         self._encoded_batch = 0
         self._ws = None             # scratch handed to the library (torch caching allocator), see _ensure_workspace
         self._ws_shape = (0, 0)
+        self._ws_pins = set()       # ids of captured graphs that have the workspace's addresses baked in (pin_workspace)
 
     # ------------------------------------------------------------------ weight synchronisation
     def _apply(self, fn, *a, **kw):  # .cuda() / .to() / .float() move or replace the storage
@@ -221,7 +222,16 @@ class COTR(nn.Module):
         need = ctypes.c_size_t()
         _lib.check(lib.cotr_scratch_bytes(self._handle, b, max(q, 1), ctypes.byref(need)), self._handle, 'cotr_scratch_bytes')
         if self._ws is None or self._ws.numel() < need.value + 256:
+            if self._ws is not None and self.__dict__.get('_ws_pins'):
+                raise _lib.CotrHipError(
+                    f'the workspace would have to grow to {need.value} bytes for {b} pairs x {q} queries, but a captured training '
+                    'step (GraphedTrainStep) has its addresses baked in: call model.reserve(max_pairs, max_queries) BEFORE '
+                    'capturing, or close() the captured step first')
             ws = torch.empty(need.value + 256, dtype=torch.uint8, device=device)
+            if self._ws is not None:
+                # the old workspace goes back to torch's caching allocator, which may hand it out on ANOTHER stream while
+                # kernels enqueued here still use it
+                self._ws.record_stream(torch.cuda.current_stream(device))
             off = (-ws.data_ptr()) % 256
             keep = int(keep_encode and b == self._ws_shape[0])     # same pairs, more queries: the cached encode moves along
             _lib.check(lib.cotr_set_workspace(self._handle, ctypes.c_void_p(ws.data_ptr() + off), need.value, keep,
@@ -246,7 +256,7 @@ class COTR(nn.Module):
     def __getstate__(self):  # the HIP handle is per process: never pickled / deep-copied
         state = self.__dict__.copy()
         state['_handle'], state['_handle_device'], state['_weights_dirty'], state['_encoded_batch'] = None, None, True, 0
-        state['_ws'], state['_ws_shape'] = None, (0, 0)
+        state['_ws'], state['_ws_shape'], state['_ws_pins'] = None, (0, 0), set()
         return state
 
     # ------------------------------------------------------------------ the path
@@ -311,6 +321,14 @@ class COTR(nn.Module):
             _lib.check(lib.cotr_decode(self._handle, qs.data_ptr(), b, q, out.data_ptr(), _lib.current_stream_ptr()),
                        self._handle, 'cotr_decode')
         return out
+
+    def pin_workspace(self, owner):
+        """A captured HIP graph (training.GraphedTrainStep) holds the workspace's addresses: until unpin_workspace(owner) the
+        workspace may not be replaced - a call that needs a larger one raises instead of silently freeing memory the graph writes."""
+        self.__dict__.setdefault('_ws_pins', set()).add(id(owner))
+
+    def unpin_workspace(self, owner):
+        self.__dict__.setdefault('_ws_pins', set()).discard(id(owner))
 
     def reserve(self, pairs, queries):
         """Size the scratch workspace for calls of up to ``pairs`` x ``queries`` (optional; it otherwise grows on demand)."""

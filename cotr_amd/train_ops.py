@@ -95,7 +95,7 @@ def gemm_tn(dy, x, with_colsum=False):
     assert dy.is_contiguous() and x.is_contiguous() and x.shape[0] == m
     extra = n if with_colsum else 0
     buf = _empty((n * k + extra,), dy)
-    part = _empty((lib.cotr_train_gemm_tn_splits(m, n, k) * (n * k + extra),), dy)
+    part = _empty((max(1, lib.cotr_train_gemm_tn_splits(m, n, k)) * (n * k + extra),), dy)
     cs = ctypes.c_void_p(buf.data_ptr() + n * k * 4) if with_colsum else None
     with _on(dy.device):
         _chk(lib.cotr_train_gemm_tn(_P(dy), _P(x), _P(part), _P(buf), cs, m, n, k, _sp()), f'cotr_train_gemm_tn {m}x{n}x{k}')

@@ -1,6 +1,6 @@
-"""Training step: the reference's stage 1 (frozen backbone, ``train_cotr.py --lr_backbone=0``) on
-hand-written HIP kernels forward AND backward, and, with layer2 / layer3 of the backbone as torch convolutions under
-autograd, its stages 2-3 (``--lr_backbone > 0``).
+"""Training step: the reference's stage 1 (frozen backbone, ``train_cotr.py --lr_backbone=0``) and its
+stages 2-3 (``--lr_backbone > 0``: layer2 / layer3 of the backbone train, backbone.py:64-69) on hand-written HIP kernels,
+forward AND backward.
 
 What runs where:
 * backbone (ResNet-50 to layer3, FrozenBN; 70 % of the forward FLOPs, no gradient in stage 1): the inference kernels,
@@ -12,8 +12,10 @@ What runs where:
   bias gradients, the lin_sine encodings and the 256 -> 2 head.  Between ``forward_train``'s entry and the loss PyTorch
   allocates tensors and records the tape; it computes nothing.  The loss (two ``mse_loss`` and a mask, cotr_trainer.py:
   124-135) and Adam stay torch;
-* stages 2-3 (``--lr_backbone > 0``): conv1 + layer1 on the HIP kernels, layer2 / layer3 as torch convolutions under autograd
-  (conv dgrad / wgrad kernels of our own are not written).
+* stages 2-3 (``--lr_backbone > 0``): conv1 + layer1 (frozen, backbone.py:66-69) on the inference kernels, layer2 / layer3
+  under autograd on the HIP kernels as well (``train_ops.ConvBN``: implicit-GEMM forward, dX as a GEMM on the cached W^T +
+  col2im, dW by the transpose-free TN kernel on an explicit im2col); the torch-convolution form is kept as a cross-check only
+  (``backbone_features_trainable(..., use_torch_convs=True)``).
 ``forward_train_torch`` is the round-1 tape (HIP GEMMs + torch ops for everything else); it is kept as an independent
 cross-check of the kernels (tests) and is not used by the product path.
 
@@ -160,19 +162,19 @@ def _bottleneck(x, blk):
     return F.relu(out + idt)
 
 
-_bn_cache = {}
-
-
 def _frozen_bn_affine(bn):
-    """(scale, bias) of a FrozenBatchNorm2d (backbone.py:46-56): buffers only -> constants, computed once per module."""
-    key = id(bn)
-    ver = tuple(t._version for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))
-    hit = _bn_cache.get(key)
-    if hit is None or hit[0] != ver or hit[1].device != bn.weight.device:
+    """(scale, bias) of a FrozenBatchNorm2d (backbone.py:46-56): buffers only -> constants, computed once per module and kept
+    ON the module (a process-wide dict keyed by id(bn) would hand a new module that reuses a dead one's address - with the same
+    version counters - the dead one's affine, and keep its device tensors alive).  Re-derived when a buffer is replaced
+    (.to() / load_state_dict assign new tensors or bump versions) or moved."""
+    bufs = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version, t.device) for t in bufs)
+    hit = bn.__dict__.get('_hip_affine')
+    if hit is None or hit[0] != key:
         with torch.no_grad():
             scale = bn.weight * (bn.running_var + 1e-5).rsqrt()
-            hit = (ver, scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
-        _bn_cache[key] = hit
+            hit = (key, scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
+        bn.__dict__['_hip_affine'] = hit          # plain attribute: not a buffer, not in the state dict
     return hit[1], hit[2]
 
 
@@ -431,6 +433,9 @@ class GraphedTrainStep:
         self.img, self.query, self.target = img.clone(), query.clone(), target.clone()
         self.salt = torch.zeros(1, dtype=torch.int32, device=img.device)
         lib = _lib.load_library()
+        # the captured graph bakes in the addresses of the library's workspace: it must not be replaced (a larger eval batch
+        # between replays) while this object is alive - pin it; a call that would have to grow it raises instead
+        model.pin_workspace(self)
         _lib.check(lib.cotr_train_set_dropout_salt(self.salt.data_ptr()), None, 'cotr_train_set_dropout_salt')
         side = torch.cuda.Stream(device=img.device)
         side.wait_stream(torch.cuda.current_stream(img.device))
@@ -463,6 +468,10 @@ class GraphedTrainStep:
         self.query.copy_(query)
         self.target.copy_(target)
         self.graph.replay()
+        # a replay updates the weights without bumping their Python version counters: a W^T cached by an eager step in between
+        # would be stale for the next eager backward
+        from . import train_ops as T
+        T.clear_weight_cache()
         if check and not bool(torch.isfinite(self.loss)):
             raise FloatingPointError('loss is not finite in a captured training step (train_batch would have skipped it)')
         return self.loss, self.pred
@@ -472,11 +481,16 @@ class GraphedTrainStep:
         object is collected: the kernels must not keep reading a word whose tensor is gone."""
         if getattr(self, 'salt', None) is not None:
             try:
-                _lib.load_library().cotr_train_set_dropout_salt(None)
+                with torch.cuda.device(self.salt.device):     # only if the registered word is still ours
+                    _lib.load_library().cotr_train_clear_dropout_salt(self.salt.data_ptr())
             except Exception:
                 pass
             self.salt = None
             self.graph = None          # (the captured step writes the salt word: it must not be replayed after this)
+            try:
+                self.model.unpin_workspace(self)
+            except Exception:
+                pass
 
     def __del__(self):
         self.close()

@@ -191,8 +191,11 @@ int cotr_train_ln_bwd(const float* dy, const float* s_in, const float* stats, co
 /* Captured (hipGraph) training steps: the seed argument of a dropout launch is baked into the graph, so every training kernel that
  * draws a mask XORs its seed with the word at `salt` (device memory, read at kernel start); the captured step advances that word
  * itself (any device-side add), so each replay draws fresh masks and forward / backward of one step agree.  NULL (default) = the
- * seeds alone.  Per host thread. */
+ * seeds alone.  The registration is per DEVICE (the current one) and process-wide: the autograd engine runs the backward kernels
+ * that recompute a mask on its own worker thread, and they must see the salt the forward drew the mask with.
+ * cotr_train_clear_dropout_salt unregisters `salt` only if it is still the registered word (COTR_ERR_STATE otherwise). */
 int cotr_train_set_dropout_salt(const unsigned int* salt);
+int cotr_train_clear_dropout_salt(const unsigned int* salt);
 /* in place x *= mask / (1-p) (n % 4 == 0); backward of y = dropout(relu(h)): dx = y > 0 ? dy / (1-p) : 0 (p == 0: relu backward) */
 int cotr_train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, cotr_stream stream);
 int cotr_train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, float p, cotr_stream stream);

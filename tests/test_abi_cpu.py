@@ -90,3 +90,23 @@ def test_no_cpu_fallback_and_shape_contract():
     mask[0, 0, 0] = True
     with pytest.raises(NotImplementedError):
         COTR._as_batch(NestedTensor(img, mask))
+
+
+def test_knob_registry_round_trip_without_a_gpu():
+    """cotr_set_* switches are process-wide; the registry (cotr_knob_count / _name / get / set / reset) is what tests and A/B
+    tools snapshot and restore through.  Setting and resetting needs no device."""
+    k0 = _lib.knobs()
+    assert len(k0) >= 17 and all(cur == dflt for cur, dflt in k0.values())
+    assert k0['head_fusion_max_rows'] == (0, 0) and k0['attention_fusion_max_rows'] == (1024, 1024)
+    try:
+        _lib.set_knob('head_fusion_max_rows', 2048)
+        _lib.set_knob('conv1x1_dense', 0)
+        assert _lib.load_library().cotr_set_ffn_fusion_max_rows(0) == 0      # the direct setters record too
+        k1 = _lib.knobs()
+        assert k1['head_fusion_max_rows'] == (2048, 0) and k1['conv1x1_dense'] == (0, 1) and k1['ffn_fusion_max_rows'] == (0, 1024)
+        with pytest.raises(_lib.CotrHipError):
+            _lib.set_knob('no_such_knob', 1)
+        assert _lib.load_library().cotr_set_knob(b'xcd_mapping', 3) != 0    # the setter's own range check applies
+    finally:
+        _lib.reset_knobs()
+    assert _lib.knobs() == k0
