@@ -8,11 +8,17 @@ Workloads
                       disabled -> one ``model(img[1,3,256,512], q[1,1000,2])`` call per step PER GPU (weak scaling).
   batch256            BASELINE.json configs[3]: 256 pairs x 1000 queries per step for the whole job, pairs sharded over the
                       ranks (32 per GPU on 8 GPUs, 256 on one), every rank holds only its own pairs (strong scaling).
-  train               BASELINE.json configs[4] / SURVEY.md 8f4: one ``COTRTrainer.train_batch`` step (cycle + bidirectional,
-                      Adam, dropout 0.1) at 16 pairs x 200 queries per GPU; value = pairs/s.  Not the headline metric.
+  train               BASELINE.json configs[4] / SURVEY.md 8f4: one STAGE-2 ``COTRTrainer.train_batch`` step (cycle + bidirectional,
+                      Adam, dropout 0.1, lr_backbone 1e-5: layer2 / layer3 of the backbone train) at 16 pairs x 200 queries per
+                      GPU; value = pairs/s; ``--stage 1`` = the frozen-backbone first stage.  Not the headline metric.
 Synthetic data and seeded random weights of the COTR architecture (no checkpoint exists offline).  Inputs are resident in
 HBM before the timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the predicted (x,y) of
 every step are all-gathered over xGMI on RCCL's stream, overlapped with the next step; no collective in the math.
+
+``python bench.py --gpus N`` with N > 1 and no torch.distributed environment starts its own ranks (it re-executes itself under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``); under an external launcher it reads
+RANK / LOCAL_RANK / WORLD_SIZE as given.  ``--dry-run --backend gloo`` runs the same launch / timing / gather plumbing on the CPU
+with a stand-in model (tests/test_bench_cpu.py): the only use of a non-HIP model, never a measurement.
 
 Prints ONE JSON line on rank 0.  ``roofline`` is for the whole forward launch sequence (one "launch" = one cotr_forward =
 the ~100 kernels of one step): achieved = FLOP(B,Q) / mean step time measured with HIP events on the launch stream, against
@@ -49,6 +55,78 @@ def flop(b, q):
     """Algorithmic work of the path, SURVEY.md 2.2 / 8(d): per pair 24.641 GFLOP (backbone, input_proj,
     encoder, decoder K/V), per query 11.273 MFLOP (6 decoder layers + final norm + corr MLP once)."""
     return b * 24.641e9 + b * q * 11.273e6
+
+
+# algorithmic work per stage of the launch sequence (cotr_set_profiling level 1 marks): per pair, the decoder per query
+STAGE_GFLOP_PER_PAIR = {'stem+pool': 0.616563, 'layer1': 3.489661, 'layer2': 5.368709, 'layer3': 7.650410, 'input_proj': 0.268435,
+                        'encoder': 6.442451, 'dec_kv': 0.805306}
+DECODER_MFLOP_PER_QUERY = 11.273216
+
+
+def stage_breakdown(model, img, qs, step_ms, reps=20):
+    """roofline.stages: us, GFLOP, TFLOP/s and fraction of the fp32-MFMA peak per stage of one forward, from HIP events recorded
+    on the launch stream at the 8 stage boundaries (cotr_set_profiling level 1: ~3 us of stream time per event, rescaled so that
+    the stages sum to the un-instrumented step time)."""
+    import collections
+    b, q = qs.shape[0], qs.shape[1]
+    model.set_profiling(1)
+    acc = collections.OrderedDict()
+    for _ in range(reps):
+        model(img, qs)
+        torch.cuda.synchronize()
+        for name, ms in model.get_profile():
+            acc[name] = acc.get(name, 0.0) + ms
+    model.set_profiling(0)
+    raw = sum(acc.values()) / reps
+    scale = step_ms / raw if raw > 0 else 1.0
+    out = collections.OrderedDict()
+    for name, ms in acc.items():
+        us = ms / reps * scale * 1e3
+        gf = b * STAGE_GFLOP_PER_PAIR[name] if name in STAGE_GFLOP_PER_PAIR else (b * q * DECODER_MFLOP_PER_QUERY / 1e3 if name == 'decoder' else 0.0)
+        e = {'us': round(us, 1), 'gflop': round(gf, 3)}
+        if gf > 0 and us > 0:
+            e['tflops'] = round(gf / us * 1e3, 1)
+            e['frac'] = round(gf / us * 1e3 / PEAK_FP32_MFMA_TFLOPS, 3)
+        out[name] = e
+    return out
+
+
+def dominant_kernel(n_forward=20, timeout_s=240):
+    """roofline.dominant_kernel: the kernel symbol with the largest total time in a rocprofv3 --kernel-trace --stats pass of
+    this script's own forward loop (child process), with its launches per forward and average duration."""
+    exe = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if exe is None:
+        return {'error': 'rocprofv3 not found'}
+    tmp = tempfile.mkdtemp(prefix='cotr_kt_', dir='/tmp')
+    try:
+        cmd = [exe, '--kernel-trace', '--output-format', 'csv', '-d', tmp, '-o', 'kt', '--',
+               sys.executable, os.path.abspath(__file__), '--traffic-child', str(n_forward)]
+        r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           timeout=timeout_s)
+        files = glob.glob(os.path.join(tmp, '**', '*kernel_trace.csv'), recursive=True)
+        if r.returncode != 0 or not files:
+            return {'error': f'rocprofv3 --kernel-trace failed (rc {r.returncode})'}
+        rows = list(csv.DictReader(open(files[0])))
+        rows.sort(key=lambda row: int(row['Start_Timestamp']))
+        starts = [i for i, row in enumerate(rows) if 'stem_pool_kernel' in row['Kernel_Name']]
+        if len(starts) < n_forward + 1:
+            return {'error': f'expected {n_forward + 3} forwards in the trace, found {len(starts)}'}
+        steady = rows[starts[-n_forward]:]
+        tot, cnt = {}, {}
+        for row in steady:
+            k = row['Kernel_Name']
+            tot[k] = tot.get(k, 0) + int(row['End_Timestamp']) - int(row['Start_Timestamp'])
+            cnt[k] = cnt.get(k, 0) + 1
+        busy = sum(tot.values())
+        k = max(tot, key=tot.get)
+        return {'name': k, 'launches_per_forward': cnt[k] / n_forward, 'avg_us': round(tot[k] / cnt[k] / 1e3, 2),
+                'us_per_forward': round(tot[k] / n_forward / 1e3, 1), 'share_of_kernel_time': round(tot[k] / busy, 3),
+                'kernel_busy_us_per_forward': round(busy / n_forward / 1e3, 1), 'launches_per_forward_all': len(steady) / n_forward,
+                'source': f'rocprofv3 --kernel-trace child of this run, {n_forward} forwards (rocprofv3 adds ~2.5 us to every short kernel)'}
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+        return {'error': f'{type(e).__name__}: {e}'}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def min_hbm_bytes(b, q):
@@ -247,7 +325,8 @@ def cpu_baseline(budget_s=12.0):
                      f'(torch CPU, {cores} threads), {dt:.1f} s',
            'note': 'the port applies decoder.norm + corr_embed to the LAST decoder layer only and skips the head-averaged '
                    'attention maps nn.MultiheadAttention also returns; the reference computes both for all 6 layers and '
-                   'discards them (cotr_model.py:37-39), so the port is a FASTER baseline than the reference itself'}
+                   'discards them (cotr_model.py:37-39), so the port is a FASTER baseline than the reference itself.  The reference '
+                   '(/root/reference, Python) does not exist on the GPU box: kind "port" there, "reference" timing added where it is importable'}
     if ref_import.reference_available():     # authoring container only: the unmodified reference, same inputs
         try:
             model = ref_import.build_reference_model()
@@ -269,11 +348,14 @@ def run_train(args, dev, world, rank):
     from cotr_amd.models import build_model
     from cotr_amd.utils.synth import synth_state_dict
     pairs, nq = 16, 200                       # BASELINE.json configs[4]: bs=16 per GPU, 200 queries, cycle + bidirectional
-    model = build_model(cotr_amd.default_args(dropout=0.1)).to(dev)
+    # stage 2 of the reference recipe (readme.md:50, train_cotr.py --lr_backbone=1e-5): layer2 / layer3 of the backbone train
+    # (backbone.py:64-69) - what BASELINE.json configs[4] names; --stage 1 = the frozen-backbone first stage (lr_backbone 0)
+    lr_backbone = 1e-5 if args.stage == 2 else 0.0
+    model = build_model(cotr_amd.default_args(dropout=0.1, lr_backbone=lr_backbone)).to(dev)
     model.load_state_dict(synth_state_dict(0))
     model.train()
     graphed = args.graphed_train
-    optim = training.optimizer_for(model, learning_rate=1e-4, capturable=graphed)
+    optim = training.optimizer_for(model, learning_rate=1e-4, lr_backbone=lr_backbone, capturable=graphed)
     g = torch.Generator().manual_seed(5 + rank)
     img = torch.randn(pairs, 3, 256, 512, generator=g).to(dev)
     query, target = torch.rand(pairs, nq, 2, generator=g).to(dev), torch.rand(pairs, nq, 2, generator=g).to(dev)
@@ -306,12 +388,82 @@ def run_train(args, dev, world, rank):
             'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[4]: 16 pairs x 200 queries per GPU, cycle consistency + bidirectional, '
-                                   'dropout 0.1, Adam lr 1e-4, frozen backbone (stage 1 of the reference recipe)',
+            'config': {'workload': ('BASELINE.json configs[4]: stage-2 training step, 16 pairs x 200 queries per GPU, cycle consistency + '
+                                    'bidirectional, dropout 0.1, Adam lr 1e-4, lr_backbone 1e-5 (layer2 / layer3 of the backbone train)'
+                                    if args.stage == 2 else
+                                    'stage 1 of the reference recipe (NOT configs[4]): the same step with the backbone frozen (lr_backbone 0)'),
+                       'stage': args.stage, 'lr_backbone': lr_backbone,
                        'pairs_per_gpu': pairs, 'queries_per_pair': nq,
                        'step': 'captured HIP graph (GraphedTrainStep)' if graphed else 'eager train_batch',
                        'parallelism': f'data parallel x{world}, reduce-scatter + all-gather of the gradients' if world > 1 else 'single GPU'},
         }), flush=True)
+
+
+def reduce_elapsed(elapsed, steps, dev, world):
+    """-> (max over the ranks of the timed region, [ms per step of every rank]); one all-gather of a scalar."""
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    vals = [float(v.item()) for v in every]
+    return max(vals), [v / steps * 1e3 for v in vals]
+
+
+def dry_run(args, world, rank):
+    """The launcher / rendezvous / barrier / max-over-ranks timing / gather / one-JSON-line plumbing of this file on the CPU
+    (gloo), with a stand-in for the model: proves that `python bench.py --gpus N` starts its own ranks and that rank 0 alone
+    prints the line, before a driver ever runs it on 8 GPUs.  Nothing here is a measurement of the product."""
+    from cotr_amd.dist import all_gather_rows, shard_range
+    if args.steps is None:
+        args.steps = 3
+    if args.warmup is None:
+        args.warmup = 1
+    dev = torch.device('cpu')
+    if world > 1:
+        dist.init_process_group('gloo')
+    batch256 = args.workload == 'batch256'
+    total_pairs = 8 if batch256 else world                    # (a small stand-in for the 256 pairs)
+    lo, hi = shard_range(total_pairs, world, rank)
+    pairs = hi - lo
+    counts = [shard_range(total_pairs, world, r)[1] - shard_range(total_pairs, world, r)[0] for r in range(world)]
+    g = torch.Generator().manual_seed(1 + rank)
+    img, qs = torch.randn(pairs, 3, 16, 32, generator=g), torch.rand(pairs, 10, 2, generator=g)
+    fake = lambda i, q: {'pred_corrs': q * 0.5 + i.mean(dim=(1, 2, 3)).view(-1, 1, 1)}
+    finish = None
+
+    def step():
+        out = fake(img, qs)['pred_corrs']
+        return all_gather_rows(out, counts, async_op=True) if world > 1 else ((lambda: out), None)
+
+    for _ in range(args.warmup):
+        finish, w = step()
+        if w is not None:
+            w.wait()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    works = []
+    for _ in range(args.steps):
+        finish, w = step()
+        works.append(w)
+    for w in works:
+        if w is not None:
+            w.wait()
+    gathered = finish()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
+    if world > 1:
+        elapsed, rank_ms = reduce_elapsed(elapsed, args.steps, dev, world)
+    if rank == 0:
+        print(json.dumps({'metric': 'DRY RUN (CPU stand-in model, gloo): plumbing only, not a measurement', 'value': total_pairs * 10 * args.steps / elapsed,
+                          'unit': 'query-correspondences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': elapsed / args.steps * 1e3, 'ms_per_step_ranks': {'min': min(rank_ms), 'max': max(rank_ms)},
+                          'higher_is_better': True, 'scaling': 'strong' if batch256 else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                          'data': 'synthetic', 'dry_run': True, 'gathered_rows': int(gathered.shape[0]),
+                          'config': {'workload': f'dry run of --workload {args.workload}', 'pairs_per_gpu': pairs}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -328,6 +480,11 @@ def main():
                     help='roofline.traffic: measured by a rocprofv3 --pmc child of this run (auto: when available, N == 1, extras '
                          'on), or the committed profile')
     ap.add_argument('--traffic-child', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl', help='torch.distributed backend (nccl = RCCL; gloo with --dry-run)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU plumbing check (tests): stand-in model, same launch / barrier / timing / gather / JSON code; never a measurement')
+    ap.add_argument('--stage', type=int, choices=[1, 2], default=2,
+                    help='--workload train: 2 (default, BASELINE.json configs[4]) = lr_backbone 1e-5, layer2/3 train; 1 = frozen backbone')
     ap.add_argument('--set', action='append', default=[], metavar='KNOB=INT',
                     help='experiments: call cotr_set_<KNOB>(INT) first, e.g. --set attention_fusion_max_rows=0')
     args = ap.parse_args()
@@ -338,20 +495,31 @@ def main():
     if args.warmup is None:
         args.warmup = {'headline': 20, 'batch256': 2, 'train': 3}[args.workload]
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` as the driver calls it: start one rank per GPU ourselves (torch.distributed.run on this node,
+        # loopback rendezvous on a free port) and hand over; rank 0 of the child job prints the JSON line
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs the MI355X (no CPU fallback of the product path)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group(args.backend, device_id=dev if args.backend == 'nccl' else None)
 
     import cotr_amd
     from cotr_amd import _lib
@@ -412,10 +580,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, rank_ms = reduce_elapsed(elapsed, args.steps, dev, world)
     kernel_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)) / args.steps  # HIP events, launch stream
 
     if rank == 0:
@@ -436,6 +603,7 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': ms_per_step,
+            'ms_per_step_ranks': {'min': min(rank_ms), 'max': max(rank_ms)},
             'higher_is_better': True,
             'scaling': 'strong' if batch256 else 'weak',
             'vs_baseline': None,
@@ -470,6 +638,8 @@ def main():
         roof['traffic_note'] = ('bytes per forward crossing L2<->fabric (Infinity Cache / HBM): rocprofv3 PMC FETCH_SIZE x2 (gfx950) + '
                                 f'WRITE_SIZE, separate passes; algorithmic minimum {min_hbm_bytes(pairs, QUERIES) / 1e6:.1f} MB')
         if extras:
+            roof['stages'] = stage_breakdown(model, img, qs, kernel_ms)
+            roof['dominant_kernel'] = dominant_kernel()
             roof['kernels'] = kernel_breakdown(model, img, qs, kernel_ms)
             roof['launches_per_forward'] = roof['kernels']['launches_per_forward']
             line['also_measured'] = other_regimes(synth_state_dict(0), dev)

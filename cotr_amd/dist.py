@@ -102,7 +102,22 @@ class PairShardedModel:
             counts = [shard_range(B, world, r)[1] - shard_range(B, world, r)[0] for r in range(world)]
             finish, _ = all_gather_rows(local, counts, self.group)
             return {'pred_corrs': finish()}
-        # fewer pairs than ranks: every rank encodes all pairs, decodes a slice of the queries
+        if world % B == 0:
+            # fewer pairs than ranks, ranks a multiple of the pairs (the dense initial pass: 1, 2 or 4 patch pairs x 131072 grid
+            # queries on 8 GPUs): world / B ranks share one pair - each encodes ONLY that pair and decodes its slice of the
+            # pair's queries (queries are independent: no query self-attention, transformer.py:185-201).  Rank order = (pair,
+            # slice), so the gathered rows are the [B, Q, 2] tensor as it lies in memory.
+            g = world // B
+            pair, sub = rank // g, rank % g
+            lo, hi = shard_range(Q, g, sub)
+            if hi > lo:
+                local = self.model(samples[pair:pair + 1], queries[pair:pair + 1, lo:hi])['pred_corrs'][0]
+            else:
+                local = queries.new_zeros((0, 2))
+            counts = [shard_range(Q, g, r % g)[1] - shard_range(Q, g, r % g)[0] for r in range(world)]
+            finish, _ = all_gather_rows(local.contiguous(), counts, self.group)
+            return {'pred_corrs': finish().view(B, Q, 2)}
+        # otherwise: every rank encodes all pairs, decodes a slice of the queries
         lo, hi = shard_range(Q, world, rank)
         if hi > lo:
             local = self.model(samples, queries[:, lo:hi])['pred_corrs']
@@ -138,12 +153,21 @@ def sharded_zoom_engine(*args, group=None, **kwargs):
     independent (COTR/inference/refinement_task.py: a task only sees its own crops), so every rank refines a contiguous
     block with its own GPU and the per-task results are gathered as ONE packed float64 tensor
     (all_gather_into_tensor; [tasks, 4 + 2*(levels+1)] + one bookkeeping row per rank); no collective in the data path.
-    The dense initial pass, task generation and the early-exit bookkeeping are replicated; numpy's global RNG, which
-    task generation draws from, is synchronised from rank 0 first, so all ranks return the same correspondences as a
-    single-GPU run with rank 0's RNG state, bit for bit."""
+    The dense initial pass (inference_helper.py:105-165: every patch pair x the 131072-query grid - most of config 2's
+    model time before the zoom levels) is sharded too: its one model call goes through ``PairShardedModel`` (patch pairs over
+    the ranks; with fewer pairs than ranks the ranks of a pair split its queries and encode only that pair), ONE all-gather of
+    the [P,131072,2] prediction, then the post-processing, task generation and early-exit bookkeeping run replicated on the
+    gathered tensor; numpy's global RNG, which task generation draws from, is synchronised from rank 0 first.  All ranks
+    return the same correspondences; they equal a single-GPU run with rank 0's RNG state bit for bit when the model gives the
+    same bits for a pair whatever the batch shape (the fake models of the tests; the HIP model may pick another GEMM
+    configuration for another shape and then agrees to ~1e-4 px)."""
     from .inference.zoom_engine import RefineResult, ZoomEngine
 
     class ShardedZoomEngine(ZoomEngine):
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            self._dense_model = PairShardedModel(self.model, group)     # ZoomEngine.flow calls this for the dense pass
+
         def gen_tasks(self, *a, **kw):
             broadcast_numpy_rng(group)
             return super().gen_tasks(*a, **kw)

@@ -477,7 +477,8 @@ class ZoomEngine:
         jj, ii = np.meshgrid(np.arange(MAX_SIZE * 2), np.arange(MAX_SIZE))
         q_grid = np.stack([jj / (MAX_SIZE * 2), ii / MAX_SIZE], axis=-1)               # [256,512,2] float64
         q = torch.from_numpy(q_grid.reshape(1, -1, 2)).float().to(device).expand(len(pairs), -1, -1).contiguous()
-        pred = self.model(img, q)['pred_corrs']
+        # (cotr_amd.dist.sharded_zoom_engine routes this one call through a PairShardedModel: pairs / queries over the ranks)
+        pred = getattr(self, '_dense_model', self.model)(img, q)['pred_corrs']
         self.total_tasks += len(pairs)
         corr_a, con_a, corr_b, con_b = self.make_dense_post(device)(pred, pairs, img_a.shape, img_b.shape)
         res_a = res_b = None

@@ -125,6 +125,19 @@ def _engine_worker(rank, world, port, golden_dir, out_dir):
                                   make_dense_post=host_dense_post_factory)
         out = run_dense_case(g, eng)
         ok &= np.array_equal(out[0], g['corrs']) and np.array_equal(ids(out[1]), g['idx'])
+    # the dense initial pass itself is sharded: with 4 patch pairs on 2 ranks each rank's model saw 2 of them (131072 grid
+    # queries each), never all 4; with ONE patch pair (square images) the two ranks split its queries
+    dense_calls = [c for c in eng.model.calls if c[1][1] == 131072]
+    ok &= len(dense_calls) >= 1 and all(c[0][0] == 2 for c in dense_calls)
+    sq_a, sq_b = synthetic_pair(3, shape_a=(300, 300), shape_b=(320, 320))
+    eng1 = sharded_zoom_engine(CyclicFakeModel(), max_pairs=40, make_cropper=pil_cropper_factory,
+                               make_dense_post=host_dense_post_factory)
+    solo = sharded_zoom_engine(CyclicFakeModel(), max_pairs=40, make_cropper=pil_cropper_factory,
+                               make_dense_post=host_dense_post_factory)
+    solo._dense_model = solo.model                                             # the unsharded dense pass, same process
+    f1, f0 = eng1.flow(sq_a, sq_b, resample=False), solo.flow(sq_a, sq_b, resample=False)
+    ok &= all(np.array_equal(a, b) for a, b in zip(f1, f0) if a is not None)
+    ok &= [c[1] for c in eng1.model.calls] == [(1, 65536, 2)] and [c[1] for c in solo.model.calls] == [(1, 131072, 2)]
     torch.save(bool(ok), os.path.join(out_dir, f'e{rank}.pt'))
     dist.destroy_process_group()
 

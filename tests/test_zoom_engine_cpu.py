@@ -173,6 +173,8 @@ def run_faster_case(name, g, tasks_only, **engine_kw):
     seed, kind, nq, max_corrs, conv, force, known, bs, load = FASTER_CASES[name]
     img_a, img_b = synthetic_pair(seed)
     model = FakeModel() if kind == 'fake' else CyclicFakeModel()
+    if engine_kw.pop('on_device', False):        # parameters on the GPU: the engine cuts its crops with the HIP kernel
+        model = model.cuda()
     eng = FasterSparseEngine(model, bs, mode='tile', max_load=load)
     for k, v in engine_kw.items():
         setattr(eng, k, v)

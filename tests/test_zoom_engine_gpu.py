@@ -270,3 +270,65 @@ def test_stretching_mode_on_device():
     assert (corrs[:, 2] < img_b.shape[1]).all() and (corrs[:, 3] < img_b.shape[0]).all()
     with pytest.raises(ValueError):
         ZoomEngine(CyclicFakeModel().cuda(), mode='pyramid')
+
+
+# ---- FasterSparseEngine on the device (sparse_engine.py:267-427) ------------------------------------------------------------
+@pytest.mark.parametrize('name', ['engine_faster_known', 'engine_faster_dense', 'engine_faster_dense_q', 'engine_faster_force_q'])
+def test_faster_sparse_engine_with_device_crops_matches_the_reference_class(name, golden_dir):
+    """The goldens of the reference's own FasterSparseEngine (pilots, squads, np.random.permutation order, zero-padded grouped
+    model calls, the fallback loop) reproduced with every crop pair cut by the HIP kernel (Pillow-exact, so the fake model sees
+    the reference's pixels): correspondences, identifiers, crop bookkeeping and the model-call shapes, bit for bit.  The dense
+    initial pass keeps the host post-processing recipe here (the device one differs from torch-CPU's grid_sample in the last
+    bits, which can flip a borderline 'confident' pixel and with it the random draw - it has its own map-wise tests above)."""
+    from tests.test_zoom_engine_cpu import FASTER_CASES, run_faster_case
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    (corrs, idx), eng, model = run_faster_case(name, g, False, on_device=True, make_dense_post=dense_post.host_dense_post_factory)
+    assert next(model.parameters()).is_cuda and eng.make_cropper.__name__ == '_DeviceCropper'
+    assert np.array_equal(np.asarray(corrs, dtype=np.float64).reshape(-1, 4), g['corrs'])
+    assert np.array_equal(ids(idx), g['idx'])
+    assert eng.total_tasks - 4 == int(g['total_tasks'])
+    known = FASTER_CASES[name][6]
+    ref_calls = [(int(r[0]), int(r[5])) for r in g['calls']][8 if known else 4:]
+    own_calls = [(a[0], b[1]) for a, b in model.calls][2 if known else 1:]
+    assert own_calls == ref_calls
+    assert any(q > 1 for _, q in own_calls)                  # squads really formed: grouped calls with several queries per pilot
+
+
+def test_grouped_call_of_32_pilots_x_257_queries_through_the_real_model():
+    """infer_batch_grouped at its largest shape (sparse_engine.py:277-282, 295-369): 32 pilots, each with max_load = 256 riders
+    -> one model call img[32,3,256,512] x q[32,257,2] on crops cut by the device kernel.  Squads are forced by construction
+    (32 well separated clusters of 257 tasks within a few pixels of each other); the HIP model's answers are checked against
+    the CPU oracle on the same crops for three of the pilots, and every task steps with its own answer."""
+    from cotr_amd.inference import FasterSparseEngine
+    from cotr_amd.inference.zoom_engine import ZoomTask
+    sd = synth_state_dict(0)
+    hip = build_model(cotr_amd.default_args()).cuda().eval()
+    hip.load_state_dict(sd)
+    img_a, img_b = synthetic_pair(9, shape_a=(640, 640), shape_b=(640, 640))
+    rng = np.random.default_rng(2)
+    zoom = 0.125                                              # 80-pixel crops: the central half is +-20 px around the pilot
+    centres = [(60 + 90 * (c % 6) + 40, 60 + 90 * (c // 6) + 30) for c in range(32)]
+    tasks = []
+    for cx, cy in centres:
+        for _ in range(257):
+            f = np.array([cx, cy]) + rng.uniform(-3, 3, 2)
+            t = np.array([cx + 7, cy - 5]) + rng.uniform(-3, 3, 2)
+            tasks.append(ZoomTask(img_a.shape, img_b.shape, f, t, 1.0, 1.0, 1, [zoom]))
+    eng = FasterSparseEngine(hip, 32, mode='tile', max_load=256)
+    np.random.seed(4)
+    squads, boxes, queries = eng._form_grouped_batch(zoom, tasks)
+    assert len(squads) == 32 and all(len(m) == 257 for m in squads) and queries.shape == (32, 257, 2)
+    assert all(t.submitted for t in tasks)
+    device = next(hip.parameters()).device
+    cropper = eng.make_cropper(img_a, img_b, device)
+    out = eng._forward(cropper, boxes, queries, device, count=False)
+    assert out.shape == (32, 257, 2) and np.isfinite(out).all()
+    buf = torch.empty((32, 3, 256, 512), dtype=torch.float32, device=device)
+    crops = cropper(boxes, buf).cpu()
+    for i in (0, 13, 31):
+        ref = cotr_oracle.cotr_forward(sd, crops[i:i + 1], torch.from_numpy(queries[i:i + 1]))
+        assert cotr_oracle.px_err(torch.from_numpy(out[i:i + 1]), ref) < 1e-3, i
+    for i, members in enumerate(squads):                      # the loop body of cotr_corr_multiscale (:389-393)
+        for j, t in enumerate(members):
+            t.step(out[i, j])
+    assert all(not t.submitted and t.total_iter == 1 for t in tasks)
