@@ -112,6 +112,7 @@ _PROTOS = {
                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_set_ffn_tail': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_conv1x1_dense': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_ws_flags': (ctypes.c_int, [ctypes.c_int]),
     'cotr_knob_count': (ctypes.c_int, []),
     'cotr_knob_name': (ctypes.c_char_p, [ctypes.c_int]),
     'cotr_get_knob': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -1309,6 +1309,13 @@ int cotr_set_conv_patch(int enable) {
   return COTR_OK;
 }
 
+int cotr_set_ws_flags(int flags) {
+  if (flags < 0 || flags > 3) return COTR_ERR_ARG;
+  gemm_set_ws_flags(flags);
+  knob_record("ws_flags", flags);
+  return COTR_OK;
+}
+
 int cotr_set_conv1x1_dense(int enable) {
   gemm_set_conv1x1_dense(enable != 0);
   knob_record("conv1x1_dense", enable != 0);
@@ -1361,6 +1368,7 @@ Knob* knob_table(int* n) {
       {"attention_wide_min_rows", cotr_set_attention_wide_min_rows, 4096, 4096},
       {"attention_splits", cotr_set_attention_splits, 0, 0},
       {"conv1x1_dense", cotr_set_conv1x1_dense, 1, 1},
+      {"ws_flags", cotr_set_ws_flags, 2, 2},
   };
   *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
   return knobs;

@@ -108,6 +108,7 @@ struct GemmParams {
   int colscale_n;
   const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
   int xcd_msplit;      // workgroup -> tile mapping, see gemm_tile_coords
+  int ws_flags;        // wave-specialised large tiles (gemm_big.hip): priorities, see gemm_set_ws_flags
   // launch-time divisors (gemm_fill_divs, called by every launch helper): column tiles of the launch's tile shape; the
   // convolution's pixel decomposition (Hout * 2*Wout, 2*Wout, Wout), channel tiles per tap (Cin / 32), ksize; the x + pos
   // prologue's row period and column period; the row period of a table residual
@@ -203,6 +204,7 @@ void gemm_set_xcd_policy(int v);  // 0 column tiles over XCDs, 1 by operand size
 bool gemm_cfg_supports_ln(int cfg);
 void gemm_set_ks3(int v);
 void gemm_set_patch(int v);
+void gemm_set_ws_flags(int v);
 void gemm_set_conv1x1_dense(int v);  // 1 (default): 1x1 stride-1 convolutions run the dense instantiation of their configuration  // 1 (default): three-stage LDS-DMA k-split instead of the two-stage one where K >= 768
 const float* gemm_zero_buffer();  // per-DEVICE buffer of zeros (LDS-DMA padding source), on the current device
 

@@ -729,6 +729,8 @@ static const GemmCfg kCfgs[] = {
     {8, 5, 2, 1},   // 37 wave-private, 8 waves, 64x32, 1 slot
     {8, 6, 1, 1},   // 38 wave-private, 4 waves, 32x32, 4 slots
     {8, 7, 1, 0},   // 39 wave-private, 8 waves, 32x16, 2 slots
+    {5, 0, 2, 2},   // 40 large tile 128x128, wave-specialised: 4 loader + 4 MFMA wavefronts, three LDS stages (gemm_big.hip, gemm_ws_body)
+    {5, 0, 2, 1},   // 41 large tile 128x64, wave-specialised
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -844,6 +846,8 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 30: return launch_ks<8, 1, 0, MODE, 3>(p, s);
     case 31: return launch_ks<8, 1, 0, MODE, 4>(p, s);
     case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: return launch_gemm_wp(MODE, kCfgs[cfg].a, p, s);
+    case 40: return launch_gemm_big(MODE, 4, p, s);
+    case 41: return launch_gemm_big(MODE, 5, p, s);
     default: return -1;
   }
 }

@@ -329,6 +329,9 @@ int cotr_set_attention_splits(int ns);
 /* 1 (default): a 1x1 stride-1 convolution is launched as the dense product of its pixel rows (same configuration, same
  * summation order, bit-identical) - the dense kernels skip the per-row pixel decomposition of the convolution prologue */
 int cotr_set_conv1x1_dense(int enable);
+/* wave-specialised large-tile GEMM (configurations 40 / 41: 4 loader + 4 MFMA wavefronts): bit 0 = raised issue priority around
+ * the MFMA wavefronts' loop, bit 1 (default) = raised priority for the loader wavefronts */
+int cotr_set_ws_flags(int flags);
 /* The process-wide switches above as a registry (name = the part after cotr_set_): count / name enumerate them, get returns
  * the current and the shipped default value, set is cotr_set_<name>(value), reset puts EVERY switch back to its default.
  * Tests and A/B tools snapshot and restore through these instead of hand-written constants. */

@@ -8,7 +8,7 @@ from cotr_amd import _lib
 
 lib = _lib.load_library()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-CFGS = [2, 26, 27, 28, 29]
+CFGS = [2, 26, 27, 28, 29, 40, 41]
 P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
 us = ctypes.c_float()
 g = torch.Generator().manual_seed(0)
