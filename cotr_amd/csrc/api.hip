@@ -67,6 +67,7 @@ thread_local std::string g_create_error;
 int g_head_fuse_max_rows = 0;     // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower at 1000 rows: 63 workgroups each pull all 512 KB of weights; off)
 int g_attn_fuse_max_rows = 1024;  // attention with the out-projection (and, in the decoder, the q projection) fused in, up to this many rows
 int g_pos_table_min_rows = 8192;  // token rows from which the encoder in-projection / decoder K-V projection take pos . W^T from the tables
+int g_bottleneck_max_pairs = 2;   // layer1 bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass; 0 = never
 int g_ffn_fuse_max_rows = 1024;  // fused FFN block up to this many rows (forward at B=1,Q=1000: 1.064 vs 1.083 ms; slower from ~1300 rows on)
 }  // namespace
 
@@ -78,6 +79,9 @@ struct cotr_ctx {
   size_t wfloats = 0;
   bool loaded = false;
   std::vector<ConvW> convs;  // execution order: stem, then per block conv1, conv2, conv3, [downsample]
+  // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
+  struct FusedBlock { const float *w2p = nullptr, *w3p = nullptr, *wdp = nullptr; };
+  FusedBlock l1_fused[3];
   const float *ip_w = nullptr, *ip_b = nullptr;
   std::vector<EncW> enc;
   std::vector<DecW> dec;
@@ -525,6 +529,19 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
       inplanes = planes * 4;
     }
   }
+  // layer1 (convs[1..10]: block 0 = conv1, conv2, conv3, downsample; blocks 1, 2 = conv1, conv2, conv3): fragment images
+  size_t l1_w2p[3], l1_w3p[3], l1_wdp = 0;
+  for (int b = 0; b < 3; ++b) {
+    const int c1i = b == 0 ? 1 : 5 + 3 * (b - 1);
+    l1_w2p[b] = reserve(36864);
+    l1_w3p[b] = reserve(16384);
+    bottleneck_pack_w2(&host[convs[c1i + 1].w], &host[l1_w2p[b]]);
+    bottleneck_pack_w3(&host[convs[c1i + 2].w], &host[l1_w3p[b]]);
+    if (b == 0) {
+      l1_wdp = reserve(16384);
+      bottleneck_pack_w3(&host[convs[c1i + 3].w], &host[l1_wdp]);
+    }
+  }
   const size_t ip_w = put("input_proj.weight", (size_t)D * CFEAT), ip_b = put("input_proj.bias", D);
 
   struct EncOff { size_t v[12]; };
@@ -597,6 +614,11 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
   const float* base = h->wbuf;
   h->convs.clear();
   for (const auto& c : convs) h->convs.push_back({base + c.w, base + c.scale, base + c.bias, c.cin, c.cout, c.k, c.stride});
+  for (int b = 0; b < 3; ++b) {
+    h->l1_fused[b].w2p = base + l1_w2p[b];
+    h->l1_fused[b].w3p = base + l1_w3p[b];
+    h->l1_fused[b].wdp = b == 0 ? base + l1_wdp : nullptr;
+  }
   h->ip_w = base + ip_w; h->ip_b = base + ip_b;
   h->enc.clear();
   for (const auto& e : enc)
@@ -707,6 +729,16 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
         float* y = outbuf[flip];
         flip ^= 1;
         int r;
+        if (st == 0 && Bc <= g_bottleneck_max_pairs && H == 64 && W == 64) {
+          // the whole bottleneck - conv1, conv2, conv3, (downsample,) FrozenBN, identity, ReLU - in one launch (bottleneck.hip)
+          const ConvW* cd = (b == 0) ? &h->convs[ci++] : nullptr;
+          KCHK(h, launch_bottleneck(x, y, Bc, c1.cin, c1.w, h->l1_fused[b].w2p, h->l1_fused[b].w3p, h->l1_fused[b].wdp, c1.scale,
+                                    c1.bias, c2.scale, c2.bias, c3.scale, c3.bias, cd ? cd->scale : nullptr, cd ? cd->bias : nullptr, s),
+               "bottleneck");
+          if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "bottleneck layer1.%d %d pairs", b, Bc); prof_mark(h, nm, s, 2); }
+          x = y;
+          continue;
+        }
         const float* idt = x;
         bool c1_done = false;
         if (b == 0) {  // downsample branch (1x1, strided)
@@ -1309,6 +1341,39 @@ int cotr_set_conv_patch(int enable) {
   return COTR_OK;
 }
 
+int cotr_set_bottleneck_max_pairs(int pairs) {
+  g_bottleneck_max_pairs = pairs < 0 ? 0 : pairs;
+  knob_record("bottleneck_max_pairs", g_bottleneck_max_pairs);
+  return COTR_OK;
+}
+
+// one layer1 bottleneck from UNPACKED weights (tests): w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wd [256][64] or NULL (device
+// pointers); packs the fragment images on the host and launches bottleneck.hip
+int cotr_op_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2, const float* w3, const float* wd,
+                       const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
+                       const float* sd, const float* bd, cotr_stream stream) {
+  if (!x || !y || !w1 || !w2 || !w3 || B <= 0) return COTR_ERR_ARG;
+  std::vector<float> hw2(36864), hw3(16384), hwd(16384), packed(36864 + 2 * 16384);
+  if (hipMemcpy(hw2.data(), w2, hw2.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return COTR_ERR_HIP;
+  if (hipMemcpy(hw3.data(), w3, hw3.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return COTR_ERR_HIP;
+  bottleneck_pack_w2(hw2.data(), packed.data());
+  bottleneck_pack_w3(hw3.data(), packed.data() + 36864);
+  if (wd) {
+    if (hipMemcpy(hwd.data(), wd, hwd.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return COTR_ERR_HIP;
+    bottleneck_pack_w3(hwd.data(), packed.data() + 36864 + 16384);
+  }
+  float* dev = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&dev), packed.size() * 4) != hipSuccess) return COTR_ERR_HIP;
+  int rc = COTR_ERR_HIP;
+  if (hipMemcpy(dev, packed.data(), packed.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+    rc = op_ret(launch_bottleneck(x, y, B, cin, w1, dev, dev + 36864, wd ? dev + 36864 + 16384 : nullptr, s1, b1, s2, b2, s3, b3, sd, bd,
+                                  static_cast<hipStream_t>(stream)));
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) rc = COTR_ERR_HIP;
+  }
+  (void)hipFree(dev);
+  return rc;
+}
+
 int cotr_set_ws_flags(int flags) {
   if (flags < 0 || flags > 3) return COTR_ERR_ARG;
   gemm_set_ws_flags(flags);
@@ -1369,6 +1434,7 @@ Knob* knob_table(int* n) {
       {"attention_splits", cotr_set_attention_splits, 0, 0},
       {"conv1x1_dense", cotr_set_conv1x1_dense, 1, 1},
       {"ws_flags", cotr_set_ws_flags, 2, 2},
+      {"bottleneck_max_pairs", cotr_set_bottleneck_max_pairs, 2, 2},
   };
   *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
   return knobs;

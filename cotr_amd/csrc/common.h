@@ -262,3 +262,11 @@ int launch_ffn_fused_pre(const float* X, const float* pre_w, const float* pre_b,
                          const float* W2, float* P, int M, int nch, hipStream_t s);
 int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const float* residual, const float* pre_w,
                          const float* pre_b, const float* w, const float* b, float* y, int rows, hipStream_t s);
+
+// one whole layer1 bottleneck in one launch (bottleneck.hip); w2p / w3p / wdp are the packed fragment arrays (bottleneck_pack_*)
+int launch_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2p, const float* w3p, const float* wdp,
+                      const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
+                      const float* sd, const float* bd, hipStream_t s);
+void bottleneck_pack_w2(const float* w2 /*[64][576]*/, float* w2p /*[36864]*/);
+void bottleneck_pack_w3(const float* w3 /*[256][64]*/, float* w3p /*[16384]*/);
+

@@ -329,6 +329,16 @@ int cotr_set_attention_splits(int ns);
 /* 1 (default): a 1x1 stride-1 convolution is launched as the dense product of its pixel rows (same configuration, same
  * summation order, bit-identical) - the dense kernels skip the per-row pixel decomposition of the convolution prologue */
 int cotr_set_conv1x1_dense(int enable);
+/* layer1's bottlenecks (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity / downsample, FrozenBN, ReLU: torchvision
+ * Bottleneck.forward, COTR/models/backbone.py:46-56) run as ONE launch each (bottleneck.hip) for passes of up to this many pairs
+ * (default 2: the latency-bound regime; 0 = never): 9 launches of layer1 become 3 */
+int cotr_set_bottleneck_max_pairs(int pairs);
+/* one layer1 bottleneck from unpacked device weights (tests): x [B][64][128][cin] -> y [B][64][128][256]; cin = 64 with the
+ * downsample branch (wd != NULL) or 256 without; w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wd [256][64]; s* / b* FrozenBN
+ * scale / bias per output channel */
+int cotr_op_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2, const float* w3, const float* wd,
+                       const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
+                       const float* sd, const float* bd, cotr_stream stream);
 /* wave-specialised large-tile GEMM (configurations 40 / 41: 4 loader + 4 MFMA wavefronts): bit 0 = raised issue priority around
  * the MFMA wavefronts' loop, bit 1 (default) = raised priority for the loader wavefronts */
 int cotr_set_ws_flags(int flags);

@@ -514,6 +514,46 @@ def test_dual_conv_launch(B, H, cin, c_ds, c_1, stride):
     assert ran >= 5, ran
 
 
+@pytest.mark.parametrize('B,cin', [(1, 64), (1, 256), (3, 256), (2, 64)])
+def test_fused_layer1_bottleneck(B, cin):
+    """bottleneck.hip: conv1 1x1 -> conv2 3x3 -> conv3 1x1 (+ downsample 1x1 when cin == 64) with FrozenBN scale / bias, ReLU and
+    the identity in ONE launch, against torchvision's Bottleneck.forward per 64-wide half (COTR/models/backbone.py:46-56,79-92):
+    every tile's halo (conv2's zero padding applies to t1, also at the seam between the halves), every phase's MFMA layout, the
+    packed weight fragments."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(B * 7 + cin)
+    x = torch.randn(B, cin, 64, 128, generator=g)
+    w1 = torch.randn(64, cin, 1, 1, generator=g) / math.sqrt(cin)
+    w2 = torch.randn(64, 64, 3, 3, generator=g) / math.sqrt(576)
+    w3 = torch.randn(256, 64, 1, 1, generator=g) / 8
+    wd = torch.randn(256, 64, 1, 1, generator=g) / 8 if cin == 64 else None
+    sb = lambda n: (torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g))
+    (s1, b1), (s2, b2), (s3, b3), (sd, bd) = sb(64), sb(64), sb(256), sb(256)
+    bn = lambda t, s_, b_: t * s_.view(1, -1, 1, 1) + b_.view(1, -1, 1, 1)
+
+    def block(h):                                   # one 64 x 64 half, NCHW
+        t1 = F.relu(bn(F.conv2d(h, w1), s1, b1))
+        t2 = F.relu(bn(F.conv2d(t1, w2, padding=1), s2, b2))
+        out = bn(F.conv2d(t2, w3), s3, b3)
+        idt = bn(F.conv2d(h, wd), sd, bd) if wd is not None else h
+        return F.relu(out + idt)
+    ref = G.per_half(block, x)
+    d = G.dev()
+    xd = G.nchw_to_sbs(x).to(d)
+    y = torch.full((B, 64, 128, 256), float('nan'), device=d)
+    dv = lambda t: None if t is None else t.to(d)
+    args = [dv(G.pack_conv_weight(w1)), dv(G.pack_conv_weight(w2)), dv(G.pack_conv_weight(w3)), dv(None if wd is None else G.pack_conv_weight(wd)),
+            dv(s1), dv(b1), dv(s2), dv(b2), dv(s3), dv(b3), dv(sd if wd is not None else None), dv(bd if wd is not None else None)]
+    rc = lib.cotr_op_bottleneck(G.P(xd), G.P(y), B, cin, *[G.P(a) for a in args], G.sptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    e = G.rel_err(G.sbs_to_nchw(y.cpu()), ref)
+    assert e < 3e-5, e
+    # a shape it is not written for is declined, not mis-computed
+    assert lib.cotr_op_bottleneck(G.P(xd), G.P(y), B, 128, *[G.P(a) for a in args], G.sptr()) != 0
+
+
 def test_large_tile_configs_are_repeatable():
     """The LDS-DMA kernels order other wavefronts' reads by an explicit vmcnt(0) before the barrier (common.h,
     LDS_DMA_WAIT_ALL); without it thousands of workgroups in flight produced rare stale tiles.  Many workgroups, several
