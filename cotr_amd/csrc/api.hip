@@ -67,7 +67,7 @@ thread_local std::string g_create_error;
 int g_head_fuse_max_rows = 0;     // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower at 1000 rows: 63 workgroups each pull all 512 KB of weights; off)
 int g_attn_fuse_max_rows = 1024;  // attention with the out-projection (and, in the decoder, the q projection) fused in, up to this many rows
 int g_pos_table_min_rows = 8192;  // token rows from which the encoder in-projection / decoder K-V projection take pos . W^T from the tables
-int g_bottleneck_max_pairs = 2;   // layer1 bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass; 0 = never
+int g_bottleneck_max_pairs = 4;   // layer1 bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass (measured: -4.3 % at 1 pair, -1.4 % at 4, 0 at 8, +1.4 % at 32 - the halo recompute of conv1 - tools/ab_bottleneck.py); 0 = never
 int g_ffn_fuse_max_rows = 1024;  // fused FFN block up to this many rows (forward at B=1,Q=1000: 1.064 vs 1.083 ms; slower from ~1300 rows on)
 }  // namespace
 
@@ -1434,7 +1434,7 @@ Knob* knob_table(int* n) {
       {"attention_splits", cotr_set_attention_splits, 0, 0},
       {"conv1x1_dense", cotr_set_conv1x1_dense, 1, 1},
       {"ws_flags", cotr_set_ws_flags, 2, 2},
-      {"bottleneck_max_pairs", cotr_set_bottleneck_max_pairs, 2, 2},
+      {"bottleneck_max_pairs", cotr_set_bottleneck_max_pairs, 4, 4},
   };
   *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
   return knobs;

@@ -331,7 +331,8 @@ int cotr_set_attention_splits(int ns);
 int cotr_set_conv1x1_dense(int enable);
 /* layer1's bottlenecks (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity / downsample, FrozenBN, ReLU: torchvision
  * Bottleneck.forward, COTR/models/backbone.py:46-56) run as ONE launch each (bottleneck.hip) for passes of up to this many pairs
- * (default 2: the latency-bound regime; 0 = never): 9 launches of layer1 become 3 */
+ * (default 4: the latency-bound regime - at 8 pairs it is time-neutral, above that the halo recompute of conv1 loses; 0 = never):
+ * 9 launches of layer1 become 3 */
 int cotr_set_bottleneck_max_pairs(int pairs);
 /* one layer1 bottleneck from unpacked device weights (tests): x [B][64][128][cin] -> y [B][64][128][256]; cin = 64 with the
  * downsample branch (wd != NULL) or 256 without; w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wd [256][64]; s* / b* FrozenBN

@@ -33,7 +33,7 @@ def main():
                      f'from {kd} d join {ks} s on d.kernel_id = s.id order by d.start').fetchall()
     # keep only our kernels (drop torch fill/copy kernels of the setup)
     ours = [r for r in rows if any(k in r[0] for k in ('gemm_kernel', 'gemm_ks_kernel', 'attention', 'attention_kernel', 'layernorm_kernel',
-                                                       'posenc_kernel', 'maxpool_kernel', 'head2_kernel', 'fused', 'ln_reduce', 'stem_pool', 'gemm_big', 'gemm_wp', 'dual_kernel', 'dec_head'))]
+                                                       'posenc_kernel', 'maxpool_kernel', 'head2_kernel', 'fused', 'ln_reduce', 'stem_pool', 'gemm_big', 'gemm_wp', 'gemm_ws', 'bottleneck', 'dual_kernel', 'dec_head'))]
     # one stem convolution (gemm_kernel<2,2,2,1,GEMM_STEM>) per forward: robust against extra forwards in the command
     n_fwd = sum(1 for r in ours if 'stem_pool' in r[0] or
                 ('gemm_kernel' in r[0] and ('Li2ELi2ELi2ELi1ELi2E' in r[0] or '<2, 2, 2, 1, 2>' in r[0])))
