@@ -24,6 +24,7 @@
 
 #include "../../include/cotr_hip.h"
 #include "common.h"
+#include "coop_tail.h"
 #include "train.h"
 
 int init_attention_attributes();
@@ -67,6 +68,8 @@ thread_local std::string g_create_error;
 int g_head_fuse_max_rows = 0;     // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower at 1000 rows: 63 workgroups each pull all 512 KB of weights; off)
 int g_attn_fuse_max_rows = 1024;  // attention with the out-projection (and, in the decoder, the q projection) fused in, up to this many rows
 int g_pos_table_min_rows = 8192;  // token rows from which the encoder in-projection / decoder K-V projection take pos . W^T from the tables
+int g_coop_tail = 0;              // 1: the fused attention / FFN launches finish their row tiles themselves (coop_tail.h) instead of 24 ln_reduce launches; correct and schedule-independent, but measured SLOWER: 1000.7 vs 823.7 us per forward (+7.4 us per tail: arrive, poll, claim and the sc1 partial reads are four dependent memory-side round trips of 1-2 us each against 1.7 us of dispatch + 2.3 us of ln_reduce) - off
+int g_coop_tail_spin = 4000;      // polls (~0.3 us each) before a member workgroup leaves its share to the tile's last arriver
 int g_bottleneck_max_pairs = 4;   // layer1 bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass (measured: -4.3 % at 1 pair, -1.4 % at 4, 0 at 8, +1.4 % at 32 - the halo recompute of conv1 - tools/ab_bottleneck.py); 0 = never
 int g_ffn_fuse_max_rows = 1024;  // fused FFN block up to this many rows (forward at B=1,Q=1000: 1.064 vs 1.083 ms; slower from ~1300 rows on)
 }  // namespace
@@ -80,6 +83,9 @@ struct cotr_ctx {
   bool loaded = false;
   std::vector<ConvW> convs;  // execution order: stem, then per block conv1, conv2, conv3, [downsample]
   // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
+  // cooperative tails (coop_tail.h): generation-tagged arrival / claim words per row tile, and the launch counter that tags them
+  unsigned long long* tail_state = nullptr;
+  unsigned long long tail_gen = 0;
   struct FusedBlock { const float *w2p = nullptr, *w3p = nullptr, *wdp = nullptr; };
   FusedBlock l1_fused[3];
   const float *ip_w = nullptr, *ip_b = nullptr;
@@ -261,6 +267,17 @@ int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float
   return COTR_OK;
 }
 
+CoopTail make_tail(cotr_ctx* h, const float* bias, const float* residual, const float* w, const float* b, const float* post_w,
+                   const float* post_b, float* y) {
+  CoopTail ct;
+  ct.state = h->tail_state;
+  ct.gen = ++h->tail_gen;
+  ct.spin_limit = g_coop_tail_spin;
+  ct.bias = bias; ct.residual = residual; ct.w = w; ct.b = b; ct.post_w = post_w; ct.post_b = post_b; ct.y = y;
+  return ct;
+}
+bool coop_tail_ok(int nch) { return g_coop_tail && (nch == 8 || nch == 16); }
+
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
 // Up to g_ffn_fuse_max_rows rows: ONE fused launch that keeps the hidden activations on the CU and writes per-chunk
 // partial outputs + ln_reduce (sum, bias, residual, norm); above: linear1, linear2 (+residual), layernorm.
@@ -270,6 +287,11 @@ int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, c
               const float* post_w = nullptr, const float* post_b = nullptr) {
   if (post_w != nullptr) {   // (callers check ffn_block_takes_post_norm first)
     const int nch = ffn_fused_chunks(M);
+    if (coop_tail_ok(nch)) {
+      KCHK(h, launch_ffn_fused_coop(x, l1w, l1b, l2w, hid, M, nch, make_tail(h, l2b, x, nw, nb, post_w, post_b, y), s), "ffn_fused+tail");
+      if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused+tail+norm %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
+      return COTR_OK;
+    }
     KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
     if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
     KCHK(h, launch_ln_reduce_post(hid, nch, l2b, x, nw, nb, post_w, post_b, y, M, s), "ln_reduce");
@@ -281,6 +303,11 @@ int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, c
     if (g_ffn_tail) {  // partial sums + bias + residual + LayerNorm by the last workgroup of each row tile: one launch
       KCHK(h, launch_ffn_fused_ln(x, l1w, l1b, l2w, hid, M, nch, l2b, x, nw, nb, y, s), "ffn_fused_ln");
       if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused+ln %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
+      return COTR_OK;
+    }
+    if (coop_tail_ok(nch)) {
+      KCHK(h, launch_ffn_fused_coop(x, l1w, l1b, l2w, hid, M, nch, make_tail(h, l2b, x, nw, nb, nullptr, nullptr, y), s), "ffn_fused+tail");
+      if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused+tail %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
       return COTR_OK;
     }
     KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
@@ -411,6 +438,12 @@ int cotr_create(cotr_handle* out, int device) {
   }
   cotr_ctx* h = new cotr_ctx();
   h->device = device;
+  constexpr size_t kTailBytes = (size_t)1024 * COOP_WORDS * sizeof(unsigned long long);   // <= 1024 rows fused: <= 1024 row tiles
+  if (hipMalloc(reinterpret_cast<void**>(&h->tail_state), kTailBytes) != hipSuccess || hipMemset(h->tail_state, 0, kTailBytes) != hipSuccess) {
+    g_create_error = "allocating the cooperative-tail state failed";
+    delete h;
+    return COTR_ERR_HIP;
+  }
   if (hipMalloc(reinterpret_cast<void**>(&h->pos), (size_t)TOK * D * sizeof(float)) != hipSuccess ||
       launch_pos_table(h->pos, nullptr) != 0 || hipStreamSynchronize(nullptr) != hipSuccess) {
     g_create_error = "building the image position table failed";
@@ -428,6 +461,7 @@ void cotr_destroy(cotr_handle h) {
   prof_reset(h);
   if (h->wbuf) (void)hipFree(h->wbuf);
   if (h->pos) (void)hipFree(h->pos);
+  if (h->tail_state) (void)hipFree(h->tail_state);
   for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr})
     if (a->ptr && !a->external) (void)hipFree(a->ptr);
   for (auto& kv : h->tap_store)
@@ -785,11 +819,18 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
       if (n_part != 0 && M <= g_attn_fuse_max_rows && M <= g_ffn_fuse_max_rows && !g_ffn_preln) {
         // out_proj inside the attention kernel (8 per-head partial outputs), summed + bias + residual + norm1 by ln_reduce
-        KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
-                                       nullptr, 0, e.out_w, t_part, Bc, TOK, s), "attention+out_proj");
-        prof_mark(h, "attention+oproj enc", s, 2);
-        KCHK(h, launch_ln_reduce(t_part, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
-        prof_mark(h, "ln_reduce heads", s, 2);
+        if (g_coop_tail) {   // ... and the 8 head workgroups of a query tile do that sum + norm1 themselves (coop_tail.h)
+          const CoopTail ct = make_tail(h, e.out_b, xin, e.n1w, e.n1b, nullptr, nullptr, t_x1);
+          KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
+                                         nullptr, 0, e.out_w, t_part, Bc, TOK, s, &ct), "attention+out_proj+tail");
+          prof_mark(h, "attention+oproj+tail enc", s, 2);
+        } else {
+          KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
+                                         nullptr, 0, e.out_w, t_part, Bc, TOK, s), "attention+out_proj");
+          prof_mark(h, "attention+oproj enc", s, 2);
+          KCHK(h, launch_ln_reduce(t_part, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
+          prof_mark(h, "ln_reduce heads", s, 2);
+        }
         if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_tmp, y, M, s))) return r;
       } else {
         KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
@@ -894,12 +935,20 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
     if (fused) {
       // q = Wq(tgt + query_pos) * 32^-0.5 in the attention kernel's prologue (tgt == 0 at layer 0, transformer.py:54), out_proj
       // in its epilogue (8 per-head partials), then ln_reduce: sum + bias + residual + norm2; FFN block; 4 launches per layer
-      KCHK(h, launch_attention_fused(nullptr, 0, li == 0 ? nullptr : d.tgt, d.qpos, w.q_w, w.q_b, QSCALE,
-                                     kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, nullptr, 0, w.out_w, d.part,
-                                     nb, nq, s), "q_proj+attention+out_proj");
-      prof_mark(h, "qproj+attention+oproj dec", s, 2);
-      KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
-      prof_mark(h, "ln_reduce heads", s, 2);
+      if (g_coop_tail) {
+        const CoopTail ct = make_tail(h, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, nullptr, nullptr, d.t2);
+        KCHK(h, launch_attention_fused(nullptr, 0, li == 0 ? nullptr : d.tgt, d.qpos, w.q_w, w.q_b, QSCALE,
+                                       kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, nullptr, 0, w.out_w, d.part,
+                                       nb, nq, s, &ct), "q_proj+attention+out_proj+tail");
+        prof_mark(h, "qproj+attention+oproj+tail dec", s, 2);
+      } else {
+        KCHK(h, launch_attention_fused(nullptr, 0, li == 0 ? nullptr : d.tgt, d.qpos, w.q_w, w.q_b, QSCALE,
+                                       kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, nullptr, 0, w.out_w, d.part,
+                                       nb, nq, s), "q_proj+attention+out_proj");
+        prof_mark(h, "qproj+attention+oproj dec", s, 2);
+        KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
+        prof_mark(h, "ln_reduce heads", s, 2);
+      }
       // last layer: decoder.norm rides in the same ln_reduce launch (its input has no other consumer); pre2 = the normed 'hs'
       const bool post = li + 1 == L && !g_ffn_tail && R > g_head_fuse_max_rows;
       if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
@@ -1341,6 +1390,17 @@ int cotr_set_conv_patch(int enable) {
   return COTR_OK;
 }
 
+int cotr_set_coop_tail(int enable) {
+  g_coop_tail = enable != 0;
+  knob_record("coop_tail", g_coop_tail);
+  return COTR_OK;
+}
+int cotr_set_coop_tail_spin(int polls) {
+  g_coop_tail_spin = polls < 0 ? 0 : polls;
+  knob_record("coop_tail_spin", g_coop_tail_spin);
+  return COTR_OK;
+}
+
 int cotr_set_bottleneck_max_pairs(int pairs) {
   g_bottleneck_max_pairs = pairs < 0 ? 0 : pairs;
   knob_record("bottleneck_max_pairs", g_bottleneck_max_pairs);
@@ -1435,6 +1495,8 @@ Knob* knob_table(int* n) {
       {"conv1x1_dense", cotr_set_conv1x1_dense, 1, 1},
       {"ws_flags", cotr_set_ws_flags, 2, 2},
       {"bottleneck_max_pairs", cotr_set_bottleneck_max_pairs, 4, 4},
+      {"coop_tail", cotr_set_coop_tail, 0, 0},
+      {"coop_tail_spin", cotr_set_coop_tail_spin, 4000, 4000},
   };
   *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
   return knobs;

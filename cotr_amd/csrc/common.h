@@ -214,9 +214,12 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
 
 // the same with the q projection as prologue (wq != nullptr: q = ((x + x2) . wq_h^T + bq_h) * qscale, `q` unused) and / or the
 // output projection as epilogue (wo != nullptr: per-head partial outputs [8][nb*nq][256] to `part`; `o` may be nullptr)
+struct CoopTail;   // coop_tail.h: the row tile's own workgroups sum the partials + bias + residual + LayerNorm (no ln_reduce launch)
 int launch_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
                            float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
-                           float* part, int nb, int nq, hipStream_t s);
+                           float* part, int nb, int nq, hipStream_t s, const CoopTail* ct = nullptr);
+int launch_ffn_fused_coop(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                          const CoopTail& ct, hipStream_t s);
 
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s);
 // lin_sine encoding; point (bi, qi) read from pts[((bi*q_total) + qi)*2], written to row bi*nq+qi

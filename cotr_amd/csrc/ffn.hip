@@ -12,7 +12,10 @@
 //   phase 2  out[32 x 256] += H . W2[:, sub]^T: wave w -> output columns 32w..32w+31, K = 64: 32 MFMAs; the W2 operand
 //            goes global -> registers in MFMA layout (each element is used once per workgroup), prefetched under phase 1
 // X and W1 sub-chunks arrive by LDS-DMA (one wave instruction = one padded 1040-B row).
+#include <string.h>
+
 #include "common.h"
+#include "coop_tail.h"
 
 #define FF_D 256
 #define FF_H 1024
@@ -42,6 +45,7 @@ struct FfnParams {
   const float* ln_b;
   float* Y;          // [M][256]
   unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock), cotr_debug_ffn_times
+  CoopTail ct;       // ct.state != nullptr: the workgroups of a row tile finish it themselves (coop_tail.h) - no ln_reduce launch
 };
 
 __device__ __forceinline__ float ffn_wave_sum(float v) {
@@ -192,6 +196,10 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
       if (m0 + row < p.M) store_f32x4(out + (size_t)(m0 + row) * FF_D + 32 * wave + sc, val, p.wt_partials != 0);
     }
     FFN_STAMP(7);
+    if (p.ct.state != nullptr) {
+      __shared__ int coop_flags[2];
+      coop_tail_run(p.ct, p.P, (size_t)p.M * FF_D, m0 >> 5, m0, (p.M - m0) < 32 ? (p.M - m0) : 32, chunk, p.nch, coop_flags);
+    }
     return;
   }
 #pragma unroll
@@ -287,6 +295,17 @@ int launch_ffn_fused(const float* X, const float* W1, const float* b1, const flo
   return launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
+// the same with the cooperative tail (coop_tail.h): Y = [post norm] LN(residual + sum of partials + b2) by the row tile's own workgroups
+static thread_local const CoopTail* g_ffn_ct = nullptr;
+int launch_ffn_fused_coop(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                          const CoopTail& ct, hipStream_t s) {
+  if (nch != 8 && nch != 16) return -1;
+  g_ffn_ct = &ct;
+  const int r = launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+  g_ffn_ct = nullptr;
+  return r;
+}
+
 // X is the pre-norm tensor: LayerNorm(pre_w, pre_b) is applied to the X tile inside the kernel
 int launch_ffn_fused_pre(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
                          const float* W2, float* P, int M, int nch, hipStream_t s) {
@@ -318,6 +337,8 @@ static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_
   p.pre_w = pre_w; p.pre_b = pre_b;
   p.wt_partials = g_ffn_wt;
   p.dbg = g_ffn_dbg;
+  memset(&p.ct, 0, sizeof(p.ct));
+  if (g_ffn_ct != nullptr) p.ct = *g_ffn_ct;
   if (b2 != nullptr) {
     if (!residual || !ln_w || !ln_b || !Y || (M + 31) / 32 > 1024) return -1;
     p.counters = ffn_counters();

@@ -329,6 +329,16 @@ int cotr_set_attention_splits(int ns);
 /* 1 (default): a 1x1 stride-1 convolution is launched as the dense product of its pixel rows (same configuration, same
  * summation order, bit-identical) - the dense kernels skip the per-row pixel decomposition of the convolution prologue */
 int cotr_set_conv1x1_dense(int enable);
+/* 1: the launches that leave per-workgroup partial outputs of a row tile (the fused FFN block: one per hidden-unit chunk; attention
+ * with the out-projection fused in: one per head) also sum them, add bias + residual and apply LayerNorm - each workgroup of a row
+ * tile for its own share of the rows, the tile's last-arriving workgroup for every share nobody claimed (coop_tail.h: bounded waits
+ * only, bit-identical to the separate ln_reduce launch) - 24 launches fewer per forward at one pair.  0 (default): ln_reduce
+ * launches - the cooperative form measured slower (1.001 vs 0.824 ms per forward: every device-scope atomic / sc1 round trip of the
+ * hand-off costs 1-2 us on this chip, four of them per tail against 1.7 us of dispatch + 2.3 us of ln_reduce) */
+int cotr_set_coop_tail(int enable);
+/* polls of the tile's arrival word before a workgroup leaves its share to the last arriver (default 4000, ~0.3 us each; 0 = never
+ * wait: the last arriver finishes the whole tile - the schedule-independence test) */
+int cotr_set_coop_tail_spin(int polls);
 /* layer1's bottlenecks (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity / downsample, FrozenBN, ReLU: torchvision
  * Bottleneck.forward, COTR/models/backbone.py:46-56) run as ONE launch each (bottleneck.hip) for passes of up to this many pairs
  * (default 4: the latency-bound regime - at 8 pairs it is time-neutral, above that the halo recompute of conv1 loses; 0 = never):

@@ -253,6 +253,61 @@ def test_fused_and_unfused_decoder_head_agree():
     assert cotr_oracle.px_err(fused, ref) < PX_BAR and cotr_oracle.px_err(plain, ref) < PX_BAR
 
 
+@pytest.mark.parametrize('b,q', [(1, 1000), (2, 77), (1, 1), (3, 333)])
+def test_cooperative_tail_is_bit_identical_to_the_ln_reduce_launches(b, q):
+    """coop_tail.h: the fused attention / FFN launches sum their per-head / per-chunk partial outputs, add bias + residual and
+    apply LayerNorm themselves (each workgroup of a row tile its own share of the rows; the tile's last arriver every share
+    nobody claimed) instead of 24 ln_reduce launches.  Same arithmetic in the same order: the prediction must equal the two-launch
+    form BIT FOR BIT - with the normal bounded wait, and with no waiting at all (coop_tail_spin = 0: every tile is finished by its
+    last-arriving workgroup alone, the path a non-resident or timed-out member takes) - for row counts that are and are not
+    multiples of the 32-row tile, and on repeated calls (the arrival / claim words are generation-tagged, never reset)."""
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(b, q, seed=23)
+    img, qs = img.cuda(), qs.cuda()
+    m = hip_model()
+    assert _lib.knobs()['coop_tail'] == (0, 0)                 # off by default: measured slower than the launches it removes
+    plain = m(img, qs)['pred_corrs'].clone()
+    _lib.set_knob('coop_tail', 1)
+    coop = [m(img, qs)['pred_corrs'].clone() for _ in range(3)]
+    _lib.set_knob('coop_tail_spin', 0)
+    nowait = [m(img, qs)['pred_corrs'].clone() for _ in range(2)]
+    _lib.reset_knobs()
+    assert all(torch.equal(c, plain) for c in coop), 'cooperative tail differs from the ln_reduce launches'
+    assert all(torch.equal(c, plain) for c in nowait), 'last-arriver-only tail differs from the ln_reduce launches'
+    ref = cotr_oracle.cotr_forward(sd, img.cpu(), qs.cpu())
+    assert cotr_oracle.px_err(plain.cpu(), ref) < PX_BAR
+
+
+def test_cooperative_tail_with_several_forwards_in_flight():
+    """Three handles on three streams, forwards interleaving on the GPU: member workgroups of a row tile may then be late or not
+    resident while others wait - the protocol never waits without bound and the last arriver finishes what is left, so every
+    stream's result equals the single-stream result bit for bit (also with a spin limit so short that members give up)."""
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(1, 1000, seed=29)
+    img, qs = img.cuda(), qs.cuda()
+    models = []
+    for _ in range(3):
+        m = build_model(cotr_amd.default_args()).cuda().eval()
+        m.load_state_dict(sd)
+        models.append(m)
+    want = models[0](img, qs)['pred_corrs'].clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in models]
+    _lib.set_knob('coop_tail', 1)
+    for spin in (4000, 3):
+        _lib.set_knob('coop_tail_spin', spin)
+        outs = []
+        for it in range(12):
+            for m, st in zip(models, streams):
+                with torch.cuda.stream(st):
+                    outs.append(m(img, qs)['pred_corrs'])
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, want) for o in outs), spin
+    _lib.reset_knobs()
+
+
 def test_dual_conv_launch_is_bit_identical_to_two_launches():
     """The entry blocks' downsample + conv1 in one launch compute exactly what the two launches compute when the
     configuration is the same; end to end the two schedules agree to launch-configuration rounding."""

@@ -12,7 +12,7 @@ from cotr_amd.models import build_model
 from cotr_amd.utils.synth import synth_state_dict
 
 lib = _lib.load_library()
-B, Q = 16, 100
+B, Q = 16, 200   # bench.py --workload train: BASELINE.json configs[4]
 m = build_model(cotr_amd.default_args()).cuda()
 m.load_state_dict(synth_state_dict(0))
 m.train()
