@@ -8,7 +8,7 @@ from collections import defaultdict
 path = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-ours = ('gemm_kernel', 'gemm_ks_kernel', 'gemm_big_kernel', 'stem_pool_kernel', 'attention_kernel', 'layernorm_kernel', 'posenc_kernel', 'maxpool_kernel',
+ours = ('gemm_kernel', 'gemm_ks_kernel', 'gemm_big_kernel', 'gemm_wp_kernel', 'gemm_ws_kernel', 'gemm_wp_dual', 'bottleneck_kernel', 'stem_pool_kernel', 'attention_kernel', 'layernorm_kernel', 'posenc_kernel', 'maxpool_kernel',
         'head2_kernel', 'ffn_fused_kernel', 'ln_reduce_kernel', 'gemm_ks_dual_kernel', 'gemm_big_dual_kernel', 'attention_wide_kernel',
         'dec_head_kernel')
 rows = [r for r in csv.DictReader(open(path)) if any(k in r['Kernel_Name'] for k in ours)]
