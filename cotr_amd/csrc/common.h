@@ -178,6 +178,9 @@ static inline bool gemm_fill_divs(GemmParams& p, int mode, int bm, int bn) {
     p.fd_wout = fastdiv_make(p.Wout);
     p.fd_tpt = fastdiv_make(p.Cin / 32);
     p.fd_ks = fastdiv_make(p.ksize);
+    // the convolution kernels address the activation tensor with 32-bit element offsets
+    const long long pairs = (p.M + (long long)p.Hout * 2 * p.Wout - 1) / ((long long)p.Hout * 2 * p.Wout);
+    ok = ok && (pairs + 1) * p.Hin * 2 * p.Win * p.Cin < 0x7fffffffll;
     ok = ok && p.M <= fastdiv_max_n(p.fd_hw) && p.Hout * 2 * p.Wout <= fastdiv_max_n(p.fd_w2o) &&
          2 * p.Wout <= fastdiv_max_n(p.fd_wout) && p.K / 32 <= fastdiv_max_n(p.fd_tpt) && p.ksize * p.ksize <= fastdiv_max_n(p.fd_ks);
   } else {

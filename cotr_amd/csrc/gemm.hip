@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
       c_hi0[i] = ho * p.stride - p.pad;
       c_wi0[i] = wl * p.stride - p.pad;
       // pixel (b, 0, side*Win + 0), channel lc
-      a_ptr[i] = p.A + ((size_t)b * p.Hin * (2 * p.Win) + (size_t)side * p.Win) * p.Cin + lc;
+      a_ptr[i] = p.A + (long)(((b * p.Hin + c_hi0[i]) * (2 * p.Win) + side * p.Win + c_wi0[i]) * p.Cin) + lc;   // pixel (b, hi0, side, wi0): may lie in front of the tensor, only dereferenced in range
       a2_ptr[i] = nullptr;
     }
   } else {  // GEMM_STEM
@@ -116,12 +116,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     } else if constexpr (MODE == GEMM_CONV) {
       int ky, kx, c0;
       conv_ktile_decompose(p, kt, ky, kx, c0);
+      const int tapoff = (ky * (2 * p.Win) + kx) * p.Cin + c0;   // wave-uniform element offset of this tap / channel tile
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int hi = c_hi0[i] + ky, wi = c_wi0[i] + kx;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (a_ok[i] && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win)
-          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((size_t)hi * (2 * p.Win) + wi) * p.Cin + c0);
+          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + tapoff);
         ra[i] = v;
       }
     } else {
@@ -304,7 +305,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
       conv_row_decompose(p, mm, b, ho, side, wl);
       c_hi0[i] = ho * p.stride - p.pad;
       c_wi0[i] = wl * p.stride - p.pad;
-      a_ptr[i] = p.A + ((size_t)b * p.Hin * (2 * p.Win) + (size_t)side * p.Win) * p.Cin + lcc;
+      a_ptr[i] = p.A + (long)(((b * p.Hin + c_hi0[i]) * (2 * p.Win) + side * p.Win + c_wi0[i]) * p.Cin) + lcc;   // pixel (b, hi0, side, wi0): may lie in front of the tensor, only dereferenced in range
       a2_ptr[i] = nullptr;
     }
   }
@@ -338,12 +339,13 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
     } else {
       int ky, kx, c0;
       conv_ktile_decompose(p, kt, ky, kx, c0);
+      const int tapoff = (ky * (2 * p.Win) + kx) * p.Cin + c0;   // wave-uniform element offset of this tap / channel tile
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int hi = c_hi0[i] + ky, wi = c_wi0[i] + kx;
         f32x4 v = z;
         if (a_ok[i] && k_ok && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win)
-          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + ((size_t)hi * (2 * p.Win) + wi) * p.Cin + c0);
+          v = *reinterpret_cast<const f32x4*>(a_ptr[i] + tapoff);
         ra[i] = v;
       }
     }
@@ -438,11 +440,12 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
     } else {
       int ky, kx, c0;
       conv_ktile_decompose(p, kt, ky, kx, c0);
+      const int tapoff = (ky * (2 * p.Win) + kx) * p.Cin + c0;   // wave-uniform element offset of this tap / channel tile
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int hi = c_hi0[i] + ky, wi = c_wi0[i] + kx;
         const bool ok = a_ok[i] && k_ok && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
-        const float* src = ok ? a_ptr[i] + ((size_t)hi * (2 * p.Win) + wi) * p.Cin + c0 : zsrc;
+        const float* src = ok ? a_ptr[i] + tapoff : zsrc;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(As + (lr + 8 * i) * LD), 16, 0, 0);
       }
@@ -473,20 +476,28 @@ __device__ __forceinline__ void gemm_ks_body(const GemmParams& p, const int bid)
       // all of the patch addressing is wave-uniform (a wave instruction moves one pixel): kept on the scalar unit by taking the
       // wavefront index through readfirstlane - per-lane integer divisions and exec-masked branches around every DMA were 4 us
       const int wv = __builtin_amdgcn_readfirstlane(wave);
+      // 32-bit element offsets from the pair's image (a pair's activation tensor is far below 2^31 floats), every term that does not
+      // depend on the slot hoisted: round 2's form spent ~60 scalar instructions (64-bit multiplies) per DMA, 2.8 us from the first
+      // to the last of the 33 requests (profiles/r3_conv_phases_after_fastdiv.txt: "loads issued" 3.5 us after entry)
       const float* img = p.A + (size_t)b * p.Hin * (2 * p.Win) * p.Cin;
       const float* wrow = p.W + (size_t)(n0 + l15) * p.K + wave * BK + q4 * 4;
       const int per_dy = (32 / seg) * (seg + 2);          // 36 (two 16-pixel segments) or 34 patch rows per input row
+      const int Cin = 256;                                // (PATCH is the 256-channel 3x3: cfg_fits)
+      const int lane_off = lane * 4;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy) {
+        const int hi = ho - 1 + dy;
+        const bool hi_ok = hi >= 0 && hi < p.Hin;
+        const int row_off = (hi * 2 * p.Win + side0 * p.Win + wl0 - 1) * Cin;   // pixel (hi, side0, wl0 - 1)
 #pragma unroll
         for (int i = 0; i < 5; ++i) {                     // one wave instruction = one pixel (256 channels = 1 KB)
           const int sl = wv + NWK * i;                    // slot 0..39 of this phase
           const int sg = (seg == 16 && sl >= 18) ? 1 : 0, j = sl - sg * 18;
-          const int hi = ho - 1 + dy, wi = wl0 - 1 + j;
+          const int wi = wl0 - 1 + j;
           const bool slot_ok = sl < per_dy;
-          const bool ok = slot_ok && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
-          const float* base = ok ? img + ((size_t)hi * (2 * p.Win) + (size_t)(side0 + sg) * p.Win + wi) * p.Cin : p.zeros;
-          const float* src = base + (ok ? lane * 4 : 0);
+          const bool ok = slot_ok && hi_ok && wi >= 0 && wi < p.Win;
+          const int off = row_off + (sg * p.Win + j) * Cin;
+          const float* src = ok ? img + off + lane_off : p.zeros;
           const int r = slot_ok ? sg * segrows + dy * (seg + 2) + j : nrows;   // dummy row behind the patch
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)(smem + r * LD), 16, 0, 0);

@@ -82,7 +82,7 @@ __device__ __forceinline__ void gemm_wp_body(const GemmParams& p, const int bid)
       conv_row_decompose(p, mm, b, ho, side, wl);
       c_hi0[q] = ho * p.stride - p.pad;
       c_wi0[q] = wl * p.stride - p.pad;
-      a_ptr[q] = p.A + ((size_t)b * p.Hin * (2 * p.Win) + (size_t)side * p.Win) * p.Cin + lch * 4;
+      a_ptr[q] = p.A + (long)(((b * p.Hin + c_hi0[q]) * (2 * p.Win) + side * p.Win + c_wi0[q]) * p.Cin) + lch * 4;   // pixel (b, hi0, side, wi0): may lie in front of the tensor, only dereferenced in range
     }
   }
   const float* w_ptr[QW];
@@ -106,11 +106,12 @@ __device__ __forceinline__ void gemm_wp_body(const GemmParams& p, const int bid)
     } else {
       int ky, kx, c0;
       conv_ktile_decompose(p, kt, ky, kx, c0);
+      const int tapoff = (ky * (2 * p.Win) + kx) * p.Cin + c0;   // wave-uniform element offset of this tap / channel tile
 #pragma unroll
       for (int q = 0; q < QA; ++q) {
         const int hi = c_hi0[q] + ky, wi = c_wi0[q] + kx;
         const bool ok = a_ok[q] && hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win;
-        const float* src = ok ? a_ptr[q] + ((size_t)hi * (2 * p.Win) + wi) * p.Cin + c0 : p.zeros;
+        const float* src = ok ? a_ptr[q] + tapoff : p.zeros;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(S + q * 8 * BK), 16, 0, 0);
       }

@@ -41,6 +41,37 @@ def _worker(rank, world, port, B, Q, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_fake(rank, world, port, B, Q, out_dir):
+    """Same wrapper, a cheap per-pair function as the model (what is under test is the partition + gather, here 2-D)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(6)
+    img, qs = torch.randn(B, 3, 4, 4, generator=g), torch.rand(B, Q, 2, generator=g)
+    calls = []
+
+    def model(samples, queries):
+        calls.append((tuple(samples.shape[:1]), tuple(queries.shape)))
+        return {'pred_corrs': queries * 3 - samples.mean(dim=(1, 2, 3))[:, None, None]}
+
+    out = PairShardedModel(model)(img, qs)['pred_corrs']
+    torch.save({'out': out, 'want': model(img, qs)['pred_corrs'], 'calls': calls[:-1]}, os.path.join(out_dir, f'f{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_pair_x_query_shards_on_four_ranks(tmp_path):
+    """2 pairs on 4 ranks (the dense initial pass with 2 patch pairs): two ranks share a pair, each encodes ONLY that pair and
+    takes half of its queries; the gathered tensor is the unsharded result, bit for bit."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    B, Q = 2, 9
+    mp.spawn(_worker_fake, args=(4, port, B, Q, str(tmp_path)), nprocs=4, join=True)
+    res = [torch.load(tmp_path / f'f{r}.pt') for r in range(4)]
+    for r in res:
+        assert torch.equal(r['out'], res[0]['want'])
+    assert [r['calls'] for r in res] == [[((1,), (1, 5, 2))], [((1,), (1, 4, 2))], [((1,), (1, 5, 2))], [((1,), (1, 4, 2))]]
+
+
 @pytest.mark.parametrize('B,Q', [(3, 5), (1, 7)])
 def test_sharded_equals_single_process(tmp_path, B, Q):
     with socket.socket() as s:
