@@ -270,8 +270,9 @@ int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd,
  * (they change which kernels every handle of the process launches); they are not part of the drop-in
  * boundary and a binding never needs them. */
 int cotr_gemm_num_configs(void);
-/* pairs per backbone/encoder pass inside cotr_encode (1..32): smaller chunks keep the activations in the 256 MB
- * Infinity Cache, larger ones fill the CUs better */
+/* pairs per backbone/encoder pass inside cotr_encode (1..128, default 64): larger passes fill the CUs better (64 per pass: +2-3 %
+ * over 32 from 64 pairs up; 128: -20 %).  The scratch of a pass is ~66 MB per pair: set this BEFORE sizing a caller-supplied
+ * workspace (cotr_scratch_bytes uses the current value; a workspace sized for a smaller chunk is refused with an error, not overrun) */
 int cotr_set_encode_chunk(int pairs);
 /* up to this many rows (default 2048; 0 = never) decoder.norm + corr_embed run as ONE row-local launch (head.hip) instead
  * of layernorm + two linears + the 256 -> 2 head */

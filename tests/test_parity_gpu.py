@@ -115,9 +115,12 @@ def test_engine_batch_shape_b32_q1():
 
 
 def test_encode_chunking_b40():
-    """More pairs than one backbone pass (ENC_CHUNK = 32): results must not depend on the chunking."""
+    """More pairs than one backbone pass (cotr_set_encode_chunk: 64 by default, 32 here so that 40 pairs take two passes):
+    results must not depend on the chunking."""
+    from cotr_amd import _lib
     sd = synth_state_dict(0)
     img, qs = synth_inputs(40, 3, seed=10)
+    _lib.set_knob('encode_chunk', 32)              # (before the model sizes its workspace; the conftest fixture resets it)
     m = hip_model()
     out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
     tail = m(img[33:35].cuda(), qs[33:35].cuda())['pred_corrs'].cpu()
