@@ -359,11 +359,14 @@ def run_train(args, dev, world, rank):
     g = torch.Generator().manual_seed(5 + rank)
     img = torch.randn(pairs, 3, 256, 512, generator=g).to(dev)
     query, target = torch.rand(pairs, nq, 2, generator=g).to(dev), torch.rand(pairs, nq, 2, generator=g).to(dev)
+    # gradients in one flat buffer, finished by one reduction launch per backward pass (train_ops.GradSink; same values bit for bit)
+    use_sink = not args.no_grad_sink
     if graphed:      # the whole step (zero_grad .. optimizer step, gradient collectives included) as ONE captured HIP graph
-        gstep = training.GraphedTrainStep(model, optim, img, query, target, warmup=max(args.warmup, 2))
+        gstep = training.GraphedTrainStep(model, optim, img, query, target, warmup=max(args.warmup, 2), sink=use_sink)
         step = lambda: gstep(img, query, target)
     else:            # COTRTrainer.train_batch as the reference runs it: eager launches, loss.item() every step
-        step = lambda: training.train_batch(model, optim, img, query, target)
+        sink = training.grad_sink_for(optim) if use_sink else None
+        step = lambda: training.train_batch(model, optim, img, query, target, sink=sink)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -395,6 +398,7 @@ def run_train(args, dev, world, rank):
                        'stage': args.stage, 'lr_backbone': lr_backbone,
                        'pairs_per_gpu': pairs, 'queries_per_pair': nq,
                        'step': 'captured HIP graph (GraphedTrainStep)' if graphed else 'eager train_batch',
+                       'gradients': 'GradSink: flat buffer, one deferred reduction launch' if use_sink else 'per-weight reductions + autograd accumulation',
                        'parallelism': f'data parallel x{world}, reduce-scatter + all-gather of the gradients' if world > 1 else 'single GPU'},
         }), flush=True)
 
@@ -472,6 +476,8 @@ def main():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', choices=['headline', 'batch256', 'train'], default='headline')
+    ap.add_argument('--no-grad-sink', action='store_true',
+                    help='--workload train: per-weight gradient reductions + autograd accumulation instead of the GradSink')
     ap.add_argument('--graphed-train', action='store_true',
                     help='--workload train: the step as ONE captured HIP graph (training.GraphedTrainStep) instead of eager train_batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')

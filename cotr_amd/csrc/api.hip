@@ -1689,6 +1689,18 @@ int cotr_train_gemm_tn(const float* A, const float* B, float* part, float* out, 
                        cotr_stream stream) {
   return op_ret(train_gemm_tn(A, B, part, out, colsum, M, N, K, TS));
 }
+int cotr_train_gemm_tn_parts(const float* A, const float* B, float* part, int M, int N, int K, int with_colsum, cotr_stream stream) {
+  const int r = train_gemm_tn_parts(A, B, part, M, N, K, with_colsum, TS);     // >= 0: number of partials written
+  return r >= 0 ? r : op_ret(r);
+}
+static_assert(sizeof(cotr_reduce_src) == sizeof(TrainReduceSrc) && sizeof(cotr_reduce_job) == sizeof(TrainReduceJob),
+              "include/cotr_hip.h and train.h disagree on the reduction records");
+int cotr_train_reduce_jobs(const cotr_reduce_job* jobs, const cotr_reduce_src* srcs, const unsigned* chunk_job, int njobs, int nchunks,
+                           cotr_stream stream) {
+  if (njobs < 0 || nchunks < 0 || (njobs > 0 && (jobs == nullptr || srcs == nullptr || chunk_job == nullptr))) return COTR_ERR_ARG;
+  return op_ret(train_reduce_jobs(reinterpret_cast<const TrainReduceJob*>(jobs), reinterpret_cast<const TrainReduceSrc*>(srcs), chunk_job,
+                                  njobs, nchunks, TS));
+}
 int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream) {
   return op_ret(launch_head2(x, w, b, y, nb, nq, nq, TS));
 }

@@ -311,7 +311,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
       else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                     // tile kt is in LDS for everybody; the readers of tile kt-1 are done with it
-      if (kt + 3 < KT) dma_tile(kt + 3, (kt + 3) & 3);
+      if (kt + 3 < KT) dma_tile(kt + 3, (kt + 3) & (NSTG - 1));
     }
     __builtin_amdgcn_s_barrier();                       // (the MFMA wavefronts' "operand stages are free" barrier before the epilogue)
     return;
@@ -351,8 +351,8 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
   for (int kt = 0; kt < KT; ++kt) {
     __builtin_amdgcn_s_barrier();                       // the loaders have seen tile kt land
     asm volatile("" ::: "memory");                      // no LDS access of this tile may be scheduled above the barrier
-    const float* As = smem + (kt & 3) * STAGE + (wm * 64 + l31) * BK;
-    const float* Ws = smem + (kt & 3) * STAGE + BM * BK + (wn * 32 * TN + l31) * BK;
+    const float* As = smem + (kt & (NSTG - 1)) * STAGE + (wm * 64 + l31) * BK;
+    const float* Ws = smem + (kt & (NSTG - 1)) * STAGE + BM * BK + (wn * 32 * TN + l31) * BK;
     auto load_frag = [&](int j) {                       // 8-deep slice j of the tile: one ds_read_b128 per 32-row block of A / W
       Frag r;
       const int ch = ((j * 2 + hh) ^ sw) * 4;

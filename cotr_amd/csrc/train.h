@@ -36,6 +36,22 @@ int train_ln_bwd(const float* dy, const float* s_in, const float* stats, const f
                  float* dwb, int rows, float p, uint32_t seed, hipStream_t s);
 int train_add_rowmod(const float* x, const float* x2, int mod, float* y, int rows, hipStream_t s);
 int train_sum_parts(const float* part, int nparts, size_t numel, float* out, hipStream_t s);
+// deferred gradient reduction (train.hip: reduce_jobs_kernel); the layouts are part of the C ABI (include/cotr_hip.h)
+struct TrainReduceSrc {
+  const float* part;             // first partial (already offset to this destination's part of a partial record)
+  unsigned long long pstride;    // floats from one partial to the next
+  unsigned nparts, pad_;
+};
+struct TrainReduceJob {
+  float* dst;                    // accumulated into: dst[perm(e)] += scale[row] * sum of the partials, source after source
+  const float* scale;            // per-row factor (FrozenBN scale of a conv weight gradient) or nullptr
+  unsigned numel, first_src, n_src, chunk0;   // chunk0 = index of this job's first 1024-element chunk in the launch
+  unsigned row_len, cin, taps;   // row_len 0: flat; taps > 1: packed [row][tap][cin] -> dst [row][cin][tap]
+  unsigned vec;                  // 1: every pointer 16-byte aligned and numel / pstride / row_len / cin multiples of 4
+};
+int train_reduce_jobs(const TrainReduceJob* jobs, const TrainReduceSrc* srcs, const unsigned* chunk_job, int njobs, int nchunks,
+                      hipStream_t s);
+int train_gemm_tn_parts(const float* A, const float* B, float* part, int M, int N, int K, int with_colsum, hipStream_t s);
 int train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, hipStream_t s);
 int train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, float p, hipStream_t s);
 int train_colsum_parts(int M);

@@ -142,6 +142,126 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict_
   out[i] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Deferred gradient reduction (cotr_train_reduce_jobs): ONE launch finishes every split-M / per-workgroup partial of a whole
+// backward pass and accumulates it into the persistent gradient buffers -
+//   dst[perm(e)] += scale[row(e)] * sum_p part[p][e]   for every source of the job in order, p in order (deterministic),
+// instead of one sum_parts launch per weight followed by autograd's own add_ into .grad (and, for the convolutions, a row
+// scale and a layout transpose).  The partials of a step stay where the producing kernels wrote them until the flush (about
+// 1-2 GB at 16 pairs x 200 queries: the HBM is 288 GB).  A job = one destination (a parameter gradient, or a row slice of one);
+// its sources = the uses of that parameter in the step, in the order autograd ran them (the decoder's weights are used by
+// the first and by the cycle pass).  Workgroup = 1024 consecutive elements of one job (chunk_job[workgroup] = its job).  Same additions in the same order as sum_parts + scale_rows + add_: bit-identical gradients.
+//   perm: dst index of packed element e = row * row_len + tap * cin + c  is  row * row_len + c * taps + tap  (the packed
+//   [Cout][k][k][Cin] layout of the conv kernels back to torch's [Cout][Cin][k][k]); taps == 1: identity.
+// ---------------------------------------------------------------------------------------------------------------------
+// (rounds of 32 independent loads, added in order afterwards: a thread that owns a LayerNorm gradient element walks ~500 partials
+// per use of the weight - with 8 loads per round that walk was the whole launch's critical path)
+__device__ __forceinline__ float reduce_one(const TrainReduceSrc& sc, unsigned e) {
+  const float* p0 = sc.part + e;
+  float acc = 0.f;
+  unsigned p = 0;
+  for (; p + 32 <= sc.nparts; p += 32) {
+    float t[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t[k] = p0[(size_t)(p + k) * sc.pstride];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc += t[k];
+  }
+  for (; p + 8 <= sc.nparts; p += 8) {
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = p0[(size_t)(p + k) * sc.pstride];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += t[k];
+  }
+  for (; p < sc.nparts; ++p) acc += p0[(size_t)p * sc.pstride];
+  return acc;
+}
+__device__ __forceinline__ f32x4 reduce_four(const TrainReduceSrc& sc, unsigned e) {
+  const float* p0 = sc.part + e;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  unsigned p = 0;
+  for (; p + 32 <= sc.nparts; p += 32) {
+    f32x4 t[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t[k] = *reinterpret_cast<const f32x4*>(p0 + (size_t)(p + k) * sc.pstride);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc += t[k];
+  }
+  for (; p + 8 <= sc.nparts; p += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = *reinterpret_cast<const f32x4*>(p0 + (size_t)(p + k) * sc.pstride);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += t[k];
+  }
+  for (; p < sc.nparts; ++p) acc += *reinterpret_cast<const f32x4*>(p0 + (size_t)p * sc.pstride);
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(const TrainReduceJob* __restrict__ jobs,
+                                                          const TrainReduceSrc* __restrict__ srcs,
+                                                          const unsigned* __restrict__ chunk_job) {
+  const TrainReduceJob j = jobs[chunk_job[blockIdx.x]];
+  const unsigned base = (blockIdx.x - j.chunk0) * 1024u;
+  if (j.vec) {                                         // every pointer 16-byte aligned, every count a multiple of 4
+    const unsigned e = base + threadIdx.x * 4;
+    if (e >= j.numel) return;
+    unsigned d = e;
+    float sc = 1.f;
+    if (j.row_len) {
+      const unsigned row = e / j.row_len, col = e - row * j.row_len;
+      if (j.scale != nullptr) sc = j.scale[row];
+      if (j.taps > 1) {
+        const unsigned tap = col / j.cin, c = col - tap * j.cin;
+        d = row * j.row_len + c * j.taps + tap;
+      }
+    }
+    f32x4 tot;
+    if (j.taps > 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tot[i] = j.dst[d + i * j.taps];
+    } else
+      tot = *reinterpret_cast<const f32x4*>(j.dst + d);
+    for (unsigned s = 0; s < j.n_src; ++s) {
+      f32x4 a = reduce_four(srcs[j.first_src + s], e);
+      if (j.scale != nullptr) {                        // (a separate rounding, as scale_rows + add_ make: no fused multiply-add)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = __fmul_rn(a[i], sc);
+      }
+      tot += a;
+    }
+    if (j.taps > 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) j.dst[d + i * j.taps] = tot[i];
+    } else
+      *reinterpret_cast<f32x4*>(j.dst + d) = tot;
+    return;
+  }
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const unsigned e = base + i * 256 + threadIdx.x;
+    if (e >= j.numel) return;
+    unsigned d = e;
+    float sc = 1.f;
+    if (j.row_len) {
+      const unsigned row = e / j.row_len, col = e - row * j.row_len;
+      if (j.scale != nullptr) sc = j.scale[row];
+      if (j.taps > 1) {
+        const unsigned tap = col / j.cin, c = col - tap * j.cin;
+        d = row * j.row_len + c * j.taps + tap;
+      }
+    }
+    float tot = j.dst[d];
+    for (unsigned s = 0; s < j.n_src; ++s) {
+      float a = reduce_one(srcs[j.first_src + s], e);
+      if (j.scale != nullptr) a = __fmul_rn(a, sc);
+      tot += a;
+    }
+    j.dst[d] = tot;
+  }
+}
+
 // y[m][:] = x[m][:] + x2[m % mod][:] over rows of 256 (mod == 0: x2 has one row per row of x): src + pos, tgt + query_pos
 __global__ __launch_bounds__(256) void add_rowmod_kernel(const float* __restrict__ x, const float* __restrict__ x2, int mod,
                                                          float* __restrict__ y, int rows) {
@@ -564,6 +684,7 @@ int train_ln_bwd(const float* dy, const float* s_in, const float* stats, const f
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nwg), dim3(256), 0, s, dy, s_in, stats, w, ds, da, part, rows, per, train_thresh(p),
                      p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
   if (hipGetLastError() != hipSuccess) return -2;
+  if (dwb == nullptr) return 0;                          // the caller finishes the partials later (train_reduce_jobs)
   return train_sum_parts(part, nwg, (size_t)512, dwb, s);
 }
 
@@ -576,6 +697,13 @@ int train_add_rowmod(const float* x, const float* x2, int mod, float* y, int row
 int train_sum_parts(const float* part, int nparts, size_t numel, float* out, hipStream_t s) {
   if (numel == 0) return 0;
   hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, s, part, nparts, numel, out);
+  return LAUNCH_OK();
+}
+
+int train_reduce_jobs(const TrainReduceJob* jobs, const TrainReduceSrc* srcs, const unsigned* chunk_job, int njobs, int nchunks,
+                      hipStream_t s) {
+  if (njobs <= 0 || nchunks <= 0) return 0;
+  hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, jobs, srcs, chunk_job);
   return LAUNCH_OK();
 }
 
@@ -686,6 +814,16 @@ int train_gemm_tn(const float* A, const float* B, float* part, float* out, float
   if (M == 0) {   // an empty batch (no queries) contributes zero gradients: dW = 0, db = 0, like the other wrappers' no-ops
     return hipMemsetAsync(out, 0, ((size_t)N * K + (colsum != nullptr ? N : 0)) * sizeof(float), s) == hipSuccess ? 0 : -2;
   }
+  const int nsplit = train_gemm_tn_parts(A, B, part, M, N, K, colsum != nullptr ? 1 : 0, s);
+  if (nsplit < 0) return nsplit;
+  return train_sum_parts(part, nsplit, (size_t)N * K + (colsum ? N : 0), out, s);
+}
+
+// The partials alone: part[split][N*K (+ N column sums with with_colsum)]; -> number of splits written (0 for M == 0: nothing
+// to add), < 0 on error.  The caller sums them in split order (train_sum_parts, or later through train_reduce_jobs).
+int train_gemm_tn_parts(const float* A, const float* B, float* part, int M, int N, int K, int with_colsum, hipStream_t s) {
+  if (N % 64 || K % 64 || M < 0) return -1;
+  if (M == 0) return 0;
   const int splits = train_gemm_tn_splits(M, N, K);
   int per = (M + splits - 1) / splits;
   per = (per + 31) / 32 * 32;
@@ -702,12 +840,12 @@ int train_gemm_tn(const float* A, const float* B, float* part, float* out, float
       attr_set.set();
     }
     hipLaunchKernelGGL(gemm_tn_big_kernel, dim3((N / 128) * (K / 128), nsplit), dim3(256), smem, s, A, B, part, M, N, K, per,
-                       colsum != nullptr ? 1 : 0, zeros);
+                       with_colsum ? 1 : 0, zeros);
   } else
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((N / 64) * (K / 64), nsplit), dim3(256), 0, s, A, B, part, M, N, K, per,
-                       colsum != nullptr ? 1 : 0);
+                       with_colsum ? 1 : 0);
   if (hipGetLastError() != hipSuccess) return -2;
-  return train_sum_parts(part, nsplit, (size_t)N * K + (colsum ? N : 0), out, s);
+  return nsplit;
 }
 
 int train_head_bwd_parts(int rows) {
@@ -724,5 +862,6 @@ int train_head_bwd(const float* dy, const float* h, const float* w2, float* dh, 
   const int nwg = (rows + per - 1) / per;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(nwg), dim3(256), 0, s, dy, h, w2, dh, part, rows, per);
   if (hipGetLastError() != hipSuccess) return -2;
+  if (dwb == nullptr) return 0;                          // deferred (train_reduce_jobs)
   return train_sum_parts(part, nwg, (size_t)514, dwb, s);
 }

@@ -206,6 +206,19 @@ def sharded_zoom_engine(*args, group=None, **kwargs):
     return ShardedZoomEngine(*args, **kwargs)
 
 
+def sync_flat_gradients(flat, group=None):
+    """The same exchange for gradients that already ARE one flat buffer (``train_ops.GradSink.flat``: its length is a multiple
+    of 64, so of every world size up to 64): reduce-scatter, 1/N on the local shard, all-gather in place - no packing copies."""
+    if not _active(group):
+        return
+    world = dist.get_world_size(group)
+    assert flat.numel() % world == 0, (flat.numel(), world)
+    shard = torch.empty(flat.numel() // world, dtype=flat.dtype, device=flat.device)
+    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
+    shard /= world
+    dist.all_gather_into_tensor(flat, shard, group=group)
+
+
 def sync_gradients_sharded(params, group=None, bucket_elems=1 << 25):
     """Average the gradients over the ranks: per flat fp32 bucket (128 MB: the whole trainable part - 39.5 MB in stage 1
     of the reference's recipe, 72.7 MB with the backbone, SURVEY.md 8f4 - is ONE bucket) one reduce-scatter + one

@@ -102,6 +102,218 @@ def gemm_tn(dy, x, with_colsum=False):
     return buf[:n * k].view(n, k), (buf[n * k:] if with_colsum else None)
 
 
+# ---- deferred gradient reduction --------------------------------------------------------------------------------------
+_JOB_DT = None
+_SRC_DT = None
+
+
+def _record_dtypes():
+    """numpy layouts of cotr_reduce_job / cotr_reduce_src (include/cotr_hip.h)."""
+    global _JOB_DT, _SRC_DT
+    if _JOB_DT is None:
+        import numpy as np
+        _SRC_DT = np.dtype([('part', '<u8'), ('pstride', '<u8'), ('nparts', '<u4'), ('pad', '<u4')])
+        _JOB_DT = np.dtype([('dst', '<u8'), ('scale', '<u8'), ('numel', '<u4'), ('first_src', '<u4'), ('n_src', '<u4'),
+                            ('chunk0', '<u4'), ('row_len', '<u4'), ('cin', '<u4'), ('taps', '<u4'), ('vec', '<u4')])
+        assert _SRC_DT.itemsize == 24 and _JOB_DT.itemsize == 48
+    return _JOB_DT, _SRC_DT
+
+
+class GradSink:
+    """Persistent flat gradient buffer + ONE reduction launch per backward pass.
+
+    Without it every weight gradient costs: the split-M partials of ``gemm_tn`` (or the per-workgroup partials of the LayerNorm /
+    head backward), a ``sum_parts`` launch, for the convolutions a row scale and a layout transpose, a ``cat`` for the packed
+    projections and autograd's own ``add_`` into ``.grad`` - ~150 reduction launches + ~230 accumulations per step.  With a sink
+    installed (``with sink.collect(): loss.backward()``) the backward Functions below leave their partials where the kernels wrote
+    them (a step's worth is 1-2 GB; the HBM holds 288), register (destination, partials) with the sink and return no gradient for
+    the parameter; ``flush()`` then runs ``cotr_train_reduce_jobs`` once: every destination += its sources in the order autograd
+    produced them, each source's partials in split order - the additions ``sum_parts`` + ``add_`` would have made, so the
+    gradients are bit-identical to the Function-by-Function path (tests/test_training_gpu.py).
+
+    The gradients of all parameters are views of one buffer (``flat``): ``zero()`` is one memset and the gradient exchange
+    between ranks one collective.  A parameter the sink does not own (or a Function given a non-leaf weight) takes the ordinary
+    path."""
+    CHUNK = 1024
+
+    def __init__(self, params, capacity=2048):
+        params = [p for p in params if p.requires_grad]
+        assert params, 'no trainable parameter'
+        dev = params[0].device
+        self.params, offs, total = params, [], 0
+        for p in params:
+            assert p.is_leaf and p.dtype == torch.float32 and p.device == dev and p.is_contiguous()
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64                       # every gradient starts on a 256-byte boundary
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        self._lo, self._hi = self.flat.data_ptr(), self.flat.data_ptr() + total * 4
+        self.capacity = capacity
+        job_dt, src_dt = _record_dtypes()
+        # records (up to 4 uses of a parameter per step on average) + one word per 1024-element chunk
+        nbytes = capacity * (job_dt.itemsize + 4 * src_dt.itemsize) + 4 * (total // self.CHUNK + 2 * capacity)
+        self._host = torch.empty(nbytes, dtype=torch.uint8)
+        if dev.type == 'cuda':
+            self._host = self._host.pin_memory()
+        self._dev = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._uploaded = None                                          # event after the last table upload
+        self._jobs, self._keep = {}, []
+        self.frozen = False                                            # set by GraphedTrainStep after capture
+        self.last = (0, 0)                                             # (jobs, sources) of the last flush, for tests / reports
+
+    # -- ownership ------------------------------------------------------------------------------------------------------
+    def grad_of(self, w):
+        """The gradient tensor to accumulate into for weight ``w`` (a parameter of this sink, or a same-size contiguous view of
+        one, e.g. ``input_proj.weight.view(256, 1024)``), or None."""
+        base = w
+        if not w.is_leaf:
+            base = w._base
+            if base is None or not base.is_leaf or base.numel() != w.numel() or not w.is_contiguous():
+                return None
+        g = base.grad
+        if g is None or not (self._lo <= g.data_ptr() < self._hi):
+            return None
+        return g.view(w.shape)
+
+    def zero(self):
+        self.flat.zero_()
+
+    def attach(self):
+        """Re-install the gradient views (after an ``optim.zero_grad()`` with ``set_to_none`` dropped them)."""
+        off = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self._lo + off * 4:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += (p.numel() + 63) // 64 * 64
+
+    # -- collection -----------------------------------------------------------------------------------------------------
+    def collect(self):
+        """Context: the backward Functions of this module hand their parameter gradients to this sink while it is active
+        (process-wide - the autograd engine runs them on its own thread); flushes on exit."""
+        return _Collect(self)
+
+    def add(self, dst, part, part_off, nparts, pstride, numel, scale=None, row_len=0, cin=0, taps=1):
+        """dst (a contiguous view into ``flat``, ``numel`` elements) += sum over the ``nparts`` partials
+        ``part[part_off + p * pstride : ... + numel]`` (x ``scale[row]`` / re-laid-out, see cotr_reduce_job)."""
+        assert not self.frozen, 'this sink belongs to a captured step'
+        assert dst.is_contiguous() and dst.numel() == numel and self._lo <= dst.data_ptr() < self._hi
+        if nparts <= 0:
+            return
+        key = dst.data_ptr()
+        job = self._jobs.get(key)
+        meta = (numel, 0 if scale is None else scale.data_ptr(), row_len, cin, taps)
+        if job is None:
+            job = self._jobs[key] = {'meta': meta, 'srcs': []}
+        else:
+            assert job['meta'] == meta, 'two uses of one parameter disagree on the gradient layout'
+        job['srcs'].append((part.data_ptr() + part_off * 4, pstride, nparts))
+        self._keep.append(part)
+        if scale is not None:
+            self._keep.append(scale)
+
+    def tables(self):
+        """-> (jobs, srcs, nchunks) as numpy record arrays (host side of flush(); also what the CPU test inspects)."""
+        import numpy as np
+        job_dt, src_dt = _record_dtypes()
+        nj = len(self._jobs)
+        ns = sum(len(j['srcs']) for j in self._jobs.values())
+        jobs, srcs = np.zeros(nj, dtype=job_dt), np.zeros(ns, dtype=src_dt)
+        chunk = si = 0
+        # the longest per-thread walks first (a LayerNorm weight: ~500 partials per use): they would otherwise be the launch's tail.
+        # (Order of the JOBS only - within a job the sources keep autograd's order, so the arithmetic does not change.)
+        order = sorted(self._jobs.items(), key=lambda kv: -sum(n for _, _, n in kv[1]['srcs']))
+        for ji, (dst, j) in enumerate(order):
+            numel, scale, row_len, cin, taps = j['meta']
+            vec = dst % 16 == 0 and numel % 4 == 0 and row_len % 4 == 0 and cin % 4 == 0
+            for ptr, pstride, nparts in j['srcs']:
+                srcs[si] = (ptr, pstride, nparts, 0)
+                vec = vec and ptr % 16 == 0 and pstride % 4 == 0
+                si += 1
+            jobs[ji] = (dst, scale, numel, si - len(j['srcs']), len(j['srcs']), chunk, row_len, cin, taps, int(vec))
+            chunk += (numel + self.CHUNK - 1) // self.CHUNK
+        return jobs, srcs, chunk
+
+    @staticmethod
+    def chunk_map(jobs, nchunks):
+        """chunk -> job index (one workgroup of cotr_train_reduce_jobs per chunk)."""
+        import numpy as np
+        counts = np.diff(np.append(jobs['chunk0'], np.uint32(nchunks))).astype(np.int64)
+        return np.repeat(np.arange(len(jobs), dtype=np.uint32), counts)
+
+    def flush(self):
+        """One launch: every registered partial is summed into its gradient.  The partial buffers are released afterwards (the
+        caching allocator is stream-ordered: they are not reused before the launch has run)."""
+        if not self._jobs:
+            self.last = (0, 0)
+            return
+        import numpy as np
+        jobs, srcs, nchunks = self.tables()
+        cmap = self.chunk_map(jobs, nchunks)
+        jb, sb, cb = jobs.nbytes, srcs.nbytes, cmap.nbytes
+        assert jb + sb + cb <= self._host.numel(), 'GradSink capacity exceeded'
+        capturing = self.flat.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self._uploaded is not None and not capturing:
+            self._uploaded.synchronize()                               # the previous upload has left the pinned buffer
+        host = self._host.numpy()
+        host[:jb] = jobs.view(np.uint8)
+        host[jb:jb + sb] = srcs.view(np.uint8)
+        host[jb + sb:jb + sb + cb] = cmap.view(np.uint8)
+        self._dev[:jb + sb + cb].copy_(self._host[:jb + sb + cb], non_blocking=True)
+        if self.flat.is_cuda and not capturing:
+            self._uploaded = torch.cuda.Event()
+            self._uploaded.record()
+        lib = _lib.load_library()
+        with _on(self.flat.device):
+            base = self._dev.data_ptr()
+            _chk(lib.cotr_train_reduce_jobs(ctypes.c_void_p(base), ctypes.c_void_p(base + jb), ctypes.c_void_p(base + jb + sb), len(jobs),
+                                            nchunks, _sp()), 'cotr_train_reduce_jobs')
+        self.last = (len(jobs), len(srcs))
+        self._jobs, self._keep = {}, []
+
+    def discard(self):
+        self._jobs, self._keep = {}, []
+
+
+_sink = None      # the GradSink collecting right now (process-wide: backward runs on the autograd engine's thread)
+
+
+class _Collect:
+    def __init__(self, sink):
+        self.sink = sink
+
+    def __enter__(self):
+        global _sink
+        assert _sink is None, 'another GradSink is collecting'
+        self.sink.attach()
+        _sink = self.sink
+        return self.sink
+
+    def __exit__(self, exc_type, exc, tb):
+        global _sink
+        _sink = None
+        if exc_type is None:
+            self.sink.flush()
+        else:
+            self.sink.discard()
+        return False
+
+
+def gemm_tn_parts(dy, x, with_colsum=False):
+    """The split-M partials of ``gemm_tn`` alone -> (part, number of partials, floats per partial = n*k (+ n))."""
+    lib = _lib.load_library()
+    m, n = dy.shape
+    k = x.shape[1]
+    assert dy.is_contiguous() and x.is_contiguous() and x.shape[0] == m
+    pstride = n * k + (n if with_colsum else 0)
+    part = _empty((max(1, lib.cotr_train_gemm_tn_splits(m, n, k)) * pstride,), dy)
+    with _on(dy.device):
+        rc = lib.cotr_train_gemm_tn_parts(_P(dy), _P(x), _P(part), m, n, k, int(with_colsum), _sp())
+    if rc < 0:
+        _chk(rc, f'cotr_train_gemm_tn_parts {m}x{n}x{k}')
+    return part, rc, pstride
+
+
 def colsum(x, out):
     lib = _lib.load_library()
     m, n = x.shape
@@ -167,6 +379,7 @@ class Proj(torch.autograd.Function):
             with _on(ys[0].device):
                 _chk(lib.cotr_train_dropout_fwd(_P(ys[0]), ys[0].numel(), float(p), seed, _sp()), 'cotr_train_dropout_fwd')
         ctx.ranges, ctx.relu, ctx.p, ctx.has_bias = ranges, relu, float(p), b is not None
+        ctx.bias = b                                       # (the parameter itself: GradSink needs to know whose gradient db is)
         ctx.save_for_backward(w, *xs, *(ys if relu else []))
         return tuple(ys)
 
@@ -180,6 +393,12 @@ class Proj(torch.autograd.Function):
         need_w = ctx.needs_input_grad[0]
         need_b = ctx.has_bias and ctx.needs_input_grad[1]
         dws, dbs, dxs = [], [], []
+        sink, gw, gb = _sink, None, None
+        if sink is not None and need_w:                   # gradients straight into the sink's buffers (GradSink)
+            gw = sink.grad_of(w)
+            gb = sink.grad_of(ctx.bias) if need_b else None
+            if gw is None or (need_b and gb is None):
+                gw = gb = None
         for i, ((lo, hi), x, dy) in enumerate(zip(ctx.ranges, xs, dys)):
             if dy is None:      # an output nobody used
                 dy = torch.zeros((x.shape[0], hi - lo), dtype=torch.float32, device=x.device)
@@ -191,7 +410,13 @@ class Proj(torch.autograd.Function):
                     _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dh), dy.numel(), ctx.p, _sp()), 'cotr_train_relu_drop_bwd')
                 dy = dh
             dxs.append(gemm(dy, weight_t(w[lo:hi])) if ctx.needs_input_grad[5 + i] else None)
-            if need_w:
+            if gw is not None:
+                part, nparts, pstride = gemm_tn_parts(dy, x, with_colsum=need_b)
+                nk = (hi - lo) * w.shape[1]
+                sink.add(gw[lo:hi], part, 0, nparts, pstride, nk)
+                if need_b:
+                    sink.add(gb[lo:hi], part, nk, nparts, pstride, hi - lo)
+            elif need_w:
                 dwi, dbi = gemm_tn(dy, x, with_colsum=need_b)      # dW and db of this slice from one pass over dy
                 dws.append(dwi)
                 dbs.append(dbi)
@@ -199,6 +424,8 @@ class Proj(torch.autograd.Function):
                 dbs.append(colsum(dy, _empty((hi - lo,), dy)))
         assert [lo for lo, _ in ctx.ranges] == [0] + [hi for _, hi in ctx.ranges[:-1]] and ctx.ranges[-1][1] == w.shape[0], \
             'the slices must tile the weight in order'
+        if gw is not None:
+            return (None, None, None, None, None, *dxs)
         dw = (dws[0] if n == 1 else torch.cat(dws, dim=0)) if need_w else None
         db = (dbs[0] if n == 1 else torch.cat(dbs, dim=0)) if need_b else None
         return (dw, db, None, None, None, *dxs)
@@ -240,6 +467,7 @@ class AddDropLN(torch.autograd.Function):
             _chk(lib.cotr_train_add_drop_ln_fwd(_P(None if x is None else x.contiguous()), _P(a), _P(w.detach()), _P(b.detach()),
                                                 _P(s), _P(y), _P(stats), rows, float(p), seed, _sp()), 'cotr_train_add_drop_ln_fwd')
         ctx.p, ctx.seed, ctx.has_x = float(p), seed, x is not None
+        ctx.bias = b
         ctx.save_for_backward(s, stats, w)
         return y
 
@@ -251,11 +479,20 @@ class AddDropLN(torch.autograd.Function):
         rows = dy.shape[0]
         ds = torch.empty_like(dy)
         da = torch.empty_like(dy) if ctx.p > 0 else None          # p == 0: da == ds
-        part = _empty((lib.cotr_train_ln_bwd_parts(rows) * 512,), dy)
-        dwb = _empty((512,), dy)
+        nparts = lib.cotr_train_ln_bwd_parts(rows)
+        part = _empty((nparts * 512,), dy)
+        sink = _sink
+        gw = sink.grad_of(w) if sink is not None else None
+        gb = sink.grad_of(ctx.bias) if gw is not None else None
+        deferred = gb is not None and rows > 0
+        dwb = None if deferred else _empty((512,), dy)
         with _on(dy.device):
             _chk(lib.cotr_train_ln_bwd(_P(dy), _P(s), _P(stats), _P(w), _P(ds), _P(da), _P(part), _P(dwb), rows, ctx.p, ctx.seed,
                                        _sp()), 'cotr_train_ln_bwd')
+        if deferred:
+            sink.add(gw, part, 0, nparts, 512, 256)
+            sink.add(gb, part, 256, nparts, 512, 256)
+            return (ds if ctx.has_x else None), (ds if da is None else da), None, None, None
         return (ds if ctx.has_x else None), (ds if da is None else da), dwb[:256], dwb[256:], None
 
 
@@ -348,6 +585,7 @@ class ConvBN(torch.autograd.Function):
             _chk(lib.cotr_op_conv(_P(x), _P(wp), _P(scale), _P(bias), _P(None if res is None else res.contiguous()), int(relu), _P(y),
                                   b, h, wd, cin, cout, k, stride, _sp()), 'cotr_op_conv')
         ctx.meta = (b, h, wd, cin, cout, k, stride, ho, wo, bool(relu), res is not None)
+        ctx.weight = w
         ctx.save_for_backward(x, wp, scale, y)
         return y
 
@@ -371,7 +609,11 @@ class ConvBN(torch.autograd.Function):
                 col = _empty((m, kk), x)
                 _chk(lib.cotr_train_im2col(_P(x), _P(col), b, h, wd, cin, k, stride, _sp()), 'cotr_train_im2col')
             dw = None
-            if ctx.needs_input_grad[1]:
+            gw = _sink.grad_of(ctx.weight) if (_sink is not None and ctx.needs_input_grad[1]) else None
+            if gw is not None:                                                # scale + layout inside the deferred reduction
+                part, nparts, pstride = gemm_tn_parts(dz2, col)
+                _sink.add(gw, part, 0, nparts, pstride, cout * kk, scale=scale, row_len=kk, cin=cin, taps=k * k)
+            elif ctx.needs_input_grad[1]:
                 dwp, _ = gemm_tn(dz2, col)                                    # d(W * scale), packed layout
                 _chk(lib.cotr_train_scale_rows(_P(dwp), _P(scale), _P(dwp), cout, kk, _sp()), 'cotr_train_scale_rows')
                 if k == 1:
@@ -404,6 +646,7 @@ class Head(torch.autograd.Function):
         y = _empty((nb, nq, 2), h)
         with _on(h.device):
             _chk(lib.cotr_train_head_fwd(_P(h), _P(w2.detach().contiguous()), _P(b2.detach()), _P(y), nb, nq, _sp()), 'cotr_train_head_fwd')
+        ctx.bias = b2
         ctx.save_for_backward(h, w2)
         return y
 
@@ -414,8 +657,17 @@ class Head(torch.autograd.Function):
         dy = dy.contiguous()
         rows = h.shape[0]
         dh = torch.empty_like(h)
-        part = _empty((lib.cotr_train_head_bwd_parts(rows) * 514,), h)
-        dwb = _empty((514,), h)
+        nparts = lib.cotr_train_head_bwd_parts(rows)
+        part = _empty((nparts * 514,), h)
+        sink = _sink
+        gw = sink.grad_of(w2) if sink is not None else None
+        gb = sink.grad_of(ctx.bias) if gw is not None else None
+        deferred = gb is not None and rows > 0
+        dwb = None if deferred else _empty((514,), h)
         with _on(h.device):
             _chk(lib.cotr_train_head_bwd(_P(dy), _P(h), _P(w2.contiguous()), _P(dh), _P(part), _P(dwb), rows, _sp()), 'cotr_train_head_bwd')
+        if deferred:
+            sink.add(gw, part, 0, nparts, 514, 512)
+            sink.add(gb, part, 512, nparts, 514, 2)
+            return dh, None, None, None, None
         return dh, dwb[:512].view(2, 256), dwb[512:], None, None

@@ -424,11 +424,13 @@ class GraphedTrainStep:
     Difference to ``train_batch``: the reference skips backward when the loss is NaN (cotr_trainer.py:145-147); a graph cannot
     skip, so ``__call__(..., check=True)`` raises after the fact instead (the weights have then seen the NaN step)."""
 
-    def __init__(self, model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None, warmup=3):
+    def __init__(self, model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None, warmup=3, sink=True):
         from . import train_ops as T
         assert model.training and img.is_cuda
         assert all(g.get('capturable', False) for g in optim.param_groups), 'build the optimiser with capturable=True'
         self.model, self.optim, self.group = model, optim, group
+        # the step's own GradSink (its job table is baked into the graph: it is never used for eager steps)
+        self.sink = grad_sink_for(optim) if sink else None
         self.args = (cycle_consis, bidirectional)
         self.img, self.query, self.target = img.clone(), query.clone(), target.clone()
         self.salt = torch.zeros(1, dtype=torch.int32, device=img.device)
@@ -446,18 +448,32 @@ class GraphedTrainStep:
         torch.cuda.synchronize(img.device)
         T.clear_weight_cache()                             # transposes made during capture must live in the graph's pool
         self.graph = torch.cuda.CUDAGraph()
-        optim.zero_grad(set_to_none=True)
+        if self.sink is None:
+            optim.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss, self.pred = self._body()
+        if self.sink is not None:
+            self.sink.frozen = True                        # the graph replays its table upload from the sink's pinned buffer
         T.clear_weight_cache()                             # (their Python handles may go: the pool keeps the memory for the graph)
 
     def _body(self):
         self.salt.add_(0x3C6EF35F)                         # a new mask family per step (int32 wrap-around is fine)
-        self.optim.zero_grad(set_to_none=True)
+        if self.sink is not None:
+            self.sink.attach()
+            self.sink.zero()
+        else:
+            self.optim.zero_grad(set_to_none=True)
         loss, pred = compute_loss(self.model, self.img, self.query, self.target, *self.args, branch_free=True)
-        loss.backward()
+        if self.sink is not None:
+            with self.sink.collect():
+                loss.backward()
+        else:
+            loss.backward()
         import torch.distributed as dist
-        if self.group is not None or (dist.is_available() and dist.is_initialized()):
+        if (self.group is not None or (dist.is_available() and dist.is_initialized())) and self.sink is not None:
+            from .dist import sync_flat_gradients
+            sync_flat_gradients(self.sink.flat, self.group)
+        elif self.group is not None or (dist.is_available() and dist.is_initialized()):
             sync_gradients([p for g in self.optim.param_groups for p in g['params']], self.group)
         self.optim.step()
         return loss.detach(), pred.detach()
@@ -496,18 +512,34 @@ class GraphedTrainStep:
         self.close()
 
 
-def train_batch(model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None):
+def grad_sink_for(optim):
+    """A ``train_ops.GradSink`` over the optimiser's parameters: their gradients become views of one flat buffer and a backward
+    pass finishes all of them with one reduction launch (``train_batch(..., sink=...)``)."""
+    from . import train_ops as T
+    return T.GradSink([p for g in optim.param_groups for p in g['params']])
+
+
+def train_batch(model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None, sink=None):
     """One optimisation step, ``COTRTrainer.train_batch`` (cotr_trainer.py:118-150); with ``group`` (or an initialised
     default process group) the gradients are averaged over the ranks (one rank per GPU, RCCL) before the optimiser
     step.  -> (loss value, pred).
 
     Rank symmetry: the reference skips backward when the loss is NaN (:145-147).  With several ranks that decision has
     to be COMMON - a rank that skipped would leave the others alone in the gradient collective - so the NaN flag is
-    max-reduced first and every rank skips (or steps) together."""
+    max-reduced first and every rank skips (or steps) together.
+
+    ``sink`` (``grad_sink_for(optim)``, made once and passed to every step): the gradients live in the sink's flat buffer, are
+    zeroed by one memset and finished by one reduction launch after backward instead of a reduction + an accumulation per
+    weight - same values bit for bit.  A NaN step then leaves the weights alone (no optimiser step), as ``zero_grad()`` to
+    None does on the path without a sink."""
     import torch.distributed as dist
     assert model.training
     distributed = group is not None or (dist.is_available() and dist.is_initialized())
-    optim.zero_grad()
+    if sink is not None:
+        sink.attach()
+        sink.zero()
+    else:
+        optim.zero_grad()
     loss, pred = compute_loss(model, img, query, target, cycle_consis, bidirectional)
     value = loss.item()
     bad = math.isnan(value)
@@ -516,10 +548,19 @@ def train_batch(model, optim, img, query, target, cycle_consis=True, bidirection
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
         bad = bool(flag.item() > 0)
     if bad:
+        if sink is not None:
+            return value, pred.detach()
         optim.zero_grad()
     else:
-        loss.backward()
-        if distributed:
+        if sink is not None:
+            with sink.collect():
+                loss.backward()
+        else:
+            loss.backward()
+        if distributed and sink is not None:
+            from .dist import sync_flat_gradients
+            sync_flat_gradients(sink.flat, group)
+        elif distributed:
             sync_gradients([p for g in optim.param_groups for p in g['params']], group)
     optim.step()
     return value, pred.detach()

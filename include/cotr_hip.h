@@ -220,6 +220,28 @@ int cotr_train_transpose_batched(const float* src, float* dst, int batch, int R,
 int cotr_train_gemm_tn_splits(int M, int N, int K);
 int cotr_train_gemm_tn(const float* A, const float* B, float* part, float* out, float* colsum, int M, int N, int K,
                        cotr_stream stream);
+/* The partials of cotr_train_gemm_tn alone (part [splits][N*K (+ N with with_colsum)]): -> number of partials written (0 for
+ * M == 0), < 0 = error.  cotr_train_ln_bwd / cotr_train_head_bwd with dwb == NULL likewise leave their partials unsummed.
+ * cotr_train_reduce_jobs finishes ALL partials of a backward pass in one launch and accumulates them into the gradient buffers
+ * (cotr_amd/train_ops.py: GradSink - replaces one reduction launch per weight plus autograd's add_ into .grad):
+ *   for each job, each source in order:  dst[perm(e)] += scale[e / row_len] * sum_{p < nparts, in order} part[p * pstride + e]
+ * jobs / srcs / chunk_job live in DEVICE memory; one workgroup per 1024-element chunk: chunk0 = a job's first chunk
+ * ((numel + 1023) / 1024 chunks per job), nchunks = their total, chunk_job[c] = index of the job chunk c belongs to; taps > 1: element e = (row, tap, c) of a packed [row][taps][cin] record goes to (row, c, tap) (conv weight
+ * gradients back to torch's [Cout][Cin][k][k]); vec = 1 promises 16-byte aligned pointers and counts that are multiples of 4. */
+typedef struct cotr_reduce_src {
+  const float* part;
+  unsigned long long pstride;
+  unsigned nparts, pad_;
+} cotr_reduce_src;
+typedef struct cotr_reduce_job {
+  float* dst;
+  const float* scale;
+  unsigned numel, first_src, n_src, chunk0;
+  unsigned row_len, cin, taps, vec;
+} cotr_reduce_job;
+int cotr_train_gemm_tn_parts(const float* A, const float* B, float* part, int M, int N, int K, int with_colsum, cotr_stream stream);
+int cotr_train_reduce_jobs(const cotr_reduce_job* jobs, const cotr_reduce_src* srcs, const unsigned* chunk_job, int njobs, int nchunks,
+                           cotr_stream stream);
 /* last corr_embed layer 256 -> 2 (position_encoding.py:23-26): y [nb][nq][2]; backward: dh [rows][256], dwb [514] = dW2 | db2 */
 int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream);
 int cotr_train_head_bwd_parts(int rows);

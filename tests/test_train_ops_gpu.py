@@ -226,3 +226,69 @@ def test_conv_frozenbn_forward_backward(B, H, cin, cout, k, stride, res, relu):
     assert _rel(grads[1], refs[1]) < 5e-5
     if res:
         assert _rel(grads[2], nhwc(refs[2])) < 5e-5
+
+
+def test_reduce_jobs_kernel():
+    """cotr_train_reduce_jobs against torch: several jobs in one launch - plain (vector path), a tail that is not a multiple of
+    the chunk, two sources accumulating into one destination that already holds a value, misaligned records (scalar path: the
+    head's 514-float partials), and a conv weight gradient (row scale + [row][tap][cin] -> [row][cin][tap])."""
+    from cotr_amd import train_ops as T
+    g = torch.Generator().manual_seed(5)
+    dev = 'cuda'
+    params = [torch.nn.Parameter(torch.zeros(s, device=dev)) for s in ((256, 256), (256,), (2, 256), (2,), (64, 32, 3, 3), (3000,))]
+    sink = T.GradSink(params)
+    sink.flat.copy_(torch.randn(sink.flat.numel(), generator=g).to(dev))           # gradients start non-zero: the launch ACCUMULATES
+    start = [p.grad.detach().clone() for p in params]
+    want = [s.clone() for s in start]
+    # Linear: dW | db in one partial record, used twice (9 and 3 partials)
+    for nparts in (9, 3):
+        part = torch.randn(nparts, 256 * 256 + 256, generator=g).to(dev)
+        sink.add(params[0].grad, part, 0, nparts, 256 * 256 + 256, 256 * 256)
+        sink.add(params[1].grad, part, 256 * 256, nparts, 256 * 256 + 256, 256)
+        acc = torch.zeros(256 * 256 + 256, device=dev)
+        for p in range(nparts):
+            acc = acc + part[p]
+        want[0] = want[0] + acc[:256 * 256].view(256, 256)
+        want[1] = want[1] + acc[256 * 256:]
+    # head: 514-float records (8-byte aligned only)
+    part = torch.randn(5, 514, generator=g).to(dev)
+    sink.add(params[2].grad, part, 0, 5, 514, 512)
+    sink.add(params[3].grad, part, 512, 5, 514, 2)
+    acc = torch.zeros(514, device=dev)
+    for p in range(5):
+        acc = acc + part[p]
+    want[2] = want[2] + acc[:512].view(2, 256)
+    want[3] = want[3] + acc[512:]
+    # conv 3x3: packed [Cout][tap][Cin] partials, scaled per row, into torch's [Cout][Cin][3][3]
+    scale = torch.rand(64, generator=g).to(dev) + 0.5
+    part = torch.randn(17, 64 * 9 * 32, generator=g).to(dev)
+    sink.add(params[4].grad, part, 0, 17, 64 * 9 * 32, 64 * 9 * 32, scale=scale, row_len=9 * 32, cin=32, taps=9)
+    acc = torch.zeros(64 * 9 * 32, device=dev)
+    for p in range(17):
+        acc = acc + part[p]
+    want[4] = want[4] + (acc.view(64, 9 * 32) * scale[:, None]).view(64, 9, 32).permute(0, 2, 1).reshape(64, 32, 3, 3)
+    # a tail: 3000 elements = 2 full chunks + 952
+    part = torch.randn(2, 3000, generator=g).to(dev)
+    sink.add(params[5].grad, part, 0, 2, 3000, 3000)
+    want[5] = want[5] + (part[0] + part[1])
+    jobs, srcs, nchunks = sink.tables()
+    assert len(jobs) == 6 and len(srcs) == 8 and nchunks == 64 + 1 + 1 + 1 + 18 + 3
+    by_dst = {int(j['dst']): j for j in jobs}                                       # (the jobs are ordered longest walk first)
+    assert [int(by_dst[p.grad.data_ptr()]['vec']) for p in params] == [1, 1, 0, 0, 1, 1]
+    assert [int(by_dst[p.grad.data_ptr()]['n_src']) for p in params] == [2, 2, 1, 1, 1, 1]
+    assert int(jobs['chunk0'][0]) == 0 and sum(int(n) for n in srcs['nparts'][:int(jobs['n_src'][0])]) == 17
+    cmap = T.GradSink.chunk_map(jobs, nchunks)
+    assert len(cmap) == nchunks and all(jobs['chunk0'][cmap[c]] <= c for c in range(nchunks)) and cmap[-1] == len(jobs) - 1
+    untouched = sink.flat.clone()
+    sink.flush()
+    torch.cuda.synchronize()
+    for p, w in zip(params, want):
+        assert torch.equal(p.grad, w), (tuple(p.shape), float((p.grad - w).abs().max()))
+    # nothing outside the six gradients was written (the padding between them)
+    mask = torch.ones_like(untouched, dtype=torch.bool)
+    for p in params:
+        o = (p.grad.data_ptr() - sink.flat.data_ptr()) // 4
+        mask[o:o + p.numel()] = False
+    assert torch.equal(sink.flat[mask], untouched[mask])
+    sink.flush()                                                                    # nothing registered: no launch, no change
+    assert sink.last == (0, 0)

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -117,3 +118,79 @@ def test_training_mode_without_gpu_fails_loudly():
         assert 'MI355X' in str(e) or 'HIP' in str(e) or 'cuda' in str(e).lower(), e
     else:
         raise AssertionError('training forward on CPU tensors must raise')
+
+
+def test_grad_sink_tables_and_ownership():
+    """train_ops.GradSink, host side: flat gradient views, ownership of parameters and of same-size views of them, the job /
+    source records handed to cotr_train_reduce_jobs (grouping of several uses of one parameter, chunk counts, the vector flag)."""
+    from cotr_amd import train_ops as T
+    w = torch.nn.Parameter(torch.zeros(256, 1024, 1, 1))
+    b = torch.nn.Parameter(torch.zeros(256))
+    other = torch.nn.Parameter(torch.zeros(8))
+    frozen = torch.nn.Parameter(torch.zeros(8), requires_grad=False)
+    sink = T.GradSink([w, b, frozen])
+    assert sink.flat.numel() == 256 * 1024 + 256 and w.grad.shape == w.shape and b.grad.data_ptr() == sink.flat.data_ptr() + 256 * 1024 * 4
+    assert sink.grad_of(w) is not None and sink.grad_of(other) is None and sink.grad_of(frozen) is None
+    view = sink.grad_of(w.view(256, 1024))                # input_proj.weight.view(d, CFEAT) in forward_train
+    assert view is not None and view.shape == (256, 1024) and view.data_ptr() == w.grad.data_ptr()
+    assert sink.grad_of(w.view(256, 1024)[:128]) is None and sink.grad_of(w.detach()) is None
+    part1, part2 = torch.zeros(3 * (512 * 1024 + 512) + 4), torch.zeros(2 * (512 * 1024 + 512))
+    rec = 512 * 1024 + 512
+    sink.add(view[0:128], part1, 0, 3, rec, 128 * 1024)
+    sink.add(b.grad[0:128], part1, 512 * 1024, 3, rec, 128)
+    sink.add(view[128:256], part1[4:], 0, 3, rec, 128 * 1024)     # (16-byte aligned all the same)
+    sink.add(view[0:128], part2, 0, 2, rec, 128 * 1024)           # a second use of the first slice
+    sink.add(b.grad[128:130], part2, 2, 2, rec, 2)                # two floats, source 8 bytes off: scalar path
+    jobs, srcs, nchunks = sink.tables()
+    assert len(jobs) == 4 and len(srcs) == 5 and nchunks == 128 + 1 + 128 + 1
+    # jobs ordered by the number of partials a thread walks (5, 3, 3, 2), sources of a job in registration order
+    assert [int(j['dst']) for j in jobs] == [view[0:128].data_ptr(), b.grad.data_ptr(), view[128:256].data_ptr(), b.grad[128:130].data_ptr()]
+    assert list(jobs['n_src']) == [2, 1, 1, 1] and list(jobs['first_src']) == [0, 2, 3, 4]
+    assert list(jobs['chunk0']) == [0, 128, 129, 257] and list(jobs['vec']) == [1, 1, 1, 0]
+    assert srcs['part'][1] == part2.data_ptr() and srcs['nparts'][1] == 2 and srcs['pstride'][0] == rec
+    cmap = T.GradSink.chunk_map(jobs, nchunks)
+    assert len(cmap) == 258 and cmap[0] == 0 and cmap[127] == 0 and cmap[128] == 1 and cmap[129] == 2 and cmap[257] == 3
+    with pytest.raises(AssertionError):
+        sink.add(other, part1, 0, 1, 8, 8)                        # not a view into this sink
+    sink.discard()
+    assert sink.tables()[2] == 0
+    w.grad = None
+    sink.attach()                                                 # after optim.zero_grad(set_to_none=True)
+    assert w.grad is not None and w.grad.data_ptr() == sink.flat.data_ptr()
+
+
+def _sink_worker(rank, world, port, out_dir):
+    """train_batch(..., sink=...) over two gloo ranks: the flat buffer is averaged by ONE reduce-scatter + all-gather."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(4, 2)
+    lin.training = True
+    opt = torch.optim.SGD(lin.parameters(), lr=1.0)
+    sink = training.grad_sink_for(opt)
+    x = torch.ones(3, 4)
+
+    def fake_loss(model, img, query, target, *a):
+        out = model(x)
+        return out.sum() * (1.0 + rank), out
+    before = [p.detach().clone() for p in lin.parameters()]
+    training.compute_loss, saved = fake_loss, training.compute_loss
+    try:
+        for _ in range(2):                                       # two steps: the buffer is zeroed in between
+            training.train_batch(lin, opt, None, None, None, sink=sink)
+    finally:
+        training.compute_loss = saved
+    # d(sum)/dW = 3 per element, db = 3; x (1 + rank) averaged over ranks 0, 1 = x 1.5; two SGD steps of lr 1
+    ok = all(torch.allclose(b - 2 * 4.5, a) for a, b in zip(lin.parameters(), before))
+    torch.save((ok, [p.detach().clone() for p in lin.parameters()]), os.path.join(out_dir, f's{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_train_batch_with_sink_world_size_2(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sink_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), f's{r}.pt')) for r in range(2)]
+    assert res[0][0] and res[1][0]
+    assert all(torch.equal(a, b) for a, b in zip(res[0][1], res[1][1]))
