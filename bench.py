@@ -355,12 +355,14 @@ def run_train(args, dev, world, rank):
     model.load_state_dict(synth_state_dict(0))
     model.train()
     graphed = args.graphed_train
-    optim = training.optimizer_for(model, learning_rate=1e-4, lr_backbone=lr_backbone, capturable=graphed)
+    use_sink = not args.no_grad_sink
+    # Adam as one launch on the sink's flat buffers (training.FusedAdam: torch.optim.Adam's update and state dict)
+    fused_adam = use_sink and not args.torch_adam
+    optim = training.optimizer_for(model, learning_rate=1e-4, lr_backbone=lr_backbone, capturable=graphed, fused=fused_adam)
     g = torch.Generator().manual_seed(5 + rank)
     img = torch.randn(pairs, 3, 256, 512, generator=g).to(dev)
     query, target = torch.rand(pairs, nq, 2, generator=g).to(dev), torch.rand(pairs, nq, 2, generator=g).to(dev)
     # gradients in one flat buffer, finished by one reduction launch per backward pass (train_ops.GradSink; same values bit for bit)
-    use_sink = not args.no_grad_sink
     if graphed:      # the whole step (zero_grad .. optimizer step, gradient collectives included) as ONE captured HIP graph
         gstep = training.GraphedTrainStep(model, optim, img, query, target, warmup=max(args.warmup, 2), sink=use_sink)
         step = lambda: gstep(img, query, target)
@@ -399,6 +401,7 @@ def run_train(args, dev, world, rank):
                        'pairs_per_gpu': pairs, 'queries_per_pair': nq,
                        'step': 'captured HIP graph (GraphedTrainStep)' if graphed else 'eager train_batch',
                        'gradients': 'GradSink: flat buffer, one deferred reduction launch' if use_sink else 'per-weight reductions + autograd accumulation',
+                       'optimizer': 'FusedAdam (torch.optim.Adam update, one launch)' if fused_adam else 'torch.optim.Adam',
                        'parallelism': f'data parallel x{world}, reduce-scatter + all-gather of the gradients' if world > 1 else 'single GPU'},
         }), flush=True)
 
@@ -476,6 +479,7 @@ def main():
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', choices=['headline', 'batch256', 'train'], default='headline')
+    ap.add_argument('--torch-adam', action='store_true', help="--workload train: torch.optim.Adam's own multi-tensor step instead of FusedAdam")
     ap.add_argument('--no-grad-sink', action='store_true',
                     help='--workload train: per-weight gradient reductions + autograd accumulation instead of the GradSink')
     ap.add_argument('--graphed-train', action='store_true',

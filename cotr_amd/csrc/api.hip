@@ -1701,6 +1701,15 @@ int cotr_train_reduce_jobs(const cotr_reduce_job* jobs, const cotr_reduce_src* s
   return op_ret(train_reduce_jobs(reinterpret_cast<const TrainReduceJob*>(jobs), reinterpret_cast<const TrainReduceSrc*>(srcs), chunk_job,
                                   njobs, nchunks, TS));
 }
+static_assert(sizeof(cotr_adam_job) == sizeof(TrainAdamJob), "include/cotr_hip.h and train.h disagree on cotr_adam_job");
+int cotr_train_adam(const cotr_adam_job* jobs, const unsigned* chunk_job, int nchunks, const float* g, float* m, float* v, const float* lr,
+                    int ngroups, double beta1, double beta2, double eps, double bias_correction1, double bias_correction2_sqrt,
+                    const float* step, cotr_stream stream) {
+  if (nchunks < 0 || (nchunks > 0 && (jobs == nullptr || chunk_job == nullptr || g == nullptr || m == nullptr || v == nullptr)))
+    return COTR_ERR_ARG;
+  return op_ret(train_adam(reinterpret_cast<const TrainAdamJob*>(jobs), chunk_job, nchunks, g, m, v, lr, ngroups, beta1, beta2, eps,
+                           bias_correction1, bias_correction2_sqrt, step, TS));
+}
 int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream) {
   return op_ret(launch_head2(x, w, b, y, nb, nq, nq, TS));
 }

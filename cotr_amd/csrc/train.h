@@ -51,6 +51,14 @@ struct TrainReduceJob {
 };
 int train_reduce_jobs(const TrainReduceJob* jobs, const TrainReduceSrc* srcs, const unsigned* chunk_job, int njobs, int nchunks,
                       hipStream_t s);
+struct TrainAdamJob {
+  float* p;                      // the parameter
+  unsigned long long off;        // its offset (floats) in the flat gradient / m / v buffers
+  unsigned numel, chunk0, group, vec;   // vec 1: p is 16-byte aligned
+};
+// lr: HOST array of ngroups (<= 8) learning rates, passed by value
+int train_adam(const TrainAdamJob* jobs, const unsigned* chunk_job, int nchunks, const float* g, float* m, float* v, const float* lr,
+               int ngroups, double b1, double b2, double eps, double bc1, double bc2_sqrt, const float* step_ptr, hipStream_t s);
 int train_gemm_tn_parts(const float* A, const float* B, float* part, int M, int N, int K, int with_colsum, hipStream_t s);
 int train_dropout_fwd(float* x, size_t n, float p, uint32_t seed, hipStream_t s);
 int train_relu_drop_bwd(const float* dy, const float* y, float* dx, size_t n, float p, hipStream_t s);

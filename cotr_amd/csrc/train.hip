@@ -262,6 +262,69 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(const TrainReduceJob* 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Adam over every trainable parameter in ONE launch (cotr_train_adam): torch.optim.Adam's update (train_cotr.py:49-57: betas
+// (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) as torch's multi-tensor path computes it -
+//   m += (g - m) (1 - b1);  v = v b2 + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// - on the GradSink's flat gradient buffer and flat m / v buffers of the same layout; the parameters themselves stay where the
+// model keeps them (one job per parameter: pointer, offset into the flat buffers, learning-rate group).  torch's own step is
+// ~15 multi-tensor launches that each stream the state once (0.57 ms for the 10.4 M stage-1 parameters); this is one pass.
+// step_ptr != nullptr: the step count is read from device memory (captured steps: the host does not know it).
+// ---------------------------------------------------------------------------------------------------------------------
+struct AdamArgs {
+  float lr[8];                   // per parameter group
+  float b1, b2, eps;
+  float omb1, omb2;              // 1 - b1, 1 - b2 rounded from DOUBLE as torch passes them (1 - 0.999f in float is 4.7e-5 off 0.001)
+  float bc1, bc2_sqrt;           // 1 - b1^t, sqrt(1 - b2^t) (host, double precision) when step_ptr == nullptr
+  const float* step_ptr;
+};
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt, float omb1, float b2,
+                                         float omb2, float eps) {
+  m = fmaf(omb1, g - m, m);
+  v = fmaf(omb2 * g, g, v * b2);
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - step_size * (m / denom);
+}
+__global__ __launch_bounds__(256) void adam_jobs_kernel(const TrainAdamJob* __restrict__ jobs, const unsigned* __restrict__ chunk_job,
+                                                        const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                        AdamArgs a) {
+  const TrainAdamJob j = jobs[chunk_job[blockIdx.x]];
+  float bc1 = a.bc1, bc2_sqrt = a.bc2_sqrt;
+  if (a.step_ptr != nullptr) {
+    const float t = *a.step_ptr;
+    bc1 = 1.f - powf(a.b1, t);
+    bc2_sqrt = sqrtf(1.f - powf(a.b2, t));
+  }
+  const float step_size = a.lr[j.group] / bc1;
+  const unsigned e = (blockIdx.x - j.chunk0) * 1024u + threadIdx.x * 4;
+  if (e >= j.numel) return;
+  const size_t o = j.off + e;
+  if (e + 4 <= j.numel && j.vec) {
+    f32x4 pp = *reinterpret_cast<const f32x4*>(j.p + e);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + o);
+    f32x4 mm = *reinterpret_cast<const f32x4*>(m + o), vv = *reinterpret_cast<const f32x4*>(v + o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float p1 = pp[i], m1 = mm[i], v1 = vv[i];
+      adam_one(p1, gg[i], m1, v1, step_size, bc2_sqrt, a.omb1, a.b2, a.omb2, a.eps);
+      pp[i] = p1;
+      mm[i] = m1;
+      vv[i] = v1;
+    }
+    *reinterpret_cast<f32x4*>(j.p + e) = pp;
+    *reinterpret_cast<f32x4*>(m + o) = mm;
+    *reinterpret_cast<f32x4*>(v + o) = vv;
+    return;
+  }
+  for (unsigned i = 0; i < 4 && e + i < j.numel; ++i) {
+    float pp = j.p[e + i], mm = m[o + i], vv = v[o + i];
+    adam_one(pp, g[o + i], mm, vv, step_size, bc2_sqrt, a.omb1, a.b2, a.omb2, a.eps);
+    j.p[e + i] = pp;
+    m[o + i] = mm;
+    v[o + i] = vv;
+  }
+}
+
 // y[m][:] = x[m][:] + x2[m % mod][:] over rows of 256 (mod == 0: x2 has one row per row of x): src + pos, tgt + query_pos
 __global__ __launch_bounds__(256) void add_rowmod_kernel(const float* __restrict__ x, const float* __restrict__ x2, int mod,
                                                          float* __restrict__ y, int rows) {
@@ -704,6 +767,24 @@ int train_reduce_jobs(const TrainReduceJob* jobs, const TrainReduceSrc* srcs, co
                       hipStream_t s) {
   if (njobs <= 0 || nchunks <= 0) return 0;
   hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, jobs, srcs, chunk_job);
+  return LAUNCH_OK();
+}
+
+int train_adam(const TrainAdamJob* jobs, const unsigned* chunk_job, int nchunks, const float* g, float* m, float* v, const float* lr,
+               int ngroups, double b1, double b2, double eps, double bc1, double bc2_sqrt, const float* step_ptr, hipStream_t s) {
+  if (nchunks <= 0) return 0;
+  if (ngroups < 1 || ngroups > 8 || lr == nullptr) return -1;
+  AdamArgs a;
+  for (int i = 0; i < 8; ++i) a.lr[i] = i < ngroups ? lr[i] : 0.f;
+  a.b1 = (float)b1;
+  a.b2 = (float)b2;
+  a.eps = (float)eps;
+  a.omb1 = (float)(1.0 - b1);
+  a.omb2 = (float)(1.0 - b2);
+  a.bc1 = (float)bc1;
+  a.bc2_sqrt = (float)bc2_sqrt;
+  a.step_ptr = step_ptr;
+  hipLaunchKernelGGL(adam_jobs_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, jobs, chunk_job, g, m, v, a);
   return LAUNCH_OK();
 }
 

@@ -145,6 +145,7 @@ class GradSink:
             assert p.is_leaf and p.dtype == torch.float32 and p.device == dev and p.is_contiguous()
             offs.append(total)
             total += (p.numel() + 63) // 64 * 64                       # every gradient starts on a 256-byte boundary
+        self.offsets = offs
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         for p, o in zip(params, offs):
             p.grad = self.flat[o:o + p.numel()].view_as(p)

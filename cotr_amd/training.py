@@ -26,8 +26,10 @@ Semantics follow the reference line by line: ``COTR.forward`` (COTR/models/cotr_
 trainer / ``torch.optim.Adam(optim_list)`` (train_cotr.py:49-57) also run unchanged on this model.  Dropout masks come from a
 counter-based generator of our own (not torch's stream): same distribution, different draws.
 """
+import ctypes
 import math
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -514,9 +516,112 @@ class GraphedTrainStep:
 
 def grad_sink_for(optim):
     """A ``train_ops.GradSink`` over the optimiser's parameters: their gradients become views of one flat buffer and a backward
-    pass finishes all of them with one reduction launch (``train_batch(..., sink=...)``)."""
+    pass finishes all of them with one reduction launch (``train_batch(..., sink=...)``).  A ``FusedAdam`` owns one already."""
     from . import train_ops as T
+    own = getattr(optim, 'sink', None)
+    if own is not None:
+        return own
     return T.GradSink([p for g in optim.param_groups for p in g['params']])
+
+
+class FusedAdam(torch.optim.Adam):
+    """``torch.optim.Adam`` (train_cotr.py:49-57) whose step is ONE kernel launch (``cotr_train_adam``) over every trainable
+    parameter: the gradients are the flat buffer of a ``GradSink`` (``self.sink`` - pass it to ``train_batch``), exp_avg /
+    exp_avg_sq are flat buffers of the same layout.  Same update as torch's (multi-tensor) Adam up to the rounding of fused
+    multiply-adds (tests/test_training_gpu.py: 1e-6 of the weights' scale over ten steps); torch's own step is ~15 multi-tensor launches that each stream
+    the state (0.57 ms per stage-1 step, 0.73 ms per stage-2 step).  ``state_dict()`` / ``load_state_dict()`` have torch's layout
+    (per parameter ``step``, ``exp_avg``, ``exp_avg_sq``), so optimiser checkpoints are interchangeable with the reference's.
+    ``zero_grad()`` zeroes the flat buffer (the gradients stay views of it); a step with a gradient that is not the sink's view
+    raises."""
+
+    def __init__(self, groups, capturable=False, **kw):
+        from . import train_ops as T
+        super().__init__(groups, capturable=capturable, foreach=None, **kw)
+        for g in self.param_groups:
+            assert not g['amsgrad'] and g['weight_decay'] == 0 and not g['maximize'], 'FusedAdam covers the recipe of train_cotr.py only'
+        assert len(self.param_groups) <= 8
+        self.sink = T.GradSink([p for g in self.param_groups for p in g['params']])
+        flat = self.sink.flat
+        self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self._capturable = bool(capturable)
+        # ONE step count for all parameters, where torch keeps it: on the device for capturable steps, on the host otherwise
+        self._step = torch.zeros((), dtype=torch.float32, device=flat.device if capturable else 'cpu')
+        self._adopt_state()
+        # job table: one record per parameter, one workgroup per 1024 elements
+        group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g['params']}
+        dt = np.dtype([('p', '<u8'), ('off', '<u8'), ('numel', '<u4'), ('chunk0', '<u4'), ('group', '<u4'), ('vec', '<u4')])
+        jobs = np.zeros(len(self.sink.params), dtype=dt)
+        chunk = 0
+        for i, (p, off) in enumerate(zip(self.sink.params, self.sink.offsets)):
+            jobs[i] = (p.data_ptr(), off, p.numel(), chunk, group_of[id(p)], int(p.data_ptr() % 16 == 0))
+            chunk += (p.numel() + 1023) // 1024
+        cmap = T.GradSink.chunk_map(jobs, chunk)
+        self._nchunks = chunk
+        self._ptrs = [p.data_ptr() for p in self.sink.params]
+        self._jobs = torch.from_numpy(jobs.view(np.uint8).copy()).to(flat.device)
+        self._cmap = torch.from_numpy(cmap.view(np.uint8).copy()).to(flat.device)
+
+    def _adopt_state(self, loaded=None):
+        """state[p] = torch's entries as views of the flat buffers (``loaded``: a state just read by load_state_dict - copied in)."""
+        steps = set()
+        for p, off in zip(self.sink.params, self.sink.offsets):
+            m = self._m[off:off + p.numel()].view_as(p)
+            v = self._v[off:off + p.numel()].view_as(p)
+            st = None if loaded is None else loaded.get(p)
+            if st:
+                m.copy_(st['exp_avg'])
+                v.copy_(st['exp_avg_sq'])
+                steps.add(int(float(st['step'])))
+            elif loaded is not None:
+                m.zero_()
+                v.zero_()
+            self.state[p] = {'step': self._step, 'exp_avg': m, 'exp_avg_sq': v}
+        if loaded is not None:
+            assert len(steps) <= 1, 'FusedAdam keeps one step count for all parameters'
+            self._step.fill_(float(steps.pop() if steps else 0))
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        loaded = {p: dict(self.state[p]) for p in self.sink.params if p in self.state and 'exp_avg' in self.state[p]}
+        self._adopt_state(loaded)
+
+    def zero_grad(self, set_to_none=True):
+        self.sink.attach()
+        self.sink.zero()
+
+    def _check(self):
+        lo = self.sink.flat.data_ptr()
+        for p, off, ptr in zip(self.sink.params, self.sink.offsets, self._ptrs):
+            if p.grad is None or p.grad.data_ptr() != lo + off * 4:
+                raise RuntimeError('FusedAdam: a gradient is not the view of the flat buffer (use optim.zero_grad() / sink.zero(), '
+                                   'not p.grad = None)')
+            if p.data_ptr() != ptr:
+                raise RuntimeError('FusedAdam: a parameter was re-allocated after the optimiser was built')
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        self._check()
+        from . import train_ops as T
+        lib = _lib.load_library()
+        g0 = self.param_groups[0]
+        b1, b2 = g0['betas']
+        assert all(g['betas'] == g0['betas'] and g['eps'] == g0['eps'] for g in self.param_groups)
+        lrs = (ctypes.c_float * len(self.param_groups))(*[float(g['lr']) for g in self.param_groups])
+        self._step += 1
+        if self._capturable:                    # the host does not know the step count of a replayed graph
+            bc1, bc2s, step_ptr = 1.0, 1.0, ctypes.c_void_p(self._step.data_ptr())
+        else:
+            t = int(self._step.item())          # (a host tensor: no synchronisation)
+            bc1, bc2s, step_ptr = 1.0 - b1 ** t, (1.0 - b2 ** t) ** 0.5, None
+        with T._on(self.sink.flat.device):
+            T._chk(lib.cotr_train_adam(ctypes.c_void_p(self._jobs.data_ptr()), ctypes.c_void_p(self._cmap.data_ptr()), self._nchunks,
+                                       ctypes.c_void_p(self.sink.flat.data_ptr()), ctypes.c_void_p(self._m.data_ptr()),
+                                       ctypes.c_void_p(self._v.data_ptr()), lrs, len(self.param_groups), float(b1), float(b2),
+                                       float(g0['eps']), bc1, bc2s, step_ptr, T._sp()), 'cotr_train_adam')
+        # the kernel wrote the weights through raw pointers: their Python version counters did not move, so drop what is keyed by them
+        T.clear_weight_cache()
+        return None
 
 
 def train_batch(model, optim, img, query, target, cycle_consis=True, bidirectional=True, group=None, sink=None):
@@ -535,6 +640,8 @@ def train_batch(model, optim, img, query, target, cycle_consis=True, bidirection
     import torch.distributed as dist
     assert model.training
     distributed = group is not None or (dist.is_available() and dist.is_initialized())
+    if sink is None:
+        sink = getattr(optim, 'sink', None)              # a FusedAdam brings its own
     if sink is not None:
         sink.attach()
         sink.zero()
@@ -572,7 +679,7 @@ def sync_gradients(params, group=None, bucket_elems=1 << 25):
     sync_gradients_sharded(params, group, bucket_elems)
 
 
-def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0, capturable=False):
+def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0, capturable=False, fused=False):
     """``torch.optim.Adam(optim_list)`` of train_cotr.py:49-57 - group for group, including the EMPTY ``query_proj``
     group (the encoding has no parameters), so that ``optim_state_dict`` of a reference checkpoint loads here and the
     other way round (Adam requires the same number of param groups)."""
@@ -582,6 +689,8 @@ def optimizer_for(model, learning_rate=1e-4, lr_backbone=0.0, capturable=False):
               {'params': list(model.input_proj.parameters()), 'lr': learning_rate}]
     if lr_backbone > 0:
         groups.append({'params': list(model.backbone.parameters()), 'lr': lr_backbone})
+    if fused:       # same groups, same state dict; the step is one kernel launch on the GradSink's flat buffers (optim.sink)
+        return FusedAdam(groups, capturable=capturable)
     return torch.optim.Adam(groups, capturable=capturable)
 
 

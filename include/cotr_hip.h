@@ -242,6 +242,21 @@ typedef struct cotr_reduce_job {
 int cotr_train_gemm_tn_parts(const float* A, const float* B, float* part, int M, int N, int K, int with_colsum, cotr_stream stream);
 int cotr_train_reduce_jobs(const cotr_reduce_job* jobs, const cotr_reduce_src* srcs, const unsigned* chunk_job, int njobs, int nchunks,
                            cotr_stream stream);
+/* torch.optim.Adam's update (train_cotr.py:49-57: betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad) over EVERY trainable
+ * parameter in one launch, on flat gradient / exp_avg / exp_avg_sq buffers of one layout (cotr_amd/training.py: FusedAdam on the
+ * GradSink's buffer):  m += (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;  p -= lr[group] / bc1 * m / (sqrt(v) / bc2_sqrt + eps).
+ * jobs / chunk_job (device memory): one job per parameter, one workgroup per 1024 elements, as for cotr_train_reduce_jobs; lr = HOST
+ * array of ngroups <= 8 rates.  step == NULL: bias_correction1 = 1 - b1^t and bias_correction2_sqrt = sqrt(1 - b2^t) as given
+ * (torch computes them on the host in double precision); step != NULL: *step (device, float) = t, corrections computed in the kernel
+ * (captured steps). */
+typedef struct cotr_adam_job {
+  float* p;
+  unsigned long long off;
+  unsigned numel, chunk0, group, vec;
+} cotr_adam_job;
+int cotr_train_adam(const cotr_adam_job* jobs, const unsigned* chunk_job, int nchunks, const float* g, float* m, float* v, const float* lr,
+                    int ngroups, double beta1, double beta2, double eps, double bias_correction1, double bias_correction2_sqrt,
+                    const float* step, cotr_stream stream);
 /* last corr_embed layer 256 -> 2 (position_encoding.py:23-26): y [nb][nq][2]; backward: dh [rows][256], dwb [514] = dW2 | db2 */
 int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream);
 int cotr_train_head_bwd_parts(int rows);
