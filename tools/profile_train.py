@@ -1,4 +1,4 @@
-"""torch.profiler table of training steps: python tools/profile_train.py [stage=1|2] [Q=200] [sink=0|1]. GPU box."""
+"""torch.profiler table of training steps: python tools/profile_train.py [stage=1|2] [Q=200] [sink=0|1|2 (2 = GradSink + FusedAdam)]. GPU box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,8 +11,9 @@ STAGE = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 B, Q = 16, (int(sys.argv[2]) if len(sys.argv) > 2 else 200)
 LRB = 1e-5 if STAGE == 2 else 0.0
 m = build_model(cotr_amd.default_args(dropout=0.1, lr_backbone=LRB)).cuda(); m.load_state_dict(synth_state_dict(0)); m.train()
-opt = training.optimizer_for(m, 1e-4, LRB)
-SINK = training.grad_sink_for(opt) if (len(sys.argv) > 3 and sys.argv[3] == '1') else None
+MODE = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+opt = training.optimizer_for(m, 1e-4, LRB, fused=(MODE == 2))
+SINK = training.grad_sink_for(opt) if MODE else None
 g = torch.Generator().manual_seed(0)
 img = torch.randn(B, 3, 256, 512, generator=g).cuda()
 q, t = torch.rand(B, Q, 2, generator=g).cuda(), torch.rand(B, Q, 2, generator=g).cuda()

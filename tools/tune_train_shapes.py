@@ -1,5 +1,5 @@
 """GEMM shapes of one training step (forward + dX GEMMs of cotr_amd/train_ops.py), the configuration the library picks for each
-and the best one measured: candidates for gemm_tuned.inc.   python tools/tune_train_shapes.py   (GPU box)"""
+and the best one measured: candidates for gemm_tuned.inc.   python tools/tune_train_shapes.py [stage=1|2]   (GPU box)"""
 import collections
 import ctypes
 import os
@@ -13,10 +13,12 @@ from cotr_amd.utils.synth import synth_state_dict
 
 lib = _lib.load_library()
 B, Q = 16, 200   # bench.py --workload train: BASELINE.json configs[4]
-m = build_model(cotr_amd.default_args()).cuda()
+STAGE = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+LRB = 1e-5 if STAGE == 2 else 0.0
+m = build_model(cotr_amd.default_args(lr_backbone=LRB)).cuda()
 m.load_state_dict(synth_state_dict(0))
 m.train()
-opt = training.optimizer_for(m)
+opt = training.optimizer_for(m, 1e-4, LRB)
 g = torch.Generator().manual_seed(0)
 img = torch.randn(B, 3, 256, 512, generator=g).cuda()
 q, t = torch.rand(B, Q, 2, generator=g).cuda(), torch.rand(B, Q, 2, generator=g).cuda()
