@@ -423,12 +423,22 @@ class Proj(torch.autograd.Function):
                 dbs.append(dbi)
             elif need_b:
                 dbs.append(colsum(dy, _empty((hi - lo,), dy)))
-        assert [lo for lo, _ in ctx.ranges] == [0] + [hi for _, hi in ctx.ranges[:-1]] and ctx.ranges[-1][1] == w.shape[0], \
-            'the slices must tile the weight in order'
         if gw is not None:
             return (None, None, None, None, None, *dxs)
-        dw = (dws[0] if n == 1 else torch.cat(dws, dim=0)) if need_w else None
-        db = (dbs[0] if n == 1 else torch.cat(dbs, dim=0)) if need_b else None
+        tiles = [lo for lo, _ in ctx.ranges] == [0] + [hi for _, hi in ctx.ranges[:-1]] and ctx.ranges[-1][1] == w.shape[0]
+        if tiles:
+            dw = (dws[0] if n == 1 else torch.cat(dws, dim=0)) if need_w else None
+            db = (dbs[0] if n == 1 else torch.cat(dbs, dim=0)) if need_b else None
+        else:       # some rows of the weight are used elsewhere (the decoder's k / v rows: ProjKV): zero gradient from here
+            dw = db = None
+            if need_w:
+                dw = torch.zeros_like(w)
+                for (lo, hi), dwi in zip(ctx.ranges, dws):
+                    dw[lo:hi] = dwi
+            if need_b:
+                db = torch.zeros_like(ctx.bias)
+                for (lo, hi), dbi in zip(ctx.ranges, dbs):
+                    db[lo:hi] = dbi
         return (dw, db, None, None, None, *dxs)
 
 
@@ -497,6 +507,120 @@ class AddDropLN(torch.autograd.Function):
         return (ds if ctx.has_x else None), (ds if da is None else da), dwb[:256], dwb[256:], None
 
 
+def _rows_view(t):
+    """``t`` [rows, 256] usable by the attention kernels in place: unit column stride, 16-byte aligned rows; else a contiguous copy."""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.stride(0) >= t.shape[1] and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
+
+
+class ProjKV(torch.autograd.Function):
+    """The k and v projections of ALL decoder layers (rows d:2d and 2d:3d of each layer's packed in_proj, transformer.py:192-195
+    with k = memory + pos, v = memory) for all rows of ``memory`` - both passes of a training step - as TWO GEMMs
+    [rows, 256] x [L*256, 256]^T instead of 2 L per pass: the projections do not depend on the queries (the inference path hoists
+    them into the encode step the same way, csrc/api.hip).  Backward: two K = L*256 deep GEMMs give d(memory + pos) and d(memory)
+    (instead of 4 L small ones and as many gradient additions), two transpose-free gemm_tn passes give the weight / bias gradients
+    of all layers.  -> (K_all, V_all), each [rows, L*256]; layer l's block is columns l*256:(l+1)*256 (ColBlocks)."""
+
+    @staticmethod
+    def forward(ctx, mem_pos, memory, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        d = ws[0].shape[1]
+        mem_pos, memory = mem_pos.contiguous(), memory.contiguous()
+        with torch.no_grad():
+            wk = torch.cat([w.detach()[d:2 * d] for w in ws], dim=0)
+            wv = torch.cat([w.detach()[2 * d:3 * d] for w in ws], dim=0)
+            bk = torch.cat([b.detach()[d:2 * d] for b in bs], dim=0)
+            bv = torch.cat([b.detach()[2 * d:3 * d] for b in bs], dim=0)
+        k_all, v_all = gemm(mem_pos, wk, bk), gemm(memory, wv, bv)
+        ctx.params, ctx.d = (ws, bs), d
+        ctx.save_for_backward(mem_pos, memory, wk, wv)
+        return k_all, v_all
+
+    @staticmethod
+    def backward(ctx, dk_all, dv_all):
+        lib = _lib.load_library()
+        mem_pos, memory, wk, wv = ctx.saved_tensors
+        ws, bs = ctx.params
+        d, nl = ctx.d, len(ws)
+        need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_w = any(ctx.needs_input_grad[2:])
+        sink = _sink
+        gws = gbs = None
+        if sink is not None and need_w:
+            gws, gbs = [sink.grad_of(w) for w in ws], [sink.grad_of(b) for b in bs]
+            if any(g is None for g in gws + gbs):
+                gws = gbs = None
+        dxs, grads = [], [None] * (2 * nl)
+        for which, (dy, x, w_all, need) in enumerate(((dk_all, mem_pos, wk, need_x[0]), (dv_all, memory, wv, need_x[1]))):
+            dy = dy.contiguous()
+            dx = None
+            if need:
+                wt = _empty((d, nl * d), w_all)
+                with _on(dy.device):
+                    _chk(lib.cotr_train_transpose(_P(w_all), _P(wt), nl * d, d, _sp()), 'cotr_train_transpose')
+                dx = gemm(dy, wt)
+            dxs.append(dx)
+            if not need_w:
+                continue
+            lo = (1 + which) * d                                     # rows of the packed in_proj this pass owns
+            if gws is not None:
+                part, nparts, pstride = gemm_tn_parts(dy, x, with_colsum=True)
+                for l in range(nl):
+                    sink.add(gws[l][lo:lo + d], part, l * d * d, nparts, pstride, d * d)
+                    sink.add(gbs[l][lo:lo + d], part, nl * d * d + l * d, nparts, pstride, d)
+            else:
+                dw_all, db_all = gemm_tn(dy, x, with_colsum=True)
+                for l in range(nl):
+                    if grads[2 * l] is None:
+                        grads[2 * l], grads[2 * l + 1] = torch.zeros_like(ws[l]), torch.zeros_like(bs[l])
+                    grads[2 * l][lo:lo + d] = dw_all[l * d:(l + 1) * d]
+                    grads[2 * l + 1][lo:lo + d] = db_all[l * d:(l + 1) * d]
+        return (dxs[0], dxs[1], *grads)
+
+
+class ColBlocks(torch.autograd.Function):
+    """x [rows, cols] -> its row_blocks x col_blocks blocks as views (block (h, l) = rows h*R:(h+1)*R, columns l*C:(l+1)*C), in
+    (h, l) order.  Each view carries ``_grad_dst``, its block of ``gbuf``: a consumer that can write its gradient anywhere
+    (Attention.backward: dk / dv through a leading dimension) writes it THERE and returns that view, so the gradient of x is
+    assembled without a copy or an addition; a gradient that arrives elsewhere is copied in, a block nobody used is zeroed."""
+
+    @staticmethod
+    def forward(ctx, x, gbuf, row_blocks, col_blocks):
+        rows, cols = x.shape
+        assert gbuf.shape == x.shape and gbuf.is_contiguous() and x.is_contiguous() and rows % row_blocks == 0 and cols % col_blocks == 0
+        r, c = rows // row_blocks, cols // col_blocks
+        ctx.gbuf, ctx.blocks = gbuf, [(h * r, l * c, r, c) for h in range(row_blocks) for l in range(col_blocks)]
+        return tuple(x[r0:r0 + r, c0:c0 + c] for r0, c0, _, _ in ctx.blocks)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gbuf = ctx.gbuf
+        for (r0, c0, r, c), g in zip(ctx.blocks, grads):
+            dst = gbuf[r0:r0 + r, c0:c0 + c]
+            if g is None:
+                dst.zero_()
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)
+        return gbuf, None, None, None
+
+
+def col_blocks(x, row_blocks, col_blocks_):
+    """ColBlocks with the gradient destinations attached -> list over row blocks of lists over column blocks."""
+    gbuf = torch.empty_like(x)
+    outs = ColBlocks.apply(x, gbuf, row_blocks, col_blocks_)
+    r, c = x.shape[0] // row_blocks, x.shape[1] // col_blocks_
+    res = []
+    for h in range(row_blocks):
+        row = []
+        for l in range(col_blocks_):
+            o = outs[h * col_blocks_ + l]
+            o._grad_dst = gbuf[h * r:(h + 1) * r, l * c:(l + 1) * c]
+            row.append(o)
+        res.append(row)
+    return res
+
+
 class Attention(torch.autograd.Function):
     """o = dropout(softmax(q k^T * scale)) v per head - the core of nn.MultiheadAttention (transformer.py:149-153, 192-195).
     ``qk`` given: q and k are the two column halves of one [rows, 512] tensor (encoder self-attention: one projection launch
@@ -513,14 +637,19 @@ class Attention(torch.autograd.Function):
             q_t, k_t, ldq, ldk = qk, qk, 512, 512
             k_ptr = ctypes.c_void_p(qk.data_ptr() + 256 * 4)
         else:
-            q_t, k_t, ldq, ldk = q.contiguous(), k.contiguous(), 256, 256
+            # k / v may be column blocks of one wide projection output (ColBlocks: the decoder's K / V of all layers from one GEMM):
+            # the kernels take a leading dimension, so such a view is used in place
+            q_t, k_t, ldq = q.contiguous(), _rows_view(k), 256
+            ldk = k_t.stride(0)
             k_ptr = _P(k_t)
-        v = v.contiguous()
+        ctx.k_dst, ctx.v_dst = getattr(k, '_grad_dst', None), getattr(v, '_grad_dst', None)
+        v = _rows_view(v)
+        ldv = v.stride(0)
         rows = nb * nq
         o, lse = _empty((rows, 256), v), _empty((rows, 8), v)
         seed = next_seed() if p > 0 else 0
         with _on(v.device):
-            _chk(lib.cotr_train_attention_fwd(_P(q_t), ldq, k_ptr, ldk, _P(v), 256, _P(o), 256, _P(lse), nb, nq, float(scale),
+            _chk(lib.cotr_train_attention_fwd(_P(q_t), ldq, k_ptr, ldk, _P(v), ldv, _P(o), 256, _P(lse), nb, nq, float(scale),
                                               float(p), seed, _sp()), 'cotr_train_attention_fwd')
         ctx.meta = (packed, nb, nq, float(scale), float(p), seed)
         ctx.save_for_backward(q_t, k_t, v, o, lse)
@@ -534,18 +663,23 @@ class Attention(torch.autograd.Function):
         d_o = d_o.contiguous()
         rows = nb * nq
         delta = _empty((rows, 8), o)
-        dv = _empty((nb * 512, 256), o)
+        # (gradient destinations handed over by ColBlocks: dk / dv are written straight into their column block of the wide
+        # gradient buffer, nothing is copied or added afterwards)
+        dv = ctx.v_dst if ctx.v_dst is not None else _empty((nb * 512, 256), o)
+        lddv, ldv = dv.stride(0), v.stride(0)
         if packed:
             dqk = _empty((rows, 512), o)
             k_ptr = ctypes.c_void_p(k_t.data_ptr() + 256 * 4)
             dq_ptr, dk_ptr, ldq, ldk = _P(dqk), ctypes.c_void_p(dqk.data_ptr() + 256 * 4), 512, 512
+            lddq = lddk = 512
         else:
-            dq, dk = _empty((rows, 256), o), _empty((nb * 512, 256), o)
+            dq = _empty((rows, 256), o)
+            dk = ctx.k_dst if ctx.k_dst is not None else _empty((nb * 512, 256), o)
             k_ptr = _P(k_t)
-            dq_ptr, dk_ptr, ldq, ldk = _P(dq), _P(dk), 256, 256
+            dq_ptr, dk_ptr, ldq, ldk, lddq, lddk = _P(dq), _P(dk), 256, k_t.stride(0), 256, dk.stride(0)
         with _on(o.device):
-            _chk(lib.cotr_train_attention_bwd(_P(q_t), ldq, k_ptr, ldk, _P(v), 256, _P(o), _P(d_o), 256, _P(lse), _P(delta),
-                                              dq_ptr, ldq, dk_ptr, ldk, _P(dv), 256, nb, nq, scale, p, seed, _sp()),
+            _chk(lib.cotr_train_attention_bwd(_P(q_t), ldq, k_ptr, ldk, _P(v), ldv, _P(o), _P(d_o), 256, _P(lse), _P(delta),
+                                              dq_ptr, lddq, dk_ptr, lddk, _P(dv), lddv, nb, nq, scale, p, seed, _sp()),
                  'cotr_train_attention_bwd')
         if packed:
             return dqk, None, None, dv, None, None, None, None

@@ -275,23 +275,46 @@ def encode_train(model, features, b):
     return src, T.AddRows.apply(src, pos, TOK)
 
 
-def decode_train(model, memory, mem_pos, queries):
+HOIST_KV = True     # decoder k / v projections of all layers (and both passes) as two GEMMs (train_ops.ProjKV); False: per layer
+
+
+def decoder_kv_train(model, memory, mem_pos, passes=1):
+    """k / v of every decoder layer for all rows of ``memory`` [passes * B * 512, 256] (the rows of pass h are block h) from two
+    GEMMs (train_ops.ProjKV) -> list over passes of lists over layers of (k, v), each a [B*512, 256] column block (a view with
+    leading dimension 6*256 that the attention kernels read in place)."""
+    from . import train_ops as T
+    layers = model.transformer.decoder.layers
+    wb = []
+    for layer in layers:
+        wb += [layer.multihead_attn.in_proj_weight, layer.multihead_attn.in_proj_bias]
+    k_all, v_all = T.ProjKV.apply(mem_pos, memory, *wb)
+    kb, vb = T.col_blocks(k_all, passes, len(layers)), T.col_blocks(v_all, passes, len(layers))
+    return [[(kb[h][l], vb[h][l]) for l in range(len(layers))] for h in range(passes)]
+
+
+def decode_train(model, memory, mem_pos, queries, kv=None):
     """The 6 cross-attention decoder layers, decoder.norm and corr_embed (transformer.py:185-201,110-111, cotr_model.py:34-39)
     for ``queries`` [B,Q,2] against ``memory`` [B*512, 256] -> pred_corrs [B,Q,2].  The query encoding carries no gradient
     (``NerfPositionalEncoding.forward`` is ``@torch.no_grad()``, COTR/models/position_encoding.py:40-45): in the cycle pass
-    ``model(img, pred)`` nothing flows back through ``pred``."""
+    ``model(img, pred)`` nothing flows back through ``pred``.  ``kv``: this pass's entry of ``decoder_kv_train`` (then ``memory`` /
+    ``mem_pos`` are not read here)."""
     from . import train_ops as T
     tr = model.transformer
     nheads, d = tr.nhead, tr.d_model
     scale = float(d // nheads) ** -0.5
     b, nq, _ = queries.shape
     query_pos = _query_encoding(queries)                                                               # cotr_model.py:34-36
+    if kv is None and HOIST_KV:
+        kv = decoder_kv_train(model, memory, mem_pos, 1)[0]
     tgt = None                                                                                         # zeros, transformer.py:54
-    for layer in tr.decoder.layers:                                                                    # transformer.py:185-201
+    for li, layer in enumerate(tr.decoder.layers):                                                     # transformer.py:185-201
         p = float(layer.multihead_attn.dropout) if model.training else 0.0
         w, bias = layer.multihead_attn.in_proj_weight, layer.multihead_attn.in_proj_bias
         xq = query_pos if tgt is None else T.AddRows.apply(tgt, query_pos, 0)
-        q, k, v = T.Proj.apply(w, bias, ((0, d), (d, 2 * d), (2 * d, 3 * d)), False, 0.0, xq, mem_pos, memory)
+        if kv is not None:
+            (q,), (k, v) = T.Proj.apply(w, bias, ((0, d),), False, 0.0, xq), kv[li]
+        else:
+            q, k, v = T.Proj.apply(w, bias, ((0, d), (d, 2 * d), (2 * d, 3 * d)), False, 0.0, xq, mem_pos, memory)
         ao = T.Attention.apply(None, q, k, v, b, nq, scale, p)
         ao = T.linear(ao, layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias)
         tgt = T.AddDropLN.apply(tgt, ao, layer.norm2.weight, layer.norm2.bias, p)
@@ -393,14 +416,15 @@ def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=Tru
         feats2 = feat_fn(model, img_rev)
     memory, mem_pos = encode_train(model, torch.cat([feats, feats2], dim=0), 2 * b)
     rows = b * TOK
-    pred = decode_train(model, memory[:rows], mem_pos[:rows], query)
+    kv = decoder_kv_train(model, memory, mem_pos, 2) if HOIST_KV else (None, None)      # neither pass's k / v depends on its queries
+    pred = decode_train(model, memory[:rows], mem_pos[:rows], query, kv[0])
     loss = F.mse_loss(pred, target)
     if bidirectional:
-        cycle = decode_train(model, memory[rows:], mem_pos[rows:], pred)
+        cycle = decode_train(model, memory[rows:], mem_pos[rows:], pred, kv[1])
     else:
         q_rev = pred.clone()
         q_rev[..., 0] = q_rev[..., 0] - 0.5
-        cycle = decode_train(model, memory[rows:], mem_pos[rows:], q_rev)
+        cycle = decode_train(model, memory[rows:], mem_pos[rows:], q_rev, kv[1])
         cycle = torch.stack([cycle[..., 0] - 0.5, cycle[..., 1]], dim=-1)
     mask = torch.norm(cycle - query, dim=-1) < 10 / MAX_SIZE
     if branch_free:
