@@ -352,15 +352,345 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
   }
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------
+// dK, dV, second form (the one launched): workgroup = 128 keys x head x pair, each wavefront OWNS 32 keys and walks ALL query
+// tiles, so there is no cross-wavefront reduction at the end; the four wavefronts share every query tile - Q, dO, lse, delta of 32
+// queries go through LDS once per workgroup (global -> registers one tile ahead -> LDS, two buffers, ONE barrier per tile) instead
+// of once per wavefront from global memory.  Same products in the same order per (key, head dim) as the first form except that a
+// key's sum over the query tiles is now one running accumulation (first form: four partial sums, one per wavefront, added at the end).
+//   encoder 32 pairs x 512 queries: 1024 workgroups x 16 tiles;  decoder 16 x 200: 512 workgroups x 7 tiles (the first form gave a
+//   wavefront 1-2 tiles and then reduced through LDS).
+// -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                            int ldk, const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
+                                                            int ldo, const float* __restrict__ lse, const float* __restrict__ delta,
+                                                            float* __restrict__ dk, int lddk, float* __restrict__ dv, int lddv, int nq,
+                                                            float qscale, uint32_t thresh, float inv_keep, uint32_t seed,
+                                                            const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
+  constexpr int TS = 36;                                          // padded tile row (floats)
+  __shared__ __attribute__((aligned(16))) float q_s[2][32][TS];   // raw q rows of the tile, this head's 32 columns
+  __shared__ __attribute__((aligned(16))) float do_s[2][32][TS];
+  __shared__ float ld_s[2][2][32];                                // lse | delta of the tile's queries
+  __shared__ __attribute__((aligned(16))) float out_s[4][32][TS]; // per wavefront: D tile -> rows of dk / dv
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.x >> 2, kgroup = blockIdx.x & 3;
+  const int pair = blockIdx.z;
+  const int key0 = kgroup * 128 + wave * 32;
+  const int kj = key0 + l31;
+  const size_t krow = (size_t)pair * ATT_KEYS + kj;
+  f32x4 kfb[4], vfb[4];                                          // B operands: lane = key
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    kfb[j] = *reinterpret_cast<const f32x4*>(k + krow * ldk + head * ATT_HD + j * 8 + hh * 4);
+    vfb[j] = *reinterpret_cast<const f32x4*>(v + krow * ldv + head * ATT_HD + j * 8 + hh * 4);
+  }
+  f32x16 dkacc, dvacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dkacc[r] = dvacc[r] = 0.f;
+  const int nqb = (nq + 31) / 32;
+  // tile staging: thread -> (row t >> 3, 4 columns (t & 7) * 4) of Q and dO; threads 0-31 lse, 32-63 delta
+  const int srow = t >> 3, sc4 = (t & 7) * 4;
+  f32x4 pq, pdo;
+  float pld = 0.f;
+  auto fetch = [&](int qb) {
+    const int qa = qb * 32 + srow;
+    const size_t row = (size_t)pair * nq + (qa < nq ? qa : 0);
+    pq = *reinterpret_cast<const f32x4*>(q + row * ldq + head * ATT_HD + sc4);
+    pdo = *reinterpret_cast<const f32x4*>(d_o + row * ldo + head * ATT_HD + sc4);
+    if (t < 64) {
+      const int ql = qb * 32 + l31;
+      const size_t r2 = (size_t)pair * nq + (ql < nq ? ql : 0);
+      pld = (hh == 0 ? lse : delta)[r2 * 8 + head];
+    }
+  };
+  auto stash = [&](int buf) {
+    *reinterpret_cast<f32x4*>(&q_s[buf][srow][sc4]) = pq;
+    *reinterpret_cast<f32x4*>(&do_s[buf][srow][sc4]) = pdo;
+    if (t < 64) ld_s[buf][hh][l31] = pld;
+  };
+  fetch(0);
+  stash(0);
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int buf = qb & 1;
+    __syncthreads();                                             // tile qb is in q_s[buf]; everybody is done with the other buffer
+    if (qb + 1 < nqb) fetch(qb + 1);                             // (global loads in flight under this tile's products)
+    f32x4 qaf[4], doaf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qaf[j] = *reinterpret_cast<const f32x4*>(&q_s[buf][l31][j * 8 + hh * 4]);
+      qaf[j] *= qscale * LOG2E;
+      doaf[j] = *reinterpret_cast<const f32x4*>(&do_s[buf][l31][j * 8 + hh * 4]);
+    }
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qaf[j][e], kfb[j][e], s, 0, 0, 0);     // S[q][key], lane = key
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(doaf[j][e], vfb[j][e], dp, 0, 0, 0);  // dP~[q][key]
+      }
+    f32x16 pt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;            // row of D register r: query qb*32 + ql
+      const int qr = qb * 32 + ql;
+      const bool ok = qr < nq;
+      const float p = ok ? __builtin_amdgcn_exp2f(s[r] - ld_s[buf][0][ql]) : 0.f;
+      float keep = 1.f;
+      if (thresh != 0) keep = train_keep(seed, mask_index(pair, head, nq, ok ? qr : 0, kj), thresh) ? inv_keep : 0.f;
+      pt[r] = p * keep;                                          // P~[q][key]
+      s[r] = p * (dp[r] * keep - ld_s[buf][1][ql]);              // dS[q][key]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float dot = do_s[buf][ql][l31];                      // A operand of dV^T = dO^T P~: lane = head dim
+      const float qt = q_s[buf][ql][l31] * qscale;               // A operand of dK^T = Q^T dS
+      dvacc = __builtin_amdgcn_mfma_f32_32x32x2f32(dot, pt[r], dvacc, 0, 0, 0);
+      dkacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qt, s[r], dkacc, 0, 0, 0);
+    }
+    if (qb + 1 < nqb) stash(buf ^ 1);
+  }
+  // D rows = head dim, column (lane & 31) = key: through this wavefront's LDS tile to rows of dk, then of dv
+  const size_t orow = (size_t)pair * ATT_KEYS + key0 + (lane >> 1);
+  const int oc = (lane & 1) * 16;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out_s[wave][l31][(r & 3) + 8 * (r >> 2) + 4 * hh] = which == 0 ? dkacc[r] : dvacc[r];
+    __builtin_amdgcn_wave_barrier();
+    float* dst = (which == 0 ? dk + orow * lddk : dv + orow * lddv) + head * ATT_HD + oc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(dst + i * 4) = *reinterpret_cast<const f32x4*>(&out_s[wave][lane >> 1][oc + i * 4]);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
+// -------------------------------------------------------------------------------------------------------------------
+// Forward and dQ, second form: workgroup = 4 query tiles x head x pair, each wavefront OWNS 32 queries and walks all 16 key tiles
+// (no cross-wavefront combine of partial softmaxes / partial dQ at the end); the K and V tiles are shared by the four wavefronts
+// through LDS (global -> registers one tile ahead -> LDS, two buffers, one barrier per tile).  A wavefront whose tile lies past
+// nq only helps with the staging.
+// -------------------------------------------------------------------------------------------------------------------
+struct KvStage {
+  static constexpr int TS = 36;
+  f32x4 pk, pv;
+  __device__ __forceinline__ void fetch(const float* k, int ldk, const float* v, int ldv, size_t row0, int head, int t) {
+    const size_t row = row0 + (t >> 3);
+    pk = *reinterpret_cast<const f32x4*>(k + row * ldk + head * ATT_HD + (t & 7) * 4);
+    pv = *reinterpret_cast<const f32x4*>(v + row * ldv + head * ATT_HD + (t & 7) * 4);
+  }
+  __device__ __forceinline__ void stash(float (*ks)[TS], float (*vs)[TS], int t) const {
+    *reinterpret_cast<f32x4*>(&ks[t >> 3][(t & 7) * 4]) = pk;
+    *reinterpret_cast<f32x4*>(&vs[t >> 3][(t & 7) * 4]) = pv;
+  }
+};
+
+__global__ __launch_bounds__(256) void attn_train_fwd2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                              int ldk, const float* __restrict__ v, int ldv, float* __restrict__ o,
+                                                              int ldo, float* __restrict__ lse, int nq, int qgroups, float qscale,
+                                                              uint32_t thresh, float inv_keep, uint32_t seed,
+                                                              const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
+  constexpr int TS = KvStage::TS;
+  __shared__ __attribute__((aligned(16))) float k_s[2][32][TS];
+  __shared__ __attribute__((aligned(16))) float v_s[2][32][TS];
+  __shared__ __attribute__((aligned(16))) float out_s[4][32][TS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.x / qgroups, qtile = (blockIdx.x % qgroups) * 4 + wave;
+  const int pair = blockIdx.z;
+  const bool active = qtile * 32 < nq;                           // (wave-uniform)
+  const int qi = qtile * 32 + l31;
+  const bool q_ok = qi < nq;
+  const size_t qrow = (size_t)pair * nq + (q_ok ? qi : 0);
+  f32x4 qf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    qf[j] = *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4);
+    qf[j] *= qscale * LOG2E;
+  }
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const size_t key_row0 = (size_t)pair * ATT_KEYS;
+  KvStage st;
+  st.fetch(k, ldk, v, ldv, key_row0, head, t);
+  st.stash(k_s[0], v_s[0], t);
+  constexpr int NKB = ATT_KEYS / 32;
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int buf = kb & 1;
+    __syncthreads();
+    if (kb + 1 < NKB) st.fetch(k, ldk, v, ldv, key_row0 + (kb + 1) * 32, head, t);
+    if (active) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(&k_s[buf][l31][j * 8 + hh * 4]);      // A operand of S^T: lane = key
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[j][e], s, 0, 0, 0);
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+        psum += s[r];                                   // the normaliser sums the UN-dropped probabilities
+      }
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+      if (thresh != 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          s[r] = train_keep(seed, mask_index(pair, head, nq, q_ok ? qi : 0, key), thresh) ? s[r] * inv_keep : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float vf = v_s[buf][(r & 3) + 8 * (r >> 2) + 4 * hh][l31];      // A operand of O^T = V^T P^T: lane = head dim
+        oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], oacc, 0, 0, 0);
+      }
+    }
+    if (kb + 1 < NKB) st.stash(k_s[buf ^ 1], v_s[buf ^ 1], t);
+  }
+  if (!active) return;
+  l_run += __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_run;
+  // D rows = head dim, column (lane & 31) = query: through this wavefront's LDS tile to rows of o
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out_s[wave][l31][(r & 3) + 8 * (r >> 2) + 4 * hh] = oacc[r] * inv;
+  if (hh == 0 && q_ok) lse[qrow * 8 + head] = m_run + __builtin_amdgcn_logf(l_run);   // v_log_f32 = log2
+  __builtin_amdgcn_wave_barrier();
+  const int orow = qtile * 32 + (lane >> 1), oc = (lane & 1) * 16;
+  if (orow < nq) {
+    float* dst = o + ((size_t)pair * nq + orow) * ldo + head * ATT_HD + oc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(dst + i * 4) = *reinterpret_cast<const f32x4*>(&out_s[wave][lane >> 1][oc + i * 4]);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                           const float* __restrict__ v, int ldv, const float* __restrict__ d_o, int ldo,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           float* __restrict__ dq, int lddq, int nq, int qgroups, float qscale,
+                                                           uint32_t thresh, float inv_keep, uint32_t seed,
+                                                           const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
+  constexpr int TS = KvStage::TS;
+  __shared__ __attribute__((aligned(16))) float k_s[2][32][TS];
+  __shared__ __attribute__((aligned(16))) float v_s[2][32][TS];
+  __shared__ __attribute__((aligned(16))) float out_s[4][32][TS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.x / qgroups, qtile = (blockIdx.x % qgroups) * 4 + wave;
+  const int pair = blockIdx.z;
+  const bool active = qtile * 32 < nq;
+  const int qi = qtile * 32 + l31;
+  const bool q_ok = qi < nq;
+  const size_t qrow = (size_t)pair * nq + (q_ok ? qi : 0);
+  f32x4 qf[4], dof[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    qf[j] = *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4);
+    qf[j] *= qscale * LOG2E;
+    dof[j] = *reinterpret_cast<const f32x4*>(d_o + qrow * ldo + head * ATT_HD + j * 8 + hh * 4);
+  }
+  const float lse_q = lse[qrow * 8 + head], delta_q = delta[qrow * 8 + head];
+  f32x16 dqacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
+  const size_t key_row0 = (size_t)pair * ATT_KEYS;
+  KvStage st;
+  st.fetch(k, ldk, v, ldv, key_row0, head, t);
+  st.stash(k_s[0], v_s[0], t);
+  constexpr int NKB = ATT_KEYS / 32;
+  for (int kb = 0; kb < NKB; ++kb) {
+    const int buf = kb & 1;
+    __syncthreads();
+    if (kb + 1 < NKB) st.fetch(k, ldk, v, ldv, key_row0 + (kb + 1) * 32, head, t);
+    if (active) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(&k_s[buf][l31][j * 8 + hh * 4]);      // A operand of S^T: lane = key
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(&v_s[buf][l31][j * 8 + hh * 4]);      // A operand of dP^T = V dO^T
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[j][e], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], dof[j][e], dp, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[r] - lse_q);
+        float g = dp[r];
+        if (thresh != 0) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          g = train_keep(seed, mask_index(pair, head, nq, q_ok ? qi : 0, key), thresh) ? g * inv_keep : 0.f;
+        }
+        s[r] = q_ok ? p * (g - delta_q) : 0.f;          // dS[q][key]
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float ktf = k_s[buf][(r & 3) + 8 * (r >> 2) + 4 * hh][l31];     // A operand of dQ^T = K^T dS^T: lane = head dim
+        dqacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ktf, s[r], dqacc, 0, 0, 0);
+      }
+    }
+    if (kb + 1 < NKB) st.stash(k_s[buf ^ 1], v_s[buf ^ 1], t);
+  }
+  if (!active) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out_s[wave][l31][(r & 3) + 8 * (r >> 2) + 4 * hh] = dqacc[r] * qscale;   // q_eff = q * qscale
+  __builtin_amdgcn_wave_barrier();
+  const int orow = qtile * 32 + (lane >> 1), oc = (lane & 1) * 16;
+  if (orow < nq) {
+    float* dst = dq + ((size_t)pair * nq + orow) * lddq + head * ATT_HD + oc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(dst + i * 4) = *reinterpret_cast<const f32x4*>(&out_s[wave][lane >> 1][oc + i * 4]);
+  }
+}
+
 }  // namespace
+
+static int g_attn_bwd_form = 2;   // 1: first form of the three kernels (kept for A/B and as a cross-check), 2: a wavefront owns its keys / queries
+void train_set_attn_bwd_form(int v) { g_attn_bwd_form = v == 1 ? 1 : 2; }
+int train_get_attn_bwd_form() { return g_attn_bwd_form; }
 
 int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
                         int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s) {
   if (nb <= 0 || nq <= 0) return 0;
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return -1;
-  dim3 grid(((nq + 31) / 32) * 8, 1, nb);
-  hipLaunchKernelGGL(attn_train_fwd_kernel, grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, lse, nq, qscale, train_thresh(p),
-                     p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
+  if (g_attn_bwd_form == 1) {
+    dim3 grid(((nq + 31) / 32) * 8, 1, nb);
+    hipLaunchKernelGGL(attn_train_fwd_kernel, grid, dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, lse, nq, qscale, train_thresh(p),
+                       p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
+  } else {
+    const int qgroups = ((nq + 31) / 32 + 3) / 4;
+    hipLaunchKernelGGL(attn_train_fwd2_kernel, dim3(qgroups * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, lse, nq, qgroups,
+                       qscale, train_thresh(p), p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
+  }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -374,10 +704,20 @@ int train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const 
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, o, d_o, ldo, delta, rows);
   if (hipGetLastError() != hipSuccess) return -2;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((nq + 31) / 32) * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse,
-                     delta, dq, lddq, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
+  if (g_attn_bwd_form == 1)
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((nq + 31) / 32) * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse,
+                       delta, dq, lddq, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
+  else {
+    const int qgroups = ((nq + 31) / 32 + 3) / 4;
+    hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(qgroups * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dq,
+                       lddq, nq, qgroups, qscale, thresh, inv_keep, seed, train_salt_ptr());
+  }
   if (hipGetLastError() != hipSuccess) return -2;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(16 * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dk,
-                     lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
+  if (g_attn_bwd_form == 1)
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(16 * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dk,
+                       lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
+  else
+    hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3(4 * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dk,
+                       lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

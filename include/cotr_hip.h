@@ -377,6 +377,10 @@ int cotr_set_coop_tail(int enable);
 /* polls of the tile's arrival word before a workgroup leaves its share to the last arriver (default 4000, ~0.3 us each; 0 = never
  * wait: the last arriver finishes the whole tile - the schedule-independence test) */
 int cotr_set_coop_tail_spin(int polls);
+/* training attention forward + backward: 2 (default) = a wavefront owns its keys (dK / dV) or its queries (forward, dQ) and walks the other side's tiles,
+ * which the workgroup's four wavefronts share through LDS; 1 = the first form (wavefronts split the walk, partial sums reduced
+ * through LDS at the end) */
+int cotr_set_train_attention_form(int form);
 /* layer1's bottlenecks (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity / downsample, FrozenBN, ReLU: torchvision
  * Bottleneck.forward, COTR/models/backbone.py:46-56) run as ONE launch each (bottleneck.hip) for passes of up to this many pairs
  * (default 4: the latency-bound regime - at 8 pairs it is time-neutral, above that the halo recompute of conv1 loses; 0 = never):

@@ -104,9 +104,13 @@ def test_packed_in_projection_slices():
     assert torch.equal(torch.autograd.grad(yr, xr, db_.cuda())[0], db_.cuda())
 
 
-@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (2, 100, False), (1, 24, False), (3, 33, False)])
-def test_attention_forward_backward(nb, nq, packed):
-    """attn_train_fwd / attn_bwd_dq / attn_bwd_dkv (recompute-softmax backward) vs softmax attention under torch autograd."""
+@pytest.mark.parametrize('form', [2, 1])
+@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (2, 100, False), (1, 24, False), (3, 33, False), (2, 200, False)])
+def test_attention_forward_backward(nb, nq, packed, form):
+    """attn_train_fwd / attn_bwd_dq / attn_bwd_dkv (recompute-softmax backward) vs softmax attention under torch autograd; both
+    forms of the backward kernels (cotr_set_train_attention_form: 2 = the shipped one)."""
+    from cotr_amd import _lib
+    _lib.set_knob('train_attention_form', form)
     g = _g(nb * 1000 + nq)
     scale = 32 ** -0.5
     q = torch.randn(nb * nq, 256, generator=g) * 2
@@ -130,6 +134,31 @@ def test_attention_forward_backward(nb, nq, packed):
         dq, dk, dv = torch.autograd.grad(o, xs, d_o.cuda())
     assert _rel(o, o_ref) < 2e-5
     assert _rel(dq, gq) < 5e-5 and _rel(dk, gk) < 5e-5 and _rel(dv, gv) < 5e-5
+
+
+@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (3, 200, False), (1, 33, False)])
+def test_attention_backward_forms_agree_with_dropout(nb, nq, packed):
+    """Dropout on the probabilities (p = 0.1): the two forms of the backward kernels regenerate the same mask from (seed, element
+    index) and give the same dq / dk / dv up to summation order (the dropout path has no closed-form torch reference: the mask is
+    this library's own counter-based one; checked statistically below and by finite differences in test_training_gpu.py)."""
+    from cotr_amd import _lib
+    g = _g(nb * 77 + nq)
+    q, k, v = torch.randn(nb * nq, 256, generator=g), torch.randn(nb * 512, 256, generator=g), torch.randn(nb * 512, 256, generator=g)
+    d_o = torch.randn(nb * nq, 256, generator=g).cuda()
+    res = []
+    for form in (1, 2):
+        _lib.set_knob('train_attention_form', form)
+        T.reseed(99)
+        if packed:
+            qk, vv = _leaf(torch.cat([q, k], dim=1)), _leaf(v)
+            o = T.Attention.apply(qk, None, None, vv, nb, nq, 32 ** -0.5, 0.1)
+            res.append((o.detach(),) + torch.autograd.grad(o, [qk, vv], d_o))
+        else:
+            xs = [_leaf(q), _leaf(k), _leaf(v)]
+            o = T.Attention.apply(None, xs[0], xs[1], xs[2], nb, nq, 32 ** -0.5, 0.1)
+            res.append((o.detach(),) + torch.autograd.grad(o, xs, d_o))
+    for a, b in zip(res[0], res[1]):                             # output, then the gradients
+        assert _rel(b, a) < 2e-5
 
 
 def test_attention_dropout_statistics_and_determinism():
