@@ -1402,7 +1402,7 @@ int cotr_set_coop_tail_spin(int polls) {
 }
 
 int cotr_set_train_attention_form(int form) {
-  if (form != 1 && form != 2) return COTR_ERR_ARG;
+  if (form < 0 || form > 3) return COTR_ERR_ARG;
   train_set_attn_bwd_form(form);
   knob_record("train_attention_form", form);
   return COTR_OK;
@@ -1504,7 +1504,7 @@ Knob* knob_table(int* n) {
       {"bottleneck_max_pairs", cotr_set_bottleneck_max_pairs, 4, 4},
       {"coop_tail", cotr_set_coop_tail, 0, 0},
       {"coop_tail_spin", cotr_set_coop_tail_spin, 4000, 4000},
-      {"train_attention_form", cotr_set_train_attention_form, 2, 2},
+      {"train_attention_form", cotr_set_train_attention_form, 0, 0},
   };
   *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
   return knobs;

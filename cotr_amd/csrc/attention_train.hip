@@ -24,6 +24,42 @@ namespace {
 __device__ __forceinline__ uint64_t mask_index(int pair, int head, int nq, int qi, int key) {
   return (((uint64_t)(pair * 8 + head) * nq + qi) * ATT_KEYS + key);
 }
+// train_keep(seed, mask_index(pair, head, nq, qi, key), thresh) with the part that depends on the ROW (pair, head, query) hoisted: the
+// index is base + key with base a multiple of 512 and key < 512, so its low word is base_lo | key and its high word - which enters
+// the hash through one additive constant only - is the row's.  Same decisions bit for bit (the first-form kernels and the other
+// training kernels keep calling train_keep), two 32-bit multiplies per probability instead of a 64-bit index and four.
+struct MaskRow {
+  uint32_t lo, c;
+};
+__device__ __forceinline__ uint32_t mask_hi_const(uint32_t seed, uint32_t hi) {
+  return (seed * 0x9E3779B9u) ^ ((hi ^ seed) * 0x85EBCA6Bu + 0xC2B2AE35u);
+}
+__device__ __forceinline__ MaskRow mask_row(uint32_t seed, int pair, int head, int nq, int qi) {
+  const uint64_t base = mask_index(pair, head, nq, qi, 0);
+  return MaskRow{(uint32_t)base, mask_hi_const(seed, (uint32_t)(base >> 32))};
+}
+__device__ __forceinline__ bool mask_keep(MaskRow m, int key, uint32_t thresh) {
+  uint32_t x = (m.lo | (uint32_t)key) ^ m.c;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x >= thresh;
+}
+// the rows of one query TILE (32 consecutive queries from q0): row ql's base is the tile's (wave-uniform: scalar arithmetic) + ql * 512
+struct MaskTile {
+  uint32_t lo, c0, c1;
+  __device__ __forceinline__ MaskRow row(int ql) const {
+    const uint32_t l = lo + ((uint32_t)ql << 9);
+    return MaskRow{l, l < lo ? c1 : c0};
+  }
+};
+__device__ __forceinline__ MaskTile mask_tile(uint32_t seed, int pair, int head, int nq, int q0) {
+  const uint64_t base = mask_index(pair, head, nq, q0, 0);
+  const uint32_t hi = (uint32_t)(base >> 32);
+  return MaskTile{(uint32_t)base, mask_hi_const(seed, hi), mask_hi_const(seed, hi + 1)};
+}
 
 // -------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_train_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
@@ -362,6 +398,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
 //   encoder 32 pairs x 512 queries: 1024 workgroups x 16 tiles;  decoder 16 x 200: 512 workgroups x 7 tiles (the first form gave a
 //   wavefront 1-2 tiles and then reduced through LDS).
 // -------------------------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                             int ldk, const float* __restrict__ v, int ldv, const float* __restrict__ d_o,
                                                             int ldo, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -435,14 +472,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv2_kernel(const float* __restr
         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(doaf[j][e], vfb[j][e], dp, 0, 0, 0);  // dP~[q][key]
       }
     f32x16 pt;
+    const MaskTile mt = mask_tile(seed, pair, head, nq, qb * 32);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) {                               // (branch-free: one basic block for the scheduler to interleave)
       const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;            // row of D register r: query qb*32 + ql
-      const int qr = qb * 32 + ql;
-      const bool ok = qr < nq;
-      const float p = ok ? __builtin_amdgcn_exp2f(s[r] - ld_s[buf][0][ql]) : 0.f;
+      const float e = __builtin_amdgcn_exp2f(s[r] - ld_s[buf][0][ql]);
+      const float p = qb * 32 + ql < nq ? e : 0.f;
       float keep = 1.f;
-      if (thresh != 0) keep = train_keep(seed, mask_index(pair, head, nq, ok ? qr : 0, kj), thresh) ? inv_keep : 0.f;
+      if (DROP) keep = mask_keep(mt.row(ql), kj, thresh) ? inv_keep : 0.f;
       pt[r] = p * keep;                                          // P~[q][key]
       s[r] = p * (dp[r] * keep - ld_s[buf][1][ql]);              // dS[q][key]
     }
@@ -493,6 +530,7 @@ struct KvStage {
   }
 };
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_train_fwd2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                               int ldk, const float* __restrict__ v, int ldv, float* __restrict__ o,
                                                               int ldo, float* __restrict__ lse, int nq, int qgroups, float qscale,
@@ -517,6 +555,7 @@ __global__ __launch_bounds__(256) void attn_train_fwd2_kernel(const float* __res
     qf[j] = *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4);
     qf[j] *= qscale * LOG2E;
   }
+  const MaskRow mrow = mask_row(seed, pair, head, nq, q_ok ? qi : 0);
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
@@ -554,11 +593,11 @@ __global__ __launch_bounds__(256) void attn_train_fwd2_kernel(const float* __res
       }
       l_run = l_run * alpha + psum;
       m_run = m_new;
-      if (thresh != 0) {
+      if (DROP) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          s[r] = train_keep(seed, mask_index(pair, head, nq, q_ok ? qi : 0, key), thresh) ? s[r] * inv_keep : 0.f;
+          s[r] = mask_keep(mrow, key, thresh) ? s[r] * inv_keep : 0.f;
         }
       }
 #pragma unroll
@@ -588,6 +627,7 @@ __global__ __launch_bounds__(256) void attn_train_fwd2_kernel(const float* __res
   }
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                            const float* __restrict__ v, int ldv, const float* __restrict__ d_o, int ldo,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
@@ -615,6 +655,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const float* __restri
     dof[j] = *reinterpret_cast<const f32x4*>(d_o + qrow * ldo + head * ATT_HD + j * 8 + hh * 4);
   }
   const float lse_q = lse[qrow * 8 + head], delta_q = delta[qrow * 8 + head];
+  const float qmask = q_ok ? 1.f : 0.f;
+  const MaskRow mrow = mask_row(seed, pair, head, nq, q_ok ? qi : 0);
   f32x16 dqacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
@@ -645,11 +687,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) {
         const float p = __builtin_amdgcn_exp2f(s[r] - lse_q);
         float g = dp[r];
-        if (thresh != 0) {
+        if (DROP) {
           const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          g = train_keep(seed, mask_index(pair, head, nq, q_ok ? qi : 0, key), thresh) ? g * inv_keep : 0.f;
+          g = mask_keep(mrow, key, thresh) ? g * inv_keep : 0.f;
         }
-        s[r] = q_ok ? p * (g - delta_q) : 0.f;          // dS[q][key]
+        s[r] = (p * qmask) * (g - delta_q);             // dS[q][key] (0 for the rows past nq)
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -672,10 +714,216 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const float* __restri
   }
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------
+// Backward in ONE pass (third form): workgroup = head x pair; K and V of the head (512 x 32 each) stay in LDS for the whole kernel
+// (128 KB, XOR-swizzled instead of padded: the CU has 160 KB); a wavefront owns 128 keys (4 key tiles: their dK / dV accumulators live
+// in registers for the whole kernel) and walks the query tiles, which the four wavefronts share (Q, dO, lse, delta of 32 queries
+// through LDS, fetched one tile ahead into registers).  Per (query tile, key tile): S and dP~ (32 MFMAs), P~ and dS in registers,
+// dV += dO^T P~ and dK += Q^T dS (32 MFMAs, the D registers of the first two are the B operands), and - what the two-kernel forms
+// pay a second S / dP~ for - dQ^T += K^T dS^T (16 MFMAs) with dS TRANSPOSED through a 4 KB LDS tile of the wavefront (D layout:
+// lane = key; B operand of this product: lane = query).  After its 4 key tiles a wavefront holds dQ^T of the tile over ITS 128 keys;
+// the four partial tiles are summed through LDS and written out: 5 products instead of 7, every exp2 and every dropout-mask hash
+// once instead of twice, no partial results in HBM.
+// -------------------------------------------------------------------------------------------------------------------
+#ifndef FB_PIPE
+#define FB_PIPE 1   // S / dP~ of key tile kt+1 issued before the softmax arithmetic of tile kt: 258 vs 268 us (encoder shape)
+#endif
+constexpr int FB_KV = ATT_KEYS * ATT_HD;          // floats of K (or V) of one head
+constexpr int FB_TS = 36;                         // padded row of the Q / dO tiles
+constexpr int FB_DS = 33;                         // padded row of a wavefront's dS / output tile
+constexpr size_t FB_SMEM = (size_t)(2 * FB_KV + 2 * 32 * FB_TS + 2 * 32 + 4 * 32 * FB_DS) * sizeof(float);
+__device__ __forceinline__ int fb_swz(int row, int col) { return row * ATT_HD + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); }
+
+template <bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
+                                                             const float* __restrict__ v, int ldv, const float* __restrict__ d_o, int ldo,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             float* __restrict__ dq, int lddq, float* __restrict__ dk, int lddk,
+                                                             float* __restrict__ dv, int lddv, int nq, float qscale, uint32_t thresh,
+                                                             float inv_keep, uint32_t seed, const uint32_t* __restrict__ salt) {
+  seed = train_salted(seed, salt);
+  extern __shared__ __attribute__((aligned(16))) float fb_smem[];
+  float* k_s = fb_smem;                           // [512][32] swizzled
+  float* v_s = k_s + FB_KV;
+  float* q_s = v_s + FB_KV;                       // [32][FB_TS] raw q rows of the tile
+  float* do_s = q_s + 32 * FB_TS;
+  float* ld_s = do_s + 32 * FB_TS;                // lse[32] | delta[32]
+  float* w_s = ld_s + 64;                         // [4 wavefronts][32][FB_DS]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.x, pair = blockIdx.z;
+  float* my_s = w_s + wave * 32 * FB_DS;
+  // K, V of this head -> LDS: thread -> (row t >> 3 (+32 per step), float4 t & 7)
+  {
+    const size_t krow0 = (size_t)pair * ATT_KEYS;
+    const int c4 = t & 7;
+#pragma unroll 4
+    for (int r0 = 0; r0 < ATT_KEYS; r0 += 32) {
+      const int row = r0 + (t >> 3);
+      const f32x4 kk = *reinterpret_cast<const f32x4*>(k + (krow0 + row) * ldk + head * ATT_HD + c4 * 4);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (krow0 + row) * ldv + head * ATT_HD + c4 * 4);
+      *reinterpret_cast<f32x4*>(k_s + row * ATT_HD + ((c4 ^ (row & 7)) << 2)) = kk;
+      *reinterpret_cast<f32x4*>(v_s + row * ATT_HD + ((c4 ^ (row & 7)) << 2)) = vv;
+    }
+  }
+  f32x16 dkacc[4], dvacc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dkacc[kt][r] = dvacc[kt][r] = 0.f;
+  const int nqb = (nq + 31) / 32;
+  const int srow = t >> 3, sc4 = (t & 7) * 4;
+  f32x4 pq, pdo;
+  float pld = 0.f;
+  auto fetch = [&](int qb) {
+    const int qa = qb * 32 + srow;
+    const size_t row = (size_t)pair * nq + (qa < nq ? qa : 0);
+    pq = *reinterpret_cast<const f32x4*>(q + row * ldq + head * ATT_HD + sc4);
+    pdo = *reinterpret_cast<const f32x4*>(d_o + row * ldo + head * ATT_HD + sc4);
+    if (t < 64) {
+      const int ql = qb * 32 + l31;
+      const size_t r2 = (size_t)pair * nq + (ql < nq ? ql : 0);
+      pld = (hh == 0 ? lse : delta)[r2 * 8 + head];
+    }
+  };
+  fetch(0);
+  for (int qb = 0; qb < nqb; ++qb) {
+    __syncthreads();                                             // the previous tile's Q / dO and dQ partials are no longer read
+    *reinterpret_cast<f32x4*>(q_s + srow * FB_TS + sc4) = pq;
+    *reinterpret_cast<f32x4*>(do_s + srow * FB_TS + sc4) = pdo;
+    if (t < 64) ld_s[hh * 32 + l31] = pld;
+    __syncthreads();                                             // tile qb (and, the first time, K / V) is in LDS
+    if (qb + 1 < nqb) fetch(qb + 1);
+    f32x4 qaf[4], doaf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qaf[j] = *reinterpret_cast<const f32x4*>(q_s + l31 * FB_TS + j * 8 + hh * 4);
+      qaf[j] *= qscale * LOG2E;
+      doaf[j] = *reinterpret_cast<const f32x4*>(do_s + l31 * FB_TS + j * 8 + hh * 4);
+    }
+    f32x16 dqacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqacc[r] = 0.f;
+    // S and dP~ of a key tile (32 MFMAs); issued one tile AHEAD of their use, so that the softmax arithmetic of tile kt (VALU) has
+    // the matrix pipe busy with tile kt+1 underneath it (one wavefront per SIMD here: nobody else would fill it)
+    auto scores = [&](int kt, f32x16& s, f32x16& dp) {
+      const int krow = wave * 128 + kt * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int off = krow * ATT_HD + (((j * 2 + hh) ^ (krow & 7)) << 2);
+        const f32x4 kfb = *reinterpret_cast<const f32x4*>(k_s + off);      // B operands: lane = key
+        const f32x4 vfb = *reinterpret_cast<const f32x4*>(v_s + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(qaf[j][e], kfb[e], s, 0, 0, 0);       // S[q][key], lane = key
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(doaf[j][e], vfb[e], dp, 0, 0, 0);    // dP~[q][key]
+        }
+      }
+    };
+    f32x16 s_cur, dp_cur, s_nxt, dp_nxt;
+#if FB_PIPE
+    scores(0, s_cur, dp_cur);
+#endif
+    const MaskTile mt = mask_tile(seed, pair, head, nq, qb * 32);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      const int key0 = wave * 128 + kt * 32;
+      const int kj = key0 + l31;
+#if FB_PIPE
+      if (kt + 1 < 4) scores(kt + 1, s_nxt, dp_nxt);
+#else
+      scores(kt, s_cur, dp_cur);
+#endif
+      f32x16 pt, ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float e = __builtin_amdgcn_exp2f(s_cur[r] - ld_s[ql]);
+        const float p = qb * 32 + ql < nq ? e : 0.f;
+        float keep = 1.f;
+        if (DROP) keep = mask_keep(mt.row(ql), kj, thresh) ? inv_keep : 0.f;
+        pt[r] = p * keep;                                        // P~[q][key]
+        ds[r] = p * (dp_cur[r] * keep - ld_s[32 + ql]);          // dS[q][key]
+      }
+      // dS^T through this wavefront's LDS tile: [query][key]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) my_s[((r & 3) + 8 * (r >> 2) + 4 * hh) * FB_DS + l31] = ds[r];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float dot = do_s[ql * FB_TS + l31];                // A operand of dV^T = dO^T P~: lane = head dim
+        const float qt = q_s[ql * FB_TS + l31] * qscale;         // A operand of dK^T = Q^T dS
+        dvacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dot, pt[r], dvacc[kt], 0, 0, 0);
+        dkacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qt, ds[r], dkacc[kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const int kr = key0 + 2 * s2 + hh;
+        const float ka = k_s[fb_swz(kr, l31)];                   // A operand of dQ^T = K^T dS^T: lane = head dim, k = key
+        const float db = my_s[l31 * FB_DS + 2 * s2 + hh];        // B operand: lane = query
+        dqacc = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, db, dqacc, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");                             // (keep later tiles' LDS reads from being hoisted up here)
+#if FB_PIPE
+      if (kt + 1 < 4) {
+        s_cur = s_nxt;
+        dp_cur = dp_nxt;
+      }
+#endif
+    }
+    // the four wavefronts' dQ^T tiles (rows = head dim, column = query) summed through LDS, 4 head dims x 1 query per thread
+#pragma unroll
+    for (int r = 0; r < 16; ++r) my_s[r * 64 + lane] = dqacc[r];
+    __syncthreads();
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += w_s[w * 32 * FB_DS + (wave * 4 + i) * 64 + lane];
+      const int qo = qb * 32 + l31;
+      if (qo < nq)
+        *reinterpret_cast<f32x4*>(dq + ((size_t)pair * nq + qo) * lddq + head * ATT_HD + 8 * wave + 4 * hh) = acc * qscale;
+    }
+  }
+  __syncthreads();
+  // dK / dV tiles: D rows = head dim, column (lane & 31) = key: through the wavefront's LDS tile to rows
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const size_t orow = (size_t)pair * ATT_KEYS + wave * 128 + kt * 32 + (lane >> 1);
+    const int oc = (lane & 1) * 16;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) my_s[l31 * FB_DS + (r & 3) + 8 * (r >> 2) + 4 * hh] = which == 0 ? dkacc[kt][r] : dvacc[kt][r];
+      __builtin_amdgcn_wave_barrier();
+      float* dst = (which == 0 ? dk + orow * lddk : dv + orow * lddv) + head * ATT_HD + oc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = my_s[(lane >> 1) * FB_DS + oc + i * 4 + e];
+        *reinterpret_cast<f32x4*>(dst + i * 4) = o4;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 }  // namespace
 
-static int g_attn_bwd_form = 2;   // 1: first form of the three kernels (kept for A/B and as a cross-check), 2: a wavefront owns its keys / queries
-void train_set_attn_bwd_form(int v) { g_attn_bwd_form = v == 1 ? 1 : 2; }
+// 1: first form of the three kernels (kept for A/B and as a cross-check); 2: a wavefront owns its keys / queries, dQ and dK/dV in two
+// kernels; 3: the backward in one pass (attn_bwd_fused_kernel); 0 (default): 3 where it is the faster one - enough (pair, head)
+// workgroups to fill the chip and enough query tiles to amortise parking K / V in LDS (encoder self-attention of a training batch:
+// 258 vs 347 us at 32 pairs x 512; the decoder's 16 pairs x 200 queries: 110 vs 96 us, stays on form 2) - else 2
+static int g_attn_bwd_form = 0;
+static bool attn_use_fused(int nb, int nq) { return g_attn_bwd_form == 3 || (g_attn_bwd_form == 0 && nb * 8 >= 192 && nq >= 256); }
+void train_set_attn_bwd_form(int v) { g_attn_bwd_form = (v >= 0 && v <= 3) ? v : 0; }
 int train_get_attn_bwd_form() { return g_attn_bwd_form; }
 
 int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
@@ -688,8 +936,10 @@ int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const 
                        p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
   } else {
     const int qgroups = ((nq + 31) / 32 + 3) / 4;
-    hipLaunchKernelGGL(attn_train_fwd2_kernel, dim3(qgroups * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, o, ldo, lse, nq, qgroups,
-                       qscale, train_thresh(p), p > 0.f ? 1.f / (1.f - p) : 1.f, seed, train_salt_ptr());
+    const uint32_t thresh = train_thresh(p);
+    hipLaunchKernelGGL(thresh ? attn_train_fwd2_kernel<true> : attn_train_fwd2_kernel<false>, dim3(qgroups * 8, 1, nb), dim3(256), 0, s, q,
+                       ldq, k, ldk, v, ldv, o, ldo, lse, nq, qgroups, qscale, thresh, p > 0.f ? 1.f / (1.f - p) : 1.f, seed,
+                       train_salt_ptr());
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -704,20 +954,34 @@ int train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const 
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, o, d_o, ldo, delta, rows);
   if (hipGetLastError() != hipSuccess) return -2;
+  if (attn_use_fused(nb, nq)) {
+    static PerDeviceFlag attr_set;
+    if (!attr_set.get()) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)FB_SMEM) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)FB_SMEM) != hipSuccess)
+        return -2;
+      attr_set.set();
+    }
+    hipLaunchKernelGGL(thresh ? attn_bwd_fused_kernel<true> : attn_bwd_fused_kernel<false>, dim3(8, 1, nb), dim3(256), FB_SMEM, s, q, ldq, k,
+                       ldk, v, ldv, d_o, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   if (g_attn_bwd_form == 1)
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((nq + 31) / 32) * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse,
                        delta, dq, lddq, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
   else {
     const int qgroups = ((nq + 31) / 32 + 3) / 4;
-    hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(qgroups * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dq,
-                       lddq, nq, qgroups, qscale, thresh, inv_keep, seed, train_salt_ptr());
+    hipLaunchKernelGGL(thresh ? attn_bwd_dq2_kernel<true> : attn_bwd_dq2_kernel<false>, dim3(qgroups * 8, 1, nb), dim3(256), 0, s, q, ldq, k,
+                       ldk, v, ldv, d_o, ldo, lse, delta, dq, lddq, nq, qgroups, qscale, thresh, inv_keep, seed, train_salt_ptr());
   }
   if (hipGetLastError() != hipSuccess) return -2;
   if (g_attn_bwd_form == 1)
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(16 * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dk,
                        lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
   else
-    hipLaunchKernelGGL(attn_bwd_dkv2_kernel, dim3(4 * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dk,
-                       lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
+    hipLaunchKernelGGL(thresh ? attn_bwd_dkv2_kernel<true> : attn_bwd_dkv2_kernel<false>, dim3(4 * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk,
+                       v, ldv, d_o, ldo, lse, delta, dk, lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

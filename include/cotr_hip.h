@@ -377,9 +377,10 @@ int cotr_set_coop_tail(int enable);
 /* polls of the tile's arrival word before a workgroup leaves its share to the last arriver (default 4000, ~0.3 us each; 0 = never
  * wait: the last arriver finishes the whole tile - the schedule-independence test) */
 int cotr_set_coop_tail_spin(int polls);
-/* training attention forward + backward: 2 (default) = a wavefront owns its keys (dK / dV) or its queries (forward, dQ) and walks the other side's tiles,
- * which the workgroup's four wavefronts share through LDS; 1 = the first form (wavefronts split the walk, partial sums reduced
- * through LDS at the end) */
+/* training attention kernels: 1 = the first form (wavefronts split the walk over the other side's tiles, partial results reduced through
+ * LDS at the end); 2 = a wavefront owns its queries (forward, dQ) or its keys (dK / dV) and walks the other side's tiles, which the
+ * workgroup shares through LDS; 3 = forward as 2, the backward in ONE pass (K / V of a head parked in LDS, dS transposed through LDS for
+ * the dQ product: 5 matrix products instead of 7); 0 (default) = 3 where it is faster (>= 24 pairs, >= 256 queries), else 2 */
 int cotr_set_train_attention_form(int form);
 /* layer1's bottlenecks (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity / downsample, FrozenBN, ReLU: torchvision
  * Bottleneck.forward, COTR/models/backbone.py:46-56) run as ONE launch each (bottleneck.hip) for passes of up to this many pairs

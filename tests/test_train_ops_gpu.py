@@ -104,11 +104,12 @@ def test_packed_in_projection_slices():
     assert torch.equal(torch.autograd.grad(yr, xr, db_.cuda())[0], db_.cuda())
 
 
-@pytest.mark.parametrize('form', [2, 1])
-@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (2, 100, False), (1, 24, False), (3, 33, False), (2, 200, False)])
+@pytest.mark.parametrize('form', [0, 1, 2, 3])
+@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (2, 100, False), (1, 24, False), (3, 33, False), (2, 200, False), (24, 256, False)])
 def test_attention_forward_backward(nb, nq, packed, form):
     """attn_train_fwd / attn_bwd_dq / attn_bwd_dkv (recompute-softmax backward) vs softmax attention under torch autograd; both
-    forms of the backward kernels (cotr_set_train_attention_form: 2 = the shipped one)."""
+    forms of the kernels (cotr_set_train_attention_form; 0 = the shipped choice: the one-pass backward from 24 pairs x 256 queries up, the
+    two-kernel second form below)."""
     from cotr_amd import _lib
     _lib.set_knob('train_attention_form', form)
     g = _g(nb * 1000 + nq)
@@ -146,7 +147,7 @@ def test_attention_backward_forms_agree_with_dropout(nb, nq, packed):
     q, k, v = torch.randn(nb * nq, 256, generator=g), torch.randn(nb * 512, 256, generator=g), torch.randn(nb * 512, 256, generator=g)
     d_o = torch.randn(nb * nq, 256, generator=g).cuda()
     res = []
-    for form in (1, 2):
+    for form in (1, 2, 3):
         _lib.set_knob('train_attention_form', form)
         T.reseed(99)
         if packed:
@@ -157,8 +158,9 @@ def test_attention_backward_forms_agree_with_dropout(nb, nq, packed):
             xs = [_leaf(q), _leaf(k), _leaf(v)]
             o = T.Attention.apply(None, xs[0], xs[1], xs[2], nb, nq, 32 ** -0.5, 0.1)
             res.append((o.detach(),) + torch.autograd.grad(o, xs, d_o))
-    for a, b in zip(res[0], res[1]):                             # output, then the gradients
-        assert _rel(b, a) < 2e-5
+    for other in res[1:]:
+        for a, b in zip(res[0], other):                          # output, then the gradients
+            assert _rel(b, a) < 2e-5
 
 
 def test_attention_dropout_statistics_and_determinism():

@@ -7,7 +7,7 @@ import torch
 from torch.profiler import profile, ProfilerActivity
 from cotr_amd import train_ops as T, _lib
 
-for form in (1, 2):
+for form in (1, 2, 3, 0):
     _lib.set_knob('train_attention_form', form)
     for name, nb, nq, p in (('encoder 32 x 512', 32, 512, 0.1), ('decoder 16 x 200', 16, 200, 0.1), ('decoder 16 x 200 p=0', 16, 200, 0.0)):
         g = torch.Generator().manual_seed(0)
