@@ -308,18 +308,21 @@ def test_decoder_head_in_one_launch(nb, nq, q_total):
         assert torch.isnan(flat[1]).all() and torch.equal(flat[keep], flat0[keep])
 
 
-def test_layernorm():
+@pytest.mark.parametrize('rows', [1001, 8192 + 13])
+def test_layernorm(rows):
+    """(the row after the last one must stay untouched)"""
     from cotr_amd import _lib
     g = _g(3)
-    x = torch.randn(1001, 256, generator=g) * 3 + 1
+    x = torch.randn(rows, 256, generator=g) * 3 + 1
     w, b = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g)
     ref = F.layer_norm(x, (256,), w, b, 1e-5)
     d = G.dev()
-    y = torch.empty(1001, 256, device=d)
+    y = torch.full((rows + 1, 256), 7.0, device=d)
     x_d, w_d, b_d = x.to(d), w.to(d), b.to(d)
-    assert _lib.load_library().cotr_op_layernorm(G.P(x_d), G.P(w_d), G.P(b_d), G.P(y), 1001, G.sptr()) == 0
-    e = G.rel_err(y, ref)
+    assert _lib.load_library().cotr_op_layernorm(G.P(x_d), G.P(w_d), G.P(b_d), G.P(y), rows, G.sptr()) == 0
+    e = G.rel_err(y[:rows], ref)
     assert e < 5e-6, e
+    assert bool((y[rows] == 7.0).all())
 
 
 def test_lin_sine_encoding():
