@@ -121,6 +121,7 @@ _PROTOS = {
     'cotr_set_coop_tail': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_coop_tail_spin': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_train_attention_form': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_attention_resident': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_bottleneck_max_pairs': (ctypes.c_int, [ctypes.c_int]),
     'cotr_op_bottleneck': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int] + [c_float_p] * 12 + [ctypes.c_void_p]),
     'cotr_knob_count': (ctypes.c_int, []),

@@ -33,6 +33,7 @@ void set_attention_fused_splits(int v);
 void set_ffn_debug_times(unsigned long long* p);  // ffn.hip
 void set_attention_debug_times(unsigned long long* p);  // attention.hip
 void set_attention_wide_min_rows(long v);
+void set_attention_resident(int v);
 void set_attention_wide_occupancy(int v);
 
 namespace {
@@ -1401,6 +1402,11 @@ int cotr_set_coop_tail_spin(int polls) {
   return COTR_OK;
 }
 
+int cotr_set_attention_resident(int enable) {
+  set_attention_resident(enable);
+  knob_record("attention_resident", enable != 0);
+  return COTR_OK;
+}
 int cotr_set_train_attention_form(int form) {
   if (form < 0 || form > 3) return COTR_ERR_ARG;
   train_set_attn_bwd_form(form);
@@ -1505,6 +1511,7 @@ Knob* knob_table(int* n) {
       {"coop_tail", cotr_set_coop_tail, 0, 0},
       {"coop_tail_spin", cotr_set_coop_tail_spin, 4000, 4000},
       {"train_attention_form", cotr_set_train_attention_form, 0, 0},
+      {"attention_resident", cotr_set_attention_resident, 1, 1},
   };
   *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
   return knobs;

@@ -456,6 +456,131 @@ __global__ __launch_bounds__(NS * 64, OCC) void attention_wide_kernel(const floa
   }
 }
 
+// ---- many query rows per (pair, head): K_h and V_h RESIDENT in LDS ---------------------------------------------------------------------
+// Workgroup = (pair, head, chunk of up to 32 query tiles), 8 wavefronts (two per SIMD).  K_h and V_h of the head (512 x 32 floats each,
+// 128 KB together, XOR-swizzled instead of padded) are loaded into LDS ONCE and every operand of the key loop comes from there: no
+// global load, no barrier and no cross-wavefront merge in the steady state.  A wavefront owns a 32-query tile at a time and runs the
+// FOUR key quarters as four independent online-softmax chains (the arithmetic of attention_kernel<4, ..> / attention_wide_kernel<4, ..>,
+// where a wavefront ran one quarter each) merged in registers in the same order: results are bit-identical to those kernels, and the
+// four chains are independent instruction streams - the softmax VALU of one sits under the matrix instructions of the others.  The
+// output tile goes out as float4 stores straight from the D registers (rows = head dim: 4 consecutive dims per register quad).
+//   32 pairs x 512 (encoder): attention_wide 94 us;  32 x 1000 (decoder): 171 us - numbers of this kernel in DESIGN.md 3
+constexpr size_t ATT_RES_SMEM = (size_t)2 * ATT_KEYS * ATT_HD * sizeof(float);
+__global__ __launch_bounds__(512) void attention_res_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                            const float* __restrict__ v, int ldkv, float* __restrict__ o, int ldo, int nq,
+                                                            int tiles_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) float res_smem[];
+  float* k_s = res_smem;
+  float* v_s = res_smem + ATT_KEYS * ATT_HD;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.x & 7, chunk = blockIdx.x >> 3;      // head-major: a head's workgroups land on one XCD (its L2 keeps K_h / V_h)
+  const int pair = blockIdx.z;
+  {
+    const size_t krow0 = (size_t)pair * ATT_KEYS;
+    const int c4 = t & 7;
+#pragma unroll 4
+    for (int r0 = 0; r0 < ATT_KEYS; r0 += 64) {
+      const int row = r0 + (t >> 3);
+      const f32x4 kk = *reinterpret_cast<const f32x4*>(k + (krow0 + row) * ldkv + head * ATT_HD + c4 * 4);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (krow0 + row) * ldkv + head * ATT_HD + c4 * 4);
+      *reinterpret_cast<f32x4*>(k_s + row * ATT_HD + ((c4 ^ (row & 7)) << 2)) = kk;
+      *reinterpret_cast<f32x4*>(v_s + row * ATT_HD + ((c4 ^ (row & 7)) << 2)) = vv;
+    }
+  }
+  __syncthreads();
+  const int ntiles = (nq + 31) / 32;
+  const int t_end = (chunk + 1) * tiles_per_chunk < ntiles ? (chunk + 1) * tiles_per_chunk : ntiles;
+  for (int qt = chunk * tiles_per_chunk + wave; qt < t_end; qt += 8) {
+    const int qi = qt * 32 + l31;
+    const bool q_ok = qi < nq;
+    const size_t qrow = (size_t)pair * nq + (q_ok ? qi : 0);
+    f32x4 qf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      qf[j] = *reinterpret_cast<const f32x4*>(q + qrow * ldq + head * ATT_HD + j * 8 + hh * 4);
+      qf[j] *= q_ok ? 1.44269504088896340736f : 0.f;   // log2 domain; rows past nq compute on zeros and are never stored
+    }
+    f32x16 oacc[4];
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
+      m_run[c] = -INFINITY;
+      l_run[c] = 0.f;
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {                    // the four key quarters: independent chains
+        const int key0 = c * 128 + kb * 32;
+        const int krow = key0 + l31;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(k_s + krow * ATT_HD + (((j * 2 + hh) ^ (krow & 7)) << 2));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[j][e], s, 0, 0, 0);
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run[c], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[c] - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+          psum += s[r];
+        }
+        l_run[c] = l_run[c] * alpha + psum;
+        m_run[c] = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[c][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int vr = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const float vf = v_s[vr * ATT_HD + ((((l31 >> 2) ^ (vr & 7)) << 2) | (l31 & 3))];
+          oacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], oacc[c], 0, 0, 0);
+        }
+      }
+    }
+    // merge of the four quarters, the arithmetic (and order) of attention_kernel's merge through LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) l_run[c] += __shfl_xor(l_run[c], 32);
+    float m_all = m_run[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c) m_all = fmaxf(m_all, m_run[c]);
+    float f[4];
+    float l_all = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f[c] = __builtin_amdgcn_exp2f(m_run[c] - m_all);
+      l_all += f[c] * l_run[c];
+    }
+    const float inv = 1.f / l_all;
+    if (q_ok) {
+      float* dst = o + qrow * ldo + head * ATT_HD + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {                    // registers 4g .. 4g+3 = head dims 8g + 4hh .. + 3
+        f32x4 out;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float acc = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc += f[c] * oacc[c][g * 4 + i];
+          out[i] = acc * inv;
+        }
+        *reinterpret_cast<f32x4*>(dst + 8 * g) = out;
+      }
+    }
+  }
+}
+
 // 3 wavefronts per SIMD measured 162-164 us at 32768 query rows against 168-193 for 2 (and 206 for the 32-query kernel).  An in-wave
 // software pipeline pinned with sched_group_barrier (softmax of one tile between the MFMAs of the other) measured the same 164 us:
 // hipcc honours the pattern for the score MFMAs only, and three wavefronts per SIMD already interleave the phases in hardware.
@@ -463,6 +588,8 @@ static int g_att_wide_occ = 3;  // set_attention_wide_occupancy
 void set_attention_wide_occupancy(int v) { g_att_wide_occ = v == 2 ? 2 : 3; }
 static int g_att_wide_head_major = 1;  // set_attention_wide_head_major
 void set_attention_wide_head_major(int v) { g_att_wide_head_major = v != 0; }
+static int g_att_resident = 1;   // K_h / V_h resident in LDS (attention_res_kernel) from attention_wide_min_rows rows and 256 queries per pair
+void set_attention_resident(int v) { g_att_resident = v != 0; }
 static long g_att_wide_min_rows = 4096;  // query rows of a launch from which the 64-query kernel is used (set_attention_wide_min_rows)
 void set_attention_wide_min_rows(long v) { g_att_wide_min_rows = v < 0 ? 0 : v; }
 
@@ -484,6 +611,24 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
   if (nb <= 0 || nq <= 0) return 0;
   if (ldq % 4 || ldkv % 4 || ldo % 4) return -1;
   int ns = g_att_splits;
+  // query tiles per workgroup: 32 (4 per wavefront) when that still gives every CU a workgroup, down to 8 (one per wavefront: K_h / V_h
+  // are then fetched for 8 tiles only); fewer than 128 workgroups even so -> the 64-query kernel below
+  const int res_tiles = (nq + 31) / 32;
+  int res_tpc = 32;
+  while (res_tpc > 8 && (long)((res_tiles + res_tpc - 1) / res_tpc) * 8 * nb < 256) res_tpc /= 2;
+  const long res_wgs = (long)((res_tiles + res_tpc - 1) / res_tpc) * 8 * nb;
+  if (ns == 0 && g_att_resident && (long)nb * nq >= g_att_wide_min_rows && nq >= 256 && res_wgs >= 128) {
+    static PerDeviceFlag attr_set;
+    if (!attr_set.get()) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attention_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)ATT_RES_SMEM) != hipSuccess)
+        return -2;
+      attr_set.set();
+    }
+    const int chunks = (res_tiles + res_tpc - 1) / res_tpc;
+    hipLaunchKernelGGL(attention_res_kernel, dim3(chunks * 8, 1, nb), dim3(512), ATT_RES_SMEM, s, q, ldq, k, v, ldkv, o, ldo, nq, res_tpc);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+  }
   if (ns == 0 && (long)nb * nq >= g_att_wide_min_rows) {
     dim3 wgrid(((nq + 63) / 64) * 8, 1, nb);
     // head-major workgroup order here (head = XCD): with many pairs in flight every XCD then keeps one head's K/V slice of each

@@ -382,6 +382,9 @@ int cotr_set_coop_tail_spin(int polls);
  * workgroup shares through LDS; 3 = forward as 2, the backward in ONE pass (K / V of a head parked in LDS, dS transposed through LDS for
  * the dQ product: 5 matrix products instead of 7); 0 (default) = 3 where it is faster (>= 24 pairs, >= 256 queries), else 2 */
 int cotr_set_train_attention_form(int form);
+/* attention over many query rows (>= attention_wide_min_rows rows, >= 256 queries per pair): 1 (default) = K_h / V_h of a head resident in
+ * LDS for a whole chunk of query tiles (attention_res_kernel), 0 = the 64-query kernel that re-fetches them per workgroup; bit-identical */
+int cotr_set_attention_resident(int enable);
 /* layer1's bottlenecks (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity / downsample, FrozenBN, ReLU: torchvision
  * Bottleneck.forward, COTR/models/backbone.py:46-56) run as ONE launch each (bottleneck.hip) for passes of up to this many pairs
  * (default 4: the latency-bound regime - at 8 pairs it is time-neutral, above that the halo recompute of conv1 loses; 0 = never):

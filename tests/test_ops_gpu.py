@@ -180,6 +180,7 @@ def test_attention_wide_kernel_is_bit_identical(nb, nq, occ):
         for min_rows in (1 << 30, 0):
             assert lib.cotr_set_attention_wide_min_rows(min_rows) == 0
             assert lib.cotr_set_attention_wide_occupancy(occ) == 0
+            assert lib.cotr_set_attention_resident(0) == 0
             o = torch.full((nb * nq + 1, 256), float('nan'), device=d)      # one guard row behind the output
             assert lib.cotr_op_attention(G.P(qd), 256, G.P(kvd), G.P(kvd[:, 256:]), 512, G.P(o), 256, nb, nq, G.sptr()) == 0
             assert torch.isnan(o[-1]).all()
@@ -187,7 +188,37 @@ def test_attention_wide_kernel_is_bit_identical(nb, nq, occ):
     finally:
         lib.cotr_set_attention_wide_min_rows(4096)
         lib.cotr_set_attention_wide_occupancy(3)
+        lib.cotr_set_attention_resident(1)
     assert torch.equal(outs[0], outs[1])
+    assert G.rel_err(outs[1], ref) < 2e-5
+
+
+@pytest.mark.parametrize('nb,nq', [(1, 256), (3, 333), (2, 1000), (5, 2048), (1, 2100), (2, 512)])
+def test_attention_resident_kernel_is_bit_identical(nb, nq):
+    """attention_res_kernel (K_h / V_h of a head resident in LDS for a chunk of up to 32 query tiles, a wavefront runs the four key
+    quarters of its query tile as four chains and merges them in registers; taken from 4096 query rows and 256 queries per pair up)
+    does the arithmetic of attention_kernel<4> per query: bit-identical output - ragged last tiles, several chunks per pair (2100
+    queries = 66 tiles) included - and it matches the fp64 reference."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(nb * 104729 + nq)
+    q = torch.randn(nb * nq, 256, generator=g) * 3.0 / math.sqrt(32)
+    kv = torch.randn(nb * 512, 512, generator=g)
+    qh = q.double().view(nb, nq, 8, 32).permute(0, 2, 1, 3)
+    kh = kv[:, :256].double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    vh = kv[:, 256:].double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).permute(0, 2, 1, 3).reshape(nb * nq, 256)
+    d = G.dev()
+    qd, kvd = q.to(d), kv.to(d)
+    outs = []
+    for min_rows, resident in ((1 << 30, 0), (0, 1)):
+        _lib.set_knob('attention_wide_min_rows', min_rows)
+        _lib.set_knob('attention_resident', resident)
+        o = torch.full((nb * nq + 1, 256), float('nan'), device=d)      # one guard row behind the output
+        assert lib.cotr_op_attention(G.P(qd), 256, G.P(kvd), G.P(kvd[:, 256:]), 512, G.P(o), 256, nb, nq, G.sptr()) == 0
+        assert torch.isnan(o[-1]).all()
+        outs.append(o[:-1])
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
     assert G.rel_err(outs[1], ref) < 2e-5
 
 
