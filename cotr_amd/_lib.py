@@ -88,7 +88,8 @@ _PROTOS = {
     'cotr_train_attention_bwd': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p,
                                                 c_float_p, ctypes.c_int, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,
                                                 ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
-                                                ctypes.c_float, ctypes.c_uint32, ctypes.c_void_p]),
+                                                ctypes.c_float, ctypes.c_uint32, c_float_p, ctypes.c_void_p]),
+    'cotr_train_attention_bwd_scratch': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'cotr_crop_resize_pairs': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
                                               c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_dense_cycle': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, ctypes.c_void_p]),

@@ -1739,10 +1739,12 @@ int cotr_train_attention_fwd(const float* q, int ldq, const float* k, int ldk, c
 }
 int cotr_train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                              const float* d_o, int ldo, const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk,
-                             float* dv, int lddv, int nb, int nq, float qscale, float p, uint32_t seed, cotr_stream stream) {
+                             float* dv, int lddv, int nb, int nq, float qscale, float p, uint32_t seed, float* scratch,
+                             cotr_stream stream) {
   return op_ret(train_attention_bwd(q, ldq, k, ldk, v, ldv, o, d_o, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, nb, nq, qscale, p,
-                                    seed, TS));
+                                    seed, scratch, TS));
 }
+size_t cotr_train_attention_bwd_scratch(int nb, int nq) { return nb > 0 && nq > 0 ? train_attention_bwd_scratch(nb, nq) : 0; }
 #undef TS
 
 // ---- engine-side input construction --------------------------------------------------

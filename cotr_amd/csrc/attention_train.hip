@@ -729,37 +729,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(const float* __restri
 #ifndef FB_PIPE
 #define FB_PIPE 1   // S / dP~ of key tile kt+1 issued before the softmax arithmetic of tile kt: 258 vs 268 us (encoder shape)
 #endif
-constexpr int FB_KV = ATT_KEYS * ATT_HD;          // floats of K (or V) of one head
 constexpr int FB_TS = 36;                         // padded row of the Q / dO tiles
 constexpr int FB_DS = 33;                         // padded row of a wavefront's dS / output tile
-constexpr size_t FB_SMEM = (size_t)(2 * FB_KV + 2 * 32 * FB_TS + 2 * 32 + 4 * 32 * FB_DS) * sizeof(float);
+constexpr size_t fb_smem_bytes(int kt) { return (size_t)(2 * kt * 128 * ATT_HD + 2 * 32 * FB_TS + 2 * 32 + 4 * 32 * FB_DS) * sizeof(float); }
 __device__ __forceinline__ int fb_swz(int row, int col) { return row * ATT_HD + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); }
 
-template <bool DROP>
+template <bool DROP, int KT>
 __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k, int ldk,
                                                              const float* __restrict__ v, int ldv, const float* __restrict__ d_o, int ldo,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             float* __restrict__ dq, int lddq, float* __restrict__ dk, int lddk,
+                                                             float* __restrict__ dq, int lddq, size_t dq_split_stride,
+                                                             float* __restrict__ dk, int lddk,
                                                              float* __restrict__ dv, int lddv, int nq, float qscale, uint32_t thresh,
                                                              float inv_keep, uint32_t seed, const uint32_t* __restrict__ salt) {
   seed = train_salted(seed, salt);
   extern __shared__ __attribute__((aligned(16))) float fb_smem[];
   float* k_s = fb_smem;                           // [512][32] swizzled
-  float* v_s = k_s + FB_KV;
-  float* q_s = v_s + FB_KV;                       // [32][FB_TS] raw q rows of the tile
+  constexpr int WG_KEYS = KT * 128;               // keys of this workgroup: wavefront w owns KT tiles of 32 from w * KT * 32
+  float* v_s = k_s + WG_KEYS * ATT_HD;
+  float* q_s = v_s + WG_KEYS * ATT_HD;                       // [32][FB_TS] raw q rows of the tile
   float* do_s = q_s + 32 * FB_TS;
   float* ld_s = do_s + 32 * FB_TS;                // lse[32] | delta[32]
   float* w_s = ld_s + 64;                         // [4 wavefronts][32][FB_DS]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.x, pair = blockIdx.z;
+  constexpr int SPLITS = 4 / KT;                  // workgroups per (pair, head): each leaves a dQ partial (summed by the caller) when > 1
+  const int head = blockIdx.x / SPLITS, ksplit = blockIdx.x % SPLITS, pair = blockIdx.z;
+  const int kbase = ksplit * WG_KEYS;
+  dq += (size_t)ksplit * dq_split_stride;
   float* my_s = w_s + wave * 32 * FB_DS;
   // K, V of this head -> LDS: thread -> (row t >> 3 (+32 per step), float4 t & 7)
   {
-    const size_t krow0 = (size_t)pair * ATT_KEYS;
+    const size_t krow0 = (size_t)pair * ATT_KEYS + kbase;
     const int c4 = t & 7;
 #pragma unroll 4
-    for (int r0 = 0; r0 < ATT_KEYS; r0 += 32) {
+    for (int r0 = 0; r0 < WG_KEYS; r0 += 32) {
       const int row = r0 + (t >> 3);
       const f32x4 kk = *reinterpret_cast<const f32x4*>(k + (krow0 + row) * ldk + head * ATT_HD + c4 * 4);
       const f32x4 vv = *reinterpret_cast<const f32x4*>(v + (krow0 + row) * ldv + head * ATT_HD + c4 * 4);
@@ -767,9 +771,9 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
       *reinterpret_cast<f32x4*>(v_s + row * ATT_HD + ((c4 ^ (row & 7)) << 2)) = vv;
     }
   }
-  f32x16 dkacc[4], dvacc[4];
+  f32x16 dkacc[KT], dvacc[KT];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dkacc[kt][r] = dvacc[kt][r] = 0.f;
   const int nqb = (nq + 31) / 32;
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
     // S and dP~ of a key tile (32 MFMAs); issued one tile AHEAD of their use, so that the softmax arithmetic of tile kt (VALU) has
     // the matrix pipe busy with tile kt+1 underneath it (one wavefront per SIMD here: nobody else would fill it)
     auto scores = [&](int kt, f32x16& s, f32x16& dp) {
-      const int krow = wave * 128 + kt * 32 + l31;
+      const int krow = (wave * KT + kt) * 32 + l31;              // row in this workgroup's K / V
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
@@ -829,11 +833,11 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
 #endif
     const MaskTile mt = mask_tile(seed, pair, head, nq, qb * 32);
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      const int key0 = wave * 128 + kt * 32;
-      const int kj = key0 + l31;
+    for (int kt = 0; kt < KT; ++kt) {
+      const int key0 = (wave * KT + kt) * 32;                    // (local; + kbase = the key's index in the pair)
+      const int kj = kbase + key0 + l31;
 #if FB_PIPE
-      if (kt + 1 < 4) scores(kt + 1, s_nxt, dp_nxt);
+      if (kt + 1 < KT) scores(kt + 1, s_nxt, dp_nxt);
 #else
       scores(kt, s_cur, dp_cur);
 #endif
@@ -870,7 +874,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");                             // (keep later tiles' LDS reads from being hoisted up here)
 #if FB_PIPE
-      if (kt + 1 < 4) {
+      if (kt + 1 < KT) {
         s_cur = s_nxt;
         dp_cur = dp_nxt;
       }
@@ -894,8 +898,8 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
   __syncthreads();
   // dK / dV tiles: D rows = head dim, column (lane & 31) = key: through the wavefront's LDS tile to rows
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) {
-    const size_t orow = (size_t)pair * ATT_KEYS + wave * 128 + kt * 32 + (lane >> 1);
+  for (int kt = 0; kt < KT; ++kt) {
+    const size_t orow = (size_t)pair * ATT_KEYS + kbase + (wave * KT + kt) * 32 + (lane >> 1);
     const int oc = (lane & 1) * 16;
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
@@ -920,9 +924,19 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
 // 1: first form of the three kernels (kept for A/B and as a cross-check); 2: a wavefront owns its keys / queries, dQ and dK/dV in two
 // kernels; 3: the backward in one pass (attn_bwd_fused_kernel); 0 (default): 3 where it is the faster one - enough (pair, head)
 // workgroups to fill the chip and enough query tiles to amortise parking K / V in LDS (encoder self-attention of a training batch:
-// 258 vs 347 us at 32 pairs x 512; the decoder's 16 pairs x 200 queries: 110 vs 96 us, stays on form 2) - else 2
+// 258 vs 347 us at 32 pairs x 512); with fewer pairs the keys of a head are split over 2 or 4 workgroups (attn_fused_kt) - else 2
 static int g_attn_bwd_form = 0;
-static bool attn_use_fused(int nb, int nq) { return g_attn_bwd_form == 3 || (g_attn_bwd_form == 0 && nb * 8 >= 192 && nq >= 256); }
+// key tiles per wavefront of the one-pass backward (4: one workgroup per (pair, head); 2 / 1: two / four workgroups, each leaving a dQ
+// partial in `scratch` that train_sum_parts adds - the decoder's 16 pairs x 200 queries: 128 workgroups would leave half the chip idle),
+// 0: use the two-kernel second form.  The split forms need the scratch buffer and a contiguous dq.
+static int attn_fused_kt(int nb, int nq, int lddq, const float* scratch) {
+  if (g_attn_bwd_form == 1 || g_attn_bwd_form == 2) return 0;
+  const bool can_split = scratch != nullptr && lddq == 256;
+  if (nb * 8 >= 192 || !can_split) return (g_attn_bwd_form == 3 || (nb * 8 >= 192 && nq >= 256)) ? 4 : 0;
+  if (nb * 16 >= 192) return 2;
+  if (nb * 32 >= 192 || g_attn_bwd_form == 3) return 1;
+  return 0;
+}
 void train_set_attn_bwd_form(int v) { g_attn_bwd_form = (v >= 0 && v <= 3) ? v : 0; }
 int train_get_attn_bwd_form() { return g_attn_bwd_form; }
 
@@ -946,7 +960,7 @@ int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const 
 
 int train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, const float* d_o,
                         int ldo, const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
-                        int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s) {
+                        int nb, int nq, float qscale, float p, uint32_t seed, float* scratch, hipStream_t s) {
   if (nb <= 0 || nq <= 0) return 0;
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || lddq % 4 || lddk % 4 || lddv % 4) return -1;
   const int rows = nb * nq;
@@ -954,19 +968,30 @@ int train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const 
   const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, o, d_o, ldo, delta, rows);
   if (hipGetLastError() != hipSuccess) return -2;
-  if (attn_use_fused(nb, nq)) {
+  const int kt = attn_fused_kt(nb, nq, lddq, scratch);
+  if (kt != 0) {
     static PerDeviceFlag attr_set;
     if (!attr_set.get()) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)FB_SMEM) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)FB_SMEM) != hipSuccess)
-        return -2;
+      const void* fns[6] = {reinterpret_cast<const void*>(attn_bwd_fused_kernel<true, 4>), reinterpret_cast<const void*>(attn_bwd_fused_kernel<false, 4>),
+                            reinterpret_cast<const void*>(attn_bwd_fused_kernel<true, 2>), reinterpret_cast<const void*>(attn_bwd_fused_kernel<false, 2>),
+                            reinterpret_cast<const void*>(attn_bwd_fused_kernel<true, 1>), reinterpret_cast<const void*>(attn_bwd_fused_kernel<false, 1>)};
+      const int kts[6] = {4, 4, 2, 2, 1, 1};
+      for (int i = 0; i < 6; ++i)
+        if (hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_smem_bytes(kts[i])) != hipSuccess) return -2;
       attr_set.set();
     }
-    hipLaunchKernelGGL(thresh ? attn_bwd_fused_kernel<true> : attn_bwd_fused_kernel<false>, dim3(8, 1, nb), dim3(256), FB_SMEM, s, q, ldq, k,
-                       ldk, v, ldv, d_o, ldo, lse, delta, dq, lddq, dk, lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
-    return hipGetLastError() == hipSuccess ? 0 : -2;
+    const int splits = 4 / kt;
+    float* dq_dst = splits > 1 ? scratch : dq;
+    const int ld_dst = splits > 1 ? 256 : lddq;
+    const size_t split_stride = splits > 1 ? (size_t)rows * 256 : 0;
+    auto fn = kt == 4 ? (thresh ? attn_bwd_fused_kernel<true, 4> : attn_bwd_fused_kernel<false, 4>)
+            : kt == 2 ? (thresh ? attn_bwd_fused_kernel<true, 2> : attn_bwd_fused_kernel<false, 2>)
+                      : (thresh ? attn_bwd_fused_kernel<true, 1> : attn_bwd_fused_kernel<false, 1>);
+    hipLaunchKernelGGL(fn, dim3(8 * splits, 1, nb), dim3(256), fb_smem_bytes(kt), s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse, delta, dq_dst, ld_dst,
+                       split_stride, dk, lddk, dv, lddv, nq, qscale, thresh, inv_keep, seed, train_salt_ptr());
+    if (hipGetLastError() != hipSuccess) return -2;
+    if (splits > 1) return train_sum_parts(scratch, splits, (size_t)rows * 256, dq, s);   // fixed order: deterministic
+    return 0;
   }
   if (g_attn_bwd_form == 1)
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((nq + 31) / 32) * 8, 1, nb), dim3(256), 0, s, q, ldq, k, ldk, v, ldv, d_o, ldo, lse,

@@ -83,4 +83,6 @@ int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const 
 // dq [nb*nq][lddq], dk [nb*512][lddk], dv [nb*512][lddv]; delta [nb*nq][8] scratch (rowsum(dO * O) per head); o / d_o share ldo
 int train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o, const float* d_o,
                         int ldo, const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv,
-                        int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s);
+                        int nb, int nq, float qscale, float p, uint32_t seed, float* scratch, hipStream_t s);
+// floats of `scratch` train_attention_bwd can use (dQ partials of the key-split one-pass backward); scratch == nullptr is allowed
+static inline size_t train_attention_bwd_scratch(int nb, int nq) { return (size_t)4 * nb * nq * 256; }

@@ -677,9 +677,11 @@ class Attention(torch.autograd.Function):
             dk = ctx.k_dst if ctx.k_dst is not None else _empty((nb * 512, 256), o)
             k_ptr = _P(k_t)
             dq_ptr, dk_ptr, ldq, ldk, lddq, lddk = _P(dq), _P(dk), 256, k_t.stride(0), 256, dk.stride(0)
+        # room for the dQ partials of the key-split one-pass backward (decoder: few pairs); not needed from 24 pairs up
+        scratch = None if (packed or nb * 8 >= 192) else _empty((lib.cotr_train_attention_bwd_scratch(nb, nq),), o)
         with _on(o.device):
             _chk(lib.cotr_train_attention_bwd(_P(q_t), ldq, k_ptr, ldk, _P(v), ldv, _P(o), _P(d_o), 256, _P(lse), _P(delta),
-                                              dq_ptr, lddq, dk_ptr, lddk, _P(dv), lddv, nb, nq, scale, p, seed, _sp()),
+                                              dq_ptr, lddq, dk_ptr, lddk, _P(dv), lddv, nb, nq, scale, p, seed, _P(scratch), _sp()),
                  'cotr_train_attention_bwd')
         if packed:
             return dqk, None, None, dv, None, None, None, None

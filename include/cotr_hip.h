@@ -266,10 +266,14 @@ int cotr_train_head_bwd(const float* dy, const float* h, const float* w2, float*
  * (log2-domain log-sum-exp) for the backward */
 int cotr_train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
                              int nb, int nq, float qscale, float p, uint32_t seed, cotr_stream stream);
-/* dq [nb*nq][lddq], dk [nb*512][lddk], dv [nb*512][lddv]; delta: nb*nq*8 floats of scratch; o / d_o share ldo */
+/* dq [nb*nq][lddq], dk [nb*512][lddk], dv [nb*512][lddv]; delta: nb*nq*8 floats of scratch; o / d_o share ldo.
+ * scratch: cotr_train_attention_bwd_scratch(nb, nq) floats or NULL - room for the dQ partials of the one-pass backward when the keys
+ * of a head are split over several workgroups (few pairs); without it that shape takes the two-kernel form */
 int cotr_train_attention_bwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* o,
                              const float* d_o, int ldo, const float* lse, float* delta, float* dq, int lddq, float* dk, int lddk,
-                             float* dv, int lddv, int nb, int nq, float qscale, float p, uint32_t seed, cotr_stream stream);
+                             float* dv, int lddv, int nb, int nq, float qscale, float p, uint32_t seed, float* scratch,
+                             cotr_stream stream);
+size_t cotr_train_attention_bwd_scratch(int nb, int nq);
 
 /* ---- engine-side input construction (one launch per zoom level) -------------
  * For each of n tasks: crop the square box (xa, ya, size_a) of image A and (xb, yb, size_b) of image B

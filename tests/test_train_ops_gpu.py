@@ -105,7 +105,8 @@ def test_packed_in_projection_slices():
 
 
 @pytest.mark.parametrize('form', [0, 1, 2, 3])
-@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (2, 100, False), (1, 24, False), (3, 33, False), (2, 200, False), (24, 256, False)])
+@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (2, 100, False), (1, 24, False), (3, 33, False), (2, 200, False), (24, 256, False), (16, 200, False),
+                                          (12, 64, False), (7, 40, False)])
 def test_attention_forward_backward(nb, nq, packed, form):
     """attn_train_fwd / attn_bwd_dq / attn_bwd_dkv (recompute-softmax backward) vs softmax attention under torch autograd; both
     forms of the kernels (cotr_set_train_attention_form; 0 = the shipped choice: the one-pass backward from 24 pairs x 256 queries up, the
@@ -137,7 +138,7 @@ def test_attention_forward_backward(nb, nq, packed, form):
     assert _rel(dq, gq) < 5e-5 and _rel(dk, gk) < 5e-5 and _rel(dv, gv) < 5e-5
 
 
-@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (3, 200, False), (1, 33, False)])
+@pytest.mark.parametrize('nb,nq,packed', [(2, 512, True), (3, 200, False), (1, 33, False), (16, 200, False), (8, 100, False)])
 def test_attention_backward_forms_agree_with_dropout(nb, nq, packed):
     """Dropout on the probabilities (p = 0.1): the two forms of the backward kernels regenerate the same mask from (seed, element
     index) and give the same dq / dk / dv up to summation order (the dropout path has no closed-form torch reference: the mask is
@@ -147,7 +148,7 @@ def test_attention_backward_forms_agree_with_dropout(nb, nq, packed):
     q, k, v = torch.randn(nb * nq, 256, generator=g), torch.randn(nb * 512, 256, generator=g), torch.randn(nb * 512, 256, generator=g)
     d_o = torch.randn(nb * nq, 256, generator=g).cuda()
     res = []
-    for form in (1, 2, 3):
+    for form in (1, 2, 3, 0):     # (3: one workgroup per (pair, head) when dq is packed, keys split over 2 / 4 otherwise; 0: the shipped choice)
         _lib.set_knob('train_attention_form', form)
         T.reseed(99)
         if packed:
