@@ -399,7 +399,8 @@ def run_train(args, dev, world, rank):
                                     'stage 1 of the reference recipe (NOT configs[4]): the same step with the backbone frozen (lr_backbone 0)'),
                        'stage': args.stage, 'lr_backbone': lr_backbone,
                        'pairs_per_gpu': pairs, 'queries_per_pair': nq,
-                       'step': 'captured HIP graph (GraphedTrainStep)' if graphed else 'eager train_batch',
+                       'step': ('captured HIP graph (GraphedTrainStep)' if graphed else
+                                'eager train_batch (backward enqueued before the loss is read back; a NaN step is discarded afterwards)'),
                        'gradients': 'GradSink: flat buffer, one deferred reduction launch' if use_sink else 'per-weight reductions + autograd accumulation',
                        'optimizer': 'FusedAdam (torch.optim.Adam update, one launch)' if fused_adam else 'torch.optim.Adam',
                        'parallelism': f'data parallel x{world}, reduce-scatter + all-gather of the gradients' if world > 1 else 'single GPU'},
