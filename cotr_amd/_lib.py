@@ -123,6 +123,8 @@ _PROTOS = {
     'cotr_set_coop_tail_spin': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_train_attention_form': (ctypes.c_int, [ctypes.c_int]),
     'cotr_set_attention_resident': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_set_gemm_ln_min_rows': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_op_linear_ln': (ctypes.c_int, [c_float_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_set_bottleneck_max_pairs': (ctypes.c_int, [ctypes.c_int]),
     'cotr_op_bottleneck': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int] + [c_float_p] * 12 + [ctypes.c_void_p]),
     'cotr_knob_count': (ctypes.c_int, []),

@@ -13,7 +13,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcotr_hip.so')
-SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip', 'dense_post.hip', 'ffn.hip', 'head.hip', 'train.hip', 'attention_train.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'gemm_ln.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip', 'dense_post.hip', 'ffn.hip', 'head.hip', 'train.hip', 'attention_train.hip', 'api.hip']
 # Pillow-exact resamples (8-bit and float): double-precision coefficient code must not be contracted into FMAs
 EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ffp-contract=off']}
 HEADERS = ['common.h', 'train.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]

@@ -235,6 +235,7 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
 }
 
 bool g_fused_stem = true;  // cotr_set_fused_stem
+int g_gemm_ln_min_rows = 1 << 30;   // cotr_set_gemm_ln_min_rows: rows from which a 256-wide projection and the LayerNorm behind it are ONE launch (gemm_ln.hip: 128-row workgroups; sensible from 24576 rows).  OFF: in isolation -5 % (K = 256) / -8 % (K = 1024) against GEMM + layernorm_kernel, in the forward nothing (dense pass 14.74 vs 14.65 ms, 32 pairs x 1000: 11.15 vs 11.08 ms) - the 128 x 256 tile at one wavefront per SIMD loses in the K loop what the saved launch and the 2 x 33 MB of pre-norm traffic (L2 / Infinity-Cache hits anyway) gave
 bool g_ffn_tail = false;   // cotr_set_ffn_tail: measured slower, off
 bool g_ffn_preln = false;  // cotr_set_ffn_preln: the norm before the FFN folded into the fused FFN block (measured neutral, off)
 
@@ -279,6 +280,19 @@ CoopTail make_tail(cotr_ctx* h, const float* bias, const float* residual, const 
 }
 bool coop_tail_ok(int nch) { return g_coop_tail && (nch == 8 || nch == 16); }
 
+// y = LayerNorm(x . w^T + bias + residual) for a 256-wide projection: one launch from g_gemm_ln_min_rows rows (gemm_ln.hip), else the
+// GEMM into `tmp` and layernorm_kernel - bit-identical either way
+int linear_ln(cotr_ctx* h, const float* x, const float* w, const float* bias, const float* residual, const float* nw, const float* nb,
+              float* tmp, float* y, int M, int K, hipStream_t s) {
+  if (M >= g_gemm_ln_min_rows) {
+    KCHK(h, launch_gemm_ln(x, K, w, bias, residual, D, nw, nb, y, M, K, s), "linear+layernorm");
+    if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear+ln %dx%dx%d", M, D, K); prof_mark(h, nm, s, 2); }
+    return COTR_OK;
+  }
+  if (int r = linear(h, x, nullptr, 0, 1, 0, w, bias, residual, 0, 1.f, 0, tmp, M, D, K, s)) return r;
+  return layernorm(h, tmp, nw, nb, y, M, s);
+}
+
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
 // Up to g_ffn_fuse_max_rows rows: ONE fused launch that keeps the hidden activations on the CU and writes per-chunk
 // partial outputs + ln_reduce (sum, bias, residual, norm); above: linear1, linear2 (+residual), layernorm.
@@ -319,8 +333,7 @@ int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, c
   }
   int r;
   if ((r = linear(h, x, nullptr, 0, 1, 0, l1w, l1b, nullptr, 1, 1.f, 0, hid, M, FFN, D, s))) return r;
-  if ((r = linear(h, hid, nullptr, 0, 1, 0, l2w, l2b, x, 0, 1.f, 0, tmp, M, D, FFN, s))) return r;
-  return layernorm(h, tmp, nw, nb, y, M, s);
+  return linear_ln(h, hid, l2w, l2b, x, nw, nb, tmp, y, M, FFN, s);
 }
 
 // y = LN_post(x1 + FFN(x1)) with x1 = LN_pre(xpre): the norm after the attention sub-layer folded into the fused FFN block
@@ -836,9 +849,14 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       } else {
         KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
         prof_mark(h, "attention enc", s, 2);
-        if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
-        if ((r = ffn_block_pre(h, t_tmp, e.n1w, e.n1b, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_x1, t_ao, y, M, s)))
-          return r;
+        if (M >= g_gemm_ln_min_rows && !g_ffn_preln) {   // out-projection + residual + norm1 in one launch; the FFN block takes the normed rows
+          if ((r = linear_ln(h, t_ao, e.out_w, e.out_b, xin, e.n1w, e.n1b, t_tmp, t_x1, M, D, s))) return r;
+          if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_ao, y, M, s))) return r;
+        } else {
+          if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
+          if ((r = ffn_block_pre(h, t_tmp, e.n1w, e.n1b, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_x1, t_ao, y, M, s)))
+            return r;
+        }
       }
       xin = y;
     }
@@ -962,6 +980,11 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
     KCHK(h, launch_attention(d.q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d.ao, D, nb, nq, s),
          "attention");
     prof_mark(h, "attention dec", s, 2);
+    if (R >= g_gemm_ln_min_rows && !g_ffn_preln) {
+      if ((r = linear_ln(h, d.ao, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.pre2, d.t2, R, D, s))) return r;
+      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, d.tgt, R, s))) return r;
+      continue;
+    }
     if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
     if ((r = ffn_block_pre(h, d.pre2, w.n2w, w.n2b, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.t2, d.pre3, d.tgt, R, s)))
       return r;
@@ -1402,6 +1425,15 @@ int cotr_set_coop_tail_spin(int polls) {
   return COTR_OK;
 }
 
+int cotr_set_gemm_ln_min_rows(int rows) {
+  g_gemm_ln_min_rows = rows < 0 ? 0 : rows;
+  knob_record("gemm_ln_min_rows", g_gemm_ln_min_rows);
+  return COTR_OK;
+}
+int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const float* residual, const float* ln_w, const float* ln_b,
+                      float* y, int M, int K, cotr_stream stream) {
+  return op_ret(launch_gemm_ln(x, K, w, bias, residual, 256, ln_w, ln_b, y, M, K, static_cast<hipStream_t>(stream)));
+}
 int cotr_set_attention_resident(int enable) {
   set_attention_resident(enable);
   knob_record("attention_resident", enable != 0);
@@ -1512,6 +1544,7 @@ Knob* knob_table(int* n) {
       {"coop_tail_spin", cotr_set_coop_tail_spin, 4000, 4000},
       {"train_attention_form", cotr_set_train_attention_form, 0, 0},
       {"attention_resident", cotr_set_attention_resident, 1, 1},
+      {"gemm_ln_min_rows", cotr_set_gemm_ln_min_rows, 1 << 30, 1 << 30},
   };
   *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
   return knobs;

@@ -210,6 +210,9 @@ void gemm_set_patch(int v);
 void gemm_set_ws_flags(int v);
 void gemm_set_conv1x1_dense(int v);  // 1 (default): 1x1 stride-1 convolutions run the dense instantiation of their configuration  // 1 (default): three-stage LDS-DMA k-split instead of the two-stage one where K >= 768
 const float* gemm_zero_buffer();  // per-DEVICE buffer of zeros (LDS-DMA padding source), on the current device
+// gemm_ln.hip: y [M][256] = LayerNorm(x [M][K] . w [256][K]^T + bias + residual) * ln_w + ln_b, a workgroup owns 128 complete rows
+int launch_gemm_ln(const float* x, int lda, const float* w, const float* bias, const float* residual, int ldr, const float* ln_w,
+                   const float* ln_b, float* y, int M, int K, hipStream_t s);
 
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]
 int launch_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,

@@ -389,6 +389,13 @@ int cotr_set_train_attention_form(int form);
 /* attention over many query rows (>= attention_wide_min_rows rows, >= 256 queries per pair): 1 (default) = K_h / V_h of a head resident in
  * LDS for a whole chunk of query tiles (attention_res_kernel), 0 = the 64-query kernel that re-fetches them per workgroup; bit-identical */
 int cotr_set_attention_resident(int enable);
+/* rows from which a 256-wide projection followed by a LayerNorm (attention out-projection + norm, linear2 + norm) is ONE launch
+ * (gemm_ln.hip: a workgroup owns 128 complete rows; bit-identical to the two-launch form).  Default: off (1 << 30) - measured equal
+ * to the two launches inside the forward; 24576 is the value it was measured with */
+int cotr_set_gemm_ln_min_rows(int rows);
+/* y [M][256] = LayerNorm(x [M][K] . w [256][K]^T + bias + residual [M][256]) * ln_w + ln_b in one launch (op-level entry for the tests) */
+int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const float* residual, const float* ln_w, const float* ln_b,
+                      float* y, int M, int K, cotr_stream stream);
 /* layer1's bottlenecks (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity / downsample, FrozenBN, ReLU: torchvision
  * Bottleneck.forward, COTR/models/backbone.py:46-56) run as ONE launch each (bottleneck.hip) for passes of up to this many pairs
  * (default 4: the latency-bound regime - at 8 pairs it is time-neutral, above that the halo recompute of conv1 loses; 0 = never):

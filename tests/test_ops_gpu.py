@@ -621,3 +621,28 @@ def test_large_tile_configs_are_repeatable():
         for ws, base in ((40, 26), (41, 27)):
             if ws in first and base in first:
                 assert torch.equal(first[ws], first[base]), (ws, base, M, N, K)
+
+
+@pytest.mark.parametrize('M,K,res', [(1000, 256, True), (32768, 256, True), (4099, 1024, True), (130, 256, False), (128, 32, True)])
+def test_linear_plus_layernorm_kernel(M, K, res):
+    """gemm_ln_kernel: y = LayerNorm(x . w^T + bias + residual) with a workgroup owning 128 complete rows, against the large-tile GEMM
+    (config 26: the same k order) followed by layernorm_kernel - bit-identical - and against torch in fp64."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(M + K)
+    d = G.dev()
+    x = torch.randn(M, K, generator=g).to(d)
+    w = (torch.randn(256, K, generator=g) / K ** 0.5).to(d)
+    b = torch.randn(256, generator=g).to(d)
+    r = torch.randn(M, 256, generator=g).to(d) if res else None
+    lw, lb = (torch.rand(256, generator=g) + 0.5).to(d), torch.randn(256, generator=g).to(d)
+    y = torch.full((M + 1, 256), 7.0, device=d)
+    assert lib.cotr_op_linear_ln(G.P(x), G.P(w), G.P(b), G.P(r) if res else None, G.P(lw), G.P(lb), G.P(y), M, K, G.sptr()) == 0
+    assert bool((y[M] == 7.0).all())                     # nothing behind the last row
+    tmp, y2 = torch.empty(M, 256, device=d), torch.empty(M, 256, device=d)
+    assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(r) if res else None, 0, G.P(tmp), M, 256, K, 26, G.sptr()) == 0
+    assert lib.cotr_op_layernorm(G.P(tmp), G.P(lw), G.P(lb), G.P(y2), M, G.sptr()) == 0
+    assert torch.equal(y[:M], y2), float((y[:M] - y2).abs().max())
+    pre = x.double().cpu() @ w.double().cpu().t() + b.double().cpu() + (r.double().cpu() if res else 0)
+    ref = F.layer_norm(pre, (256,), lw.double().cpu(), lb.double().cpu(), 1e-5)
+    assert G.rel_err(y[:M], ref) < 2e-5

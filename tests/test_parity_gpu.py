@@ -490,3 +490,28 @@ def test_backbone_entry_points_match_the_stage_taps():
     torch.cuda.synchronize()
     assert torch.equal(full.view(3, 16, 32, 1024), out)
     assert lib.cotr_backbone_upto(m._handle, img_d.data_ptr(), 3, 4, out.data_ptr(), _lib.current_stream_ptr()) != 0
+
+
+@pytest.mark.parametrize('name', ['ragged_b2_q257', 'engine_b4_q1'])
+def test_projection_plus_layernorm_in_one_launch(name, golden_dir):
+    """gemm_ln.hip (the attention out-projection / linear2 with the LayerNorm behind them as ONE launch, taken from 24576 rows up)
+    forced onto small golden cases (cotr_set_gemm_ln_min_rows(0), with the many-row forms of everything else so that the unfused
+    GEMM + layernorm sequence is the one it replaces): the same MFMA sequence per output element and layernorm_kernel's arithmetic
+    per row; the golden's bar."""
+    from cotr_amd import _lib
+    wseed, gain = make_golden.CASES[name][:2]
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    sd, img, qs = make_golden.case_inputs(name)
+    m = hip_model(wseed, gain)
+    outs = []
+    for min_rows in (1 << 30, 0):
+        _lib.set_knob('attention_fusion_max_rows', 0)      # the unfused (many-row) layer sequence
+        _lib.set_knob('ffn_fusion_max_rows', 0)
+        _lib.set_knob('gemm_ln_min_rows', min_rows)
+        outs.append(m(img.cuda(), qs.cuda())['pred_corrs'].cpu())
+    _lib.reset_knobs()
+    # (at these row counts the unfused GEMMs run on split-K / wave-private configurations with another k order: agreement to rounding;
+    # the bit-identity against the large-tile GEMM + layernorm_kernel at the shapes where the fusion is used is tests/test_ops_gpu.py's)
+    ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), torch.from_numpy(g['pred_f64']))
+    assert cotr_oracle.px_err(outs[1], outs[0]) < max(SHAPE_NOISE_PX, 3 * ref_gap)
+    assert cotr_oracle.px_err(outs[1], torch.from_numpy(g['pred_f64'])) < max(PX_BAR, 3 * ref_gap)
