@@ -10,7 +10,10 @@ Workloads
                       ranks (32 per GPU on 8 GPUs, 256 on one), every rank holds only its own pairs (strong scaling).
   train               BASELINE.json configs[4] / SURVEY.md 8f4: one STAGE-2 ``COTRTrainer.train_batch`` step (cycle + bidirectional,
                       Adam, dropout 0.1, lr_backbone 1e-5: layer2 / layer3 of the backbone train) at 16 pairs x 200 queries per
-                      GPU; value = pairs/s; ``--stage 1`` = the frozen-backbone first stage.  Not the headline metric.
+                      GPU; value = pairs/s; ``--stage 1`` = the frozen-backbone first stage.  Not the headline metric.  The step is
+                      ``cotr_amd.training.train_batch`` with the gradients in one flat buffer finished by one reduction launch
+                      (GradSink) and Adam as one launch (FusedAdam); ``--no-grad-sink`` / ``--torch-adam`` = per-weight reductions /
+                      torch's own Adam step, ``--graphed-train`` = the whole step as one captured HIP graph.
 Synthetic data and seeded random weights of the COTR architecture (no checkpoint exists offline).  Inputs are resident in
 HBM before the timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the predicted (x,y) of
 every step are all-gathered over xGMI on RCCL's stream, overlapped with the next step; no collective in the math.
