@@ -50,8 +50,18 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 QUERIES = 1000
+DENSE_QUERIES = 256 * 512     # --workload dense: the grid (j/512, i/256) of cotr_patch_flow_exhaustive.one_pass (inference_helper.py:116-127)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz x 256 CUs
 HBM_PEAK_GBS = 8000.0
+
+
+KNOBS = []   # --set KNOB=INT pairs: applied to every model handle this run creates (tuning knobs are per handle, include/cotr_hip.h)
+
+
+def apply_knobs(model):
+    for name, val in KNOBS:
+        model.set_knob(name, val)
+    return model
 
 
 def flop(b, q):
@@ -210,7 +220,7 @@ def other_regimes(sd, dev):
     out = {}
     models = []
     for _ in range(3):
-        m = build_model(cotr_amd.default_args()).to(dev).eval()
+        m = apply_knobs(build_model(cotr_amd.default_args()).to(dev).eval())
         m.load_state_dict(sd)
         models.append(m)
     streams = [torch.cuda.Stream(device=dev) for _ in models]
@@ -247,7 +257,7 @@ def traffic_child(n_forward):
     from cotr_amd.models import build_model
     from cotr_amd.utils.synth import synth_state_dict, synth_inputs
     dev = torch.device('cuda', 0)
-    model = build_model(cotr_amd.default_args()).to(dev).eval()
+    model = apply_knobs(build_model(cotr_amd.default_args()).to(dev).eval())
     model.load_state_dict(synth_state_dict(0))
     img, qs = synth_inputs(1, QUERIES, seed=1)
     img, qs = img.to(dev), qs.to(dev)
@@ -354,7 +364,7 @@ def run_train(args, dev, world, rank):
     # stage 2 of the reference recipe (readme.md:50, train_cotr.py --lr_backbone=1e-5): layer2 / layer3 of the backbone train
     # (backbone.py:64-69) - what BASELINE.json configs[4] names; --stage 1 = the frozen-backbone first stage (lr_backbone 0)
     lr_backbone = 1e-5 if args.stage == 2 else 0.0
-    model = build_model(cotr_amd.default_args(dropout=0.1, lr_backbone=lr_backbone)).to(dev)
+    model = apply_knobs(build_model(cotr_amd.default_args(dropout=0.1, lr_backbone=lr_backbone)).to(dev))
     model.load_state_dict(synth_state_dict(0))
     model.train()
     graphed = args.graphed_train
@@ -390,8 +400,10 @@ def run_train(args, dev, world, rank):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    ident = rank_identity(world, dev)
     if rank == 0:
         print(json.dumps({
+            **ident,
             'metric': 'training pairs/sec (COTRTrainer.train_batch step, cycle + bidirectional)', 'value': world * pairs * args.steps / elapsed,
             'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -404,7 +416,7 @@ def run_train(args, dev, world, rank):
                        'pairs_per_gpu': pairs, 'queries_per_pair': nq,
                        'step': ('captured HIP graph (GraphedTrainStep)' if graphed else
                                 'eager train_batch (backward enqueued before the loss is read back; a NaN step is discarded afterwards)'),
-                       'gradients': 'GradSink: flat buffer, one deferred reduction launch' if use_sink else 'per-weight reductions + autograd accumulation',
+                       'gradients': ('GradSink: flat buffer, one deferred reduction launch' + (' per third of the buffer, each third\'s reduce-scatter / all-gather started right behind it' if world > 1 and not graphed else '')) if use_sink else 'per-weight reductions + autograd accumulation',
                        'optimizer': 'FusedAdam (torch.optim.Adam update, one launch)' if fused_adam else 'torch.optim.Adam',
                        'parallelism': f'data parallel x{world}, reduce-scatter + all-gather of the gradients' if world > 1 else 'single GPU'},
         }), flush=True)
@@ -419,6 +431,20 @@ def reduce_elapsed(elapsed, steps, dev, world):
     return max(vals), [v / steps * 1e3 for v in vals]
 
 
+def rank_identity(world, dev):
+    """What a SCALE record can be checked against: the world size as the COMMUNICATOR sees it and the device every rank really
+    runs on (gathered through the job's own process group; plain Python objects, outside the timed region)."""
+    name = torch.cuda.get_device_name(dev) if dev.type == 'cuda' else 'cpu'
+    mine = {'rank': dist.get_rank() if world > 1 else 0, 'device': str(dev), 'name': name,
+            'pci_bus_id': (torch.cuda.get_device_properties(dev).pci_bus_id if dev.type == 'cuda' and
+                           hasattr(torch.cuda.get_device_properties(dev), 'pci_bus_id') else None), 'pid': os.getpid()}
+    if world <= 1:
+        return {'rccl_ranks': 1, 'backend': None, 'ranks': [mine]}
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    return {'rccl_ranks': dist.get_world_size(), 'backend': dist.get_backend(), 'ranks': every}
+
+
 def dry_run(args, world, rank):
     """The launcher / rendezvous / barrier / max-over-ranks timing / gather / one-JSON-line plumbing of this file on the CPU
     (gloo), with a stand-in for the model: proves that `python bench.py --gpus N` starts its own ranks and that rank 0 alone
@@ -431,19 +457,36 @@ def dry_run(args, world, rank):
     dev = torch.device('cpu')
     if world > 1:
         dist.init_process_group('gloo')
-    batch256 = args.workload == 'batch256'
-    total_pairs = 8 if batch256 else world                    # (a small stand-in for the 256 pairs)
+    batch256, dense = args.workload == 'batch256', args.workload == 'dense'
+    total_pairs = 8 if batch256 else (1 if dense else world)  # (a small stand-in for the 256 pairs)
     lo, hi = shard_range(total_pairs, world, rank)
     pairs = hi - lo
     counts = [shard_range(total_pairs, world, r)[1] - shard_range(total_pairs, world, r)[0] for r in range(world)]
-    g = torch.Generator().manual_seed(1 + rank)
-    img, qs = torch.randn(pairs, 3, 16, 32, generator=g), torch.rand(pairs, 10, 2, generator=g)
+    g = torch.Generator().manual_seed(1 if dense else 1 + rank)
     fake = lambda i, q: {'pred_corrs': q * 0.5 + i.mean(dim=(1, 2, 3)).view(-1, 1, 1)}
     finish = None
+    if dense:
+        # ONE pair, a stand-in grid of 1031 queries (not a multiple of the world size), sharded by PairShardedModel exactly as the
+        # real workload's 131072: every rank holds the same inputs, decodes its slice, the all-gather is inside the step
+        from cotr_amd.dist import PairShardedModel
+        img, qs = torch.randn(1, 3, 16, 32, generator=g), torch.rand(1, 1031, 2, generator=g)
+        calls = []
 
-    def step():
-        out = fake(img, qs)['pred_corrs']
-        return all_gather_rows(out, counts, async_op=True) if world > 1 else ((lambda: out), None)
+        def counted(i, q):
+            calls.append(tuple(q.shape))
+            return fake(i, q)
+        sharded = PairShardedModel(counted)
+        pairs = 1
+
+        def step():
+            out = sharded(img, qs)['pred_corrs']
+            return (lambda: out[0]), None
+    else:
+        img, qs = torch.randn(pairs, 3, 16, 32, generator=g), torch.rand(pairs, 10, 2, generator=g)
+
+        def step():
+            out = fake(img, qs)['pred_corrs']
+            return all_gather_rows(out, counts, async_op=True) if world > 1 else ((lambda: out), None)
 
     for _ in range(args.warmup):
         finish, w = step()
@@ -466,13 +509,19 @@ def dry_run(args, world, rank):
     rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         elapsed, rank_ms = reduce_elapsed(elapsed, args.steps, dev, world)
+    ident = rank_identity(world, dev)
     if rank == 0:
-        print(json.dumps({'metric': 'DRY RUN (CPU stand-in model, gloo): plumbing only, not a measurement', 'value': total_pairs * 10 * args.steps / elapsed,
-                          'unit': 'query-correspondences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                          'ms_per_step': elapsed / args.steps * 1e3, 'ms_per_step_ranks': {'min': min(rank_ms), 'max': max(rank_ms)},
-                          'higher_is_better': True, 'scaling': 'strong' if batch256 else 'weak', 'vs_baseline': None, 'dtype': 'f32',
-                          'data': 'synthetic', 'dry_run': True, 'gathered_rows': int(gathered.shape[0]),
-                          'config': {'workload': f'dry run of --workload {args.workload}', 'pairs_per_gpu': pairs}}), flush=True)
+        line = {'metric': 'DRY RUN (CPU stand-in model, gloo): plumbing only, not a measurement', 'value': total_pairs * 10 * args.steps / elapsed,
+                'unit': 'query-correspondences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                'ms_per_step': elapsed / args.steps * 1e3, 'ms_per_step_ranks': {'min': min(rank_ms), 'max': max(rank_ms)},
+                'higher_is_better': True, 'scaling': 'strong' if (batch256 or dense) else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+                'data': 'synthetic', 'dry_run': True, 'gathered_rows': int(gathered.shape[0]),
+                'config': {'workload': f'dry run of --workload {args.workload}', 'pairs_per_gpu': pairs}}
+        line.update(ident)
+        if dense:
+            line['dense_check'] = {'equals_unsharded': bool(torch.equal(gathered, fake(img, qs)['pred_corrs'][0])),
+                                   'queries_this_rank': calls[-1][1], 'queries_total': int(qs.shape[1])}
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -482,7 +531,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--workload', choices=['headline', 'batch256', 'train'], default='headline')
+    ap.add_argument('--workload', choices=['headline', 'batch256', 'dense', 'train'], default='headline',
+                    help='headline: configs[1], one pair x 1000 queries per GPU; batch256: configs[3], 256 pairs sharded; dense: ONE pair x 131072 '
+                         'grid queries (the dense initial pass, inference_helper.py:106-145) with the QUERIES sharded over the GPUs (strong scaling); '
+                         'train: configs[4]')
     ap.add_argument('--torch-adam', action='store_true', help="--workload train: torch.optim.Adam's own multi-tensor step instead of FusedAdam")
     ap.add_argument('--no-grad-sink', action='store_true',
                     help='--workload train: per-weight gradient reductions + autograd accumulation instead of the GradSink')
@@ -500,14 +552,14 @@ def main():
     ap.add_argument('--stage', type=int, choices=[1, 2], default=2,
                     help='--workload train: 2 (default, BASELINE.json configs[4]) = lr_backbone 1e-5, layer2/3 train; 1 = frozen backbone')
     ap.add_argument('--set', action='append', default=[], metavar='KNOB=INT',
-                    help='experiments: call cotr_set_<KNOB>(INT) first, e.g. --set attention_fusion_max_rows=0')
+                    help='experiments: cotr_set_knob(h, KNOB, INT) on every model handle (and the process-wide set) first, e.g. --set attention_fusion_max_rows=0')
     args = ap.parse_args()
     if args.traffic_child:
         return traffic_child(args.traffic_child)
     if args.steps is None:
-        args.steps = {'headline': 200, 'batch256': 5, 'train': 10}[args.workload]
+        args.steps = {'headline': 200, 'batch256': 5, 'dense': 10, 'train': 10}[args.workload]
     if args.warmup is None:
-        args.warmup = {'headline': 20, 'batch256': 2, 'train': 3}[args.workload]
+        args.warmup = {'headline': 20, 'batch256': 2, 'dense': 2, 'train': 3}[args.workload]
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` as the driver calls it: start one rank per GPU ourselves (torch.distributed.run on this node,
@@ -541,31 +593,46 @@ def main():
     from cotr_amd.models import build_model
     from cotr_amd.utils.synth import synth_state_dict, synth_inputs
 
-    for kv in args.set:
-        name, val = kv.split('=')
-        if getattr(_lib.load_library(), 'cotr_set_' + name)(int(val)) != 0:
-            raise SystemExit(f'cotr_set_{name}({val}) failed')
+    global KNOBS
+    KNOBS = [(kv.split('=')[0], int(kv.split('=')[1])) for kv in args.set]
+    for name, val in KNOBS:                                   # the handle-less entry points (training ops) read the process-wide set
+        _lib.set_knob(name, val)
     if args.workload == 'train':
         run_train(args, dev, world, rank)
         if world > 1:
             dist.destroy_process_group()
         return
 
-    batch256 = args.workload == 'batch256'
-    total_pairs = 256 if batch256 else world
+    batch256, dense = args.workload == 'batch256', args.workload == 'dense'
+    total_pairs = 256 if batch256 else (1 if dense else world)
+    queries = DENSE_QUERIES if dense else QUERIES
     lo, hi = shard_range(total_pairs, world, rank)
-    pairs = hi - lo                                           # this rank's pairs (batch256: its block of the 256)
-    model = build_model(cotr_amd.default_args()).to(dev).eval()
+    pairs = 1 if dense else hi - lo                           # this rank's pairs (batch256: its block of the 256; dense: THE pair)
+    model = apply_knobs(build_model(cotr_amd.default_args()).to(dev).eval())
     model.load_state_dict(synth_state_dict(0))
-    img, qs = synth_inputs(pairs, QUERIES, seed=1 + rank)
+    # dense: every rank holds the same pair and the same 256 x 512 query grid (inference_helper.py:116-127) and decodes ITS
+    # slice of the queries (dist.PairShardedModel: pair x query shards; queries are independent, transformer.py:185-201)
+    img, qs = synth_inputs(pairs, queries, seed=1 if dense else 1 + rank)
+    if dense:
+        jj, ii = torch.meshgrid(torch.arange(512), torch.arange(256), indexing='xy')
+        qs = torch.stack([jj / 512.0, ii / 256.0], dim=-1).reshape(1, DENSE_QUERIES, 2).float()
     img, qs = img.to(dev), qs.to(dev)
     counts = [shard_range(total_pairs, world, r)[1] - shard_range(total_pairs, world, r)[0] for r in range(world)]
+    my_queries = queries
+    if dense and world > 1:
+        from cotr_amd.dist import PairShardedModel
+        sharded = PairShardedModel(model)
+        q_lo, q_hi = shard_range(queries, world, rank)
+        my_queries = q_hi - q_lo
     # one-time setup, not a step: pack the weights into the library (74 MB + the pos.W^T tables) and reserve its workspace, so
     # that a run with --warmup 0 does not time initialisation either.  No forward pass runs here.
-    model.reserve(pairs, QUERIES)
+    model.reserve(pairs, my_queries)
     torch.cuda.synchronize()
 
     def step():
+        if dense and world > 1:                                 # encode the pair, decode this rank's query slice, all-gather: all timed
+            sharded(img, qs)
+            return None
         out = model(img, qs)['pred_corrs']
         if world > 1:  # RCCL all-gather of the predicted (x,y), asynchronous w.r.t. the next step's kernels
             return all_gather_rows(out, counts, async_op=True)[1]
@@ -598,12 +665,19 @@ def main():
     if world > 1:
         elapsed, rank_ms = reduce_elapsed(elapsed, args.steps, dev, world)
     kernel_ms = sum(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)) / args.steps  # HIP events, launch stream
+    ident = rank_identity(world, dev)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        units = total_pairs * QUERIES * args.steps
-        achieved = flop(pairs, QUERIES) / (kernel_ms * 1e-3) / 1e12
-        if batch256:
+        units = total_pairs * queries * args.steps
+        # this rank's algorithmic work per step (dense on several ranks: the whole encode + its slice of the queries)
+        my_flop = 24.641e9 + my_queries * 11.273e6 if dense else flop(pairs, QUERIES)
+        achieved = my_flop / (kernel_ms * 1e-3) / 1e12
+        if dense:
+            workload = ('the dense initial pass of cotr_flow (inference_helper.py:106-145): ONE pair 256x512 side-by-side x 131072 grid queries '
+                        f'per step for the whole job; every rank encodes the pair and decodes {my_queries} of the queries '
+                        '(dist.PairShardedModel), all-gather of pred_corrs inside the timed region; seeded random COTR weights')
+        elif batch256:
             workload = ('BASELINE.json configs[3]: 256 pairs 256x512 side-by-side x 1000 queries per step for the whole job, '
                         f'{pairs} pairs on this GPU, model(img[{pairs},3,256,512], q[{pairs},1000,2]); seeded random COTR weights')
         else:
@@ -619,20 +693,22 @@ def main():
             'ms_per_step': ms_per_step,
             'ms_per_step_ranks': {'min': min(rank_ms), 'max': max(rank_ms)},
             'higher_is_better': True,
-            'scaling': 'strong' if batch256 else 'weak',
+            'scaling': 'strong' if (batch256 or dense) else 'weak',
             'vs_baseline': None,
             'dtype': 'f32',
             'data': 'synthetic',
-            'config': {'workload': workload, 'pairs_per_gpu': pairs, 'queries_per_pair': QUERIES,
-                       'parallelism': f'pairs sharded x{world}, all-gather of pred_corrs' if world > 1 else 'single GPU'},
+            'config': {'workload': workload, 'pairs_per_gpu': pairs, 'queries_per_pair': queries,
+                       'parallelism': (f'queries of one pair sharded x{world} (encode replicated), all-gather of pred_corrs' if dense and world > 1 else
+                                       f'pairs sharded x{world}, all-gather of pred_corrs' if world > 1 else 'single GPU')},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
                          'launch': 'one cotr_forward (all kernels of a step)', 'launch_ms_hip_events': kernel_ms,
-                         'algorithmic_gflop_per_launch': flop(pairs, QUERIES) / 1e9,
-                         'min_hbm_gbs': min_hbm_bytes(pairs, QUERIES) / (kernel_ms * 1e-3) / 1e9,
+                         'algorithmic_gflop_per_launch': my_flop / 1e9,
+                         'min_hbm_gbs': min_hbm_bytes(pairs, my_queries) / (kernel_ms * 1e-3) / 1e9,
                          'hbm_peak_gbs': HBM_PEAK_GBS},
         }
-        extras = world == 1 and not args.no_extras and not batch256
+        extras = world == 1 and not args.no_extras and not batch256 and not dense
+        line.update(ident)
         roof = line['roofline']
         mode = args.traffic
         if mode == 'auto':
@@ -645,7 +721,7 @@ def main():
             else:
                 roof['traffic_measure_error'] = detail
                 mode = 'committed'
-        if mode == 'committed' and not batch256:
+        if mode == 'committed' and not batch256 and not dense:
             c = committed_traffic()
             if c is not None:
                 roof['traffic'], roof['traffic_source'] = c[0], f'committed profile {c[1]}'
@@ -659,7 +735,7 @@ def main():
             line['also_measured'] = other_regimes(synth_state_dict(0), dev)
             roof['batched_frac'] = line['also_measured']['batch_32_pairs_x_1000_queries']['frac_of_fp32_mfma_peak']
             roof['batched_frac_note'] = 'same path at 32 pairs x 1000 queries per call (throughput regime)'
-        if world == 1 and not args.no_cpu_baseline and not batch256:
+        if world == 1 and not args.no_cpu_baseline and not batch256 and not dense:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

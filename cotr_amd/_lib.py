@@ -10,7 +10,7 @@ import os
 
 import torch  # noqa: F401  (must be imported before the HIP library is opened)
 
-from .build import LIB
+from .build import LIB, LIB_EXP
 
 c_float_p = ctypes.c_void_p  # raw device/host addresses from tensor.data_ptr()
 
@@ -50,7 +50,6 @@ _PROTOS = {
     'cotr_op_attention_fused': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_float,
                                                c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p, c_float_p,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    'cotr_op_dec_head': (ctypes.c_int, [c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_ln_reduce': (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                          ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_layernorm': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
@@ -97,42 +96,18 @@ _PROTOS = {
                                         c_float_p, c_float_p, ctypes.c_void_p]),
     'cotr_resize_f32': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p]),
-    'cotr_set_encode_chunk': (ctypes.c_int, [ctypes.c_int]),
     'cotr_gemm_num_configs': (ctypes.c_int, []),
-    'cotr_set_ffn_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_attention_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_head_fusion_max_rows': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_attention_splits': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_attention_fused_splits': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_attention_wide_min_rows': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_pos_table_min_rows': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_conv_patch': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_attention_wide_occupancy': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_xcd_mapping': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_fused_stem': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_dual_conv': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_ks3': (ctypes.c_int, [ctypes.c_int]),
     'cotr_op_conv_dual_cfg': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, c_float_p, c_float_p, c_float_p, ctypes.c_int, c_float_p,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    'cotr_set_ffn_tail': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_conv1x1_dense': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_ws_flags': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_coop_tail': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_coop_tail_spin': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_train_attention_form': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_attention_resident': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_set_gemm_ln_min_rows': (ctypes.c_int, [ctypes.c_int]),
-    'cotr_op_linear_ln': (ctypes.c_int, [c_float_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    'cotr_set_bottleneck_max_pairs': (ctypes.c_int, [ctypes.c_int]),
     'cotr_op_bottleneck': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int] + [c_float_p] * 12 + [ctypes.c_void_p]),
     'cotr_knob_count': (ctypes.c_int, []),
     'cotr_knob_name': (ctypes.c_char_p, [ctypes.c_int]),
-    'cotr_get_knob': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
-    'cotr_set_knob': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
-    'cotr_reset_knobs': (ctypes.c_int, []),
-    'cotr_set_ffn_preln': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_get_knob': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    'cotr_set_knob': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),
+    'cotr_reset_knobs': (ctypes.c_int, [ctypes.c_void_p]),
+    'cotr_is_experimental': (ctypes.c_int, []),
     'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
     'cotr_bench_conv': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 9 +
@@ -148,7 +123,15 @@ _PROTOS = {
                               [ctypes.c_void_p, ctypes.c_void_p]),
 }
 
+# exported by libcotr_hip_exp.so only (the experimental build: cotr_amd/csrc/experimental/)
+_EXP_PROTOS = {
+    'cotr_op_dec_head': (ctypes.c_int, [c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_linear_ln': (ctypes.c_int, [c_float_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+}
+
 EXPORTED_SYMBOLS = tuple(_PROTOS)
+EXPERIMENTAL_SYMBOLS = tuple(_EXP_PROTOS)
+ABI_VERSION = 2
 _lib = None
 
 
@@ -156,22 +139,39 @@ class CotrHipError(RuntimeError):
     pass
 
 
+def experimental_selected():
+    """COTR_HIP_EXPERIMENTAL=1 in the environment makes this PROCESS load libcotr_hip_exp.so (the product library plus the
+    measured dead ends and their knobs) instead of libcotr_hip.so: tests/test_experimental_gpu.py and A/B tools only."""
+    return os.environ.get('COTR_HIP_EXPERIMENTAL', '0') not in ('', '0')
+
+
+def library_path():
+    return LIB_EXP if experimental_selected() else LIB
+
+
 def load_library():
     """Open libcotr_hip.so and declare every prototype; raises if it is absent."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
+    path = library_path()
+    if not os.path.exists(path):
         raise CotrHipError(
-            f'{LIB} is missing: build it with `python -m cotr_amd.build` (or __graft_entry__.build()). '
-            'cotr_amd has no CPU or PyTorch fallback for the forward path.')
-    lib = ctypes.CDLL(LIB)
-    for name, (res, args) in _PROTOS.items():
+            f'{path} is missing: build it with `python -m cotr_amd.build{" --experimental" if experimental_selected() else ""}` '
+            '(or __graft_entry__.build()). cotr_amd has no CPU or PyTorch fallback for the forward path.')
+    lib = ctypes.CDLL(path)
+    protos = dict(_PROTOS)
+    if experimental_selected():
+        protos.update(_EXP_PROTOS)
+    for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.cotr_abi_version() != 1:
-        raise CotrHipError('libcotr_hip.so ABI version mismatch; rebuild with `python -m cotr_amd.build --force`')
+    if lib.cotr_abi_version() != ABI_VERSION:
+        raise CotrHipError(f'{os.path.basename(path)} has ABI version {lib.cotr_abi_version()}, this binding needs {ABI_VERSION}; '
+                           'rebuild with `python -m cotr_amd.build --force`')
+    if bool(lib.cotr_is_experimental()) != experimental_selected():
+        raise CotrHipError(f'{path}: experimental flag of the library does not match the file name')
     _lib = lib
     return lib
 
@@ -194,23 +194,27 @@ def current_stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def knobs():
-    """{name: (current, default)} of every process-wide tuning switch of the library (cotr_set_<name>)."""
+def _h(handle):
+    return handle if handle is None or isinstance(handle, ctypes.c_void_p) else ctypes.c_void_p(handle)
+
+
+def knobs(handle=None):
+    """{name: (current, default)} of every tuning knob of a handle (cotr_set_knob(h, ...)); handle None = the process-wide
+    set of the handle-less op-level entry points (cotr_op_*, cotr_bench_*, cotr_train_*)."""
     lib = load_library()
     out = {}
     for i in range(lib.cotr_knob_count()):
         name = lib.cotr_knob_name(i)
         cur, dflt = ctypes.c_int(), ctypes.c_int()
-        check(lib.cotr_get_knob(name, ctypes.byref(cur), ctypes.byref(dflt)), None, 'cotr_get_knob')
+        check(lib.cotr_get_knob(_h(handle), name, ctypes.byref(cur), ctypes.byref(dflt)), handle, 'cotr_get_knob')
         out[name.decode()] = (cur.value, dflt.value)
     return out
 
 
-def set_knob(name, value):
-    check(load_library().cotr_set_knob(name.encode(), int(value)), None, f'cotr_set_knob({name}, {value})')
+def set_knob(name, value, handle=None):
+    check(load_library().cotr_set_knob(_h(handle), name.encode(), int(value)), handle, f'cotr_set_knob({name}, {value})')
 
 
-def reset_knobs():
-    """Every tuning switch back to its shipped default (tests call this after each test that touched one)."""
-    check(load_library().cotr_reset_knobs(), None, 'cotr_reset_knobs')
-
+def reset_knobs(handle=None):
+    """Every knob of the set back to its shipped default (tests call this for the process-wide set after each GPU test)."""
+    check(load_library().cotr_reset_knobs(_h(handle)), handle, 'cotr_reset_knobs')

@@ -1,6 +1,6 @@
 """Build libcotr_hip.so (gfx950) in-tree with hipcc.
 
-    python -m cotr_amd.build [--force]
+    python -m cotr_amd.build [--force] [--experimental | --experimental-only]
 
 The shared object lands next to the sources (``cotr_amd/csrc/libcotr_hip.so``): it is
 git-ignored but travels with the gpurun snapshot, so the GPU box never compiles.
@@ -13,10 +13,18 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcotr_hip.so')
-SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'gemm_ln.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip', 'dense_post.hip', 'ffn.hip', 'head.hip', 'train.hip', 'attention_train.hip', 'api.hip']
-# Pillow-exact resamples (8-bit and float): double-precision coefficient code must not be contracted into FMAs
+# the experimental build: the same sources with -DCOTR_EXPERIMENTAL plus csrc/experimental/*.hip - the measured dead ends (cooperative
+# tails, fused decoder head, GEMM + LayerNorm tile, FFN tail / pre-norm, three-stage large tiles) and their knobs.  Never loaded by the
+# product path; tests/test_experimental_gpu.py and the A/B tools select it with COTR_HIP_EXPERIMENTAL=1.
+LIB_EXP = os.path.join(CSRC, 'libcotr_hip_exp.so')
+SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip',
+           'dense_post.hip', 'ffn.hip', 'train.hip', 'attention_train.hip', 'api.hip']
+EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip')]
+# Pillow-exact resamples and the torch-CPU-exact cycle map (8-bit, float and double code whose products must not be contracted into
+# FMAs behind the source's back; the FMAs that belong there are explicit)
 EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ffp-contract=off']}
 HEADERS = ['common.h', 'train.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
+EXP_HEADERS = [os.path.join('experimental', f) for f in ('coop_tail.h', 'experimental.h', 'api_exp.inc')]
 # code-object v5: loadable by the ROCm 7.0 runtime torch bundles as well as by ROCm 7.2's
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-mcode-object-version=5',
          '-Wall', '-Wno-unused-function']
@@ -29,24 +37,29 @@ def _hipcc():
     return exe
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def needs_build(experimental=False):
+    lib = LIB_EXP if experimental else LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + (EXP_SOURCES + EXP_HEADERS if experimental else [])]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link the C-ABI shared library. Returns its path."""
-    if not force and not needs_build():
-        return LIB
+def build_library(force=False, verbose=False, experimental=False):
+    """Compile every HIP source for gfx950 and link the C-ABI shared library (the experimental one with experimental=True).
+    Returns its path."""
+    lib = LIB_EXP if experimental else LIB
+    if not force and not needs_build(experimental):
+        return lib
     hipcc = _hipcc()
+    objdir = os.path.join(CSRC, 'experimental', 'obj') if experimental else CSRC
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+    for src in SOURCES + (EXP_SOURCES if experimental else []):
+        obj = os.path.join(objdir, os.path.basename(src).replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + (['-DCOTR_EXPERIMENTAL'] if experimental else []) + EXTRA_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -57,12 +70,16 @@ def build_library(force=False, verbose=False):
             raise RuntimeError(f'hipcc failed on {src}:\n{out}')
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}')
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    print(build_library(force='--force' in sys.argv, verbose=True))
+    force = '--force' in sys.argv
+    if '--experimental-only' not in sys.argv:
+        print(build_library(force=force, verbose=True))
+    if '--experimental' in sys.argv or '--experimental-only' in sys.argv:
+        print(build_library(force=force, verbose=True, experimental=True))

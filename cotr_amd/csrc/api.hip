@@ -22,25 +22,20 @@
 #include <string>
 #include <vector>
 
+#include <limits.h>
+
 #include "../../include/cotr_hip.h"
 #include "common.h"
-#include "coop_tail.h"
 #include "train.h"
 
 int init_attention_attributes();
-void set_attention_splits(int ns);
-void set_attention_fused_splits(int v);
 void set_ffn_debug_times(unsigned long long* p);  // ffn.hip
 void set_attention_debug_times(unsigned long long* p);  // attention.hip
-void set_attention_wide_min_rows(long v);
-void set_attention_resident(int v);
-void set_attention_wide_occupancy(int v);
 
 namespace {
 
 constexpr int D = 256, FFN = 1024, TOK = 512, CFEAT = 1024;
-constexpr int ENC_CHUNK_MAX = 128; // largest settable chunk (scratch ~66 MB per pair of a pass: 8.4 GB at 128 - of 288 GB)
-int g_enc_chunk = 64;             // pairs per pass actually used (tuning knob, <= ENC_CHUNK_MAX).  Measured (tools/ab_enc_chunk.py): 64 pairs per pass run 2-3 % faster than 32 from 64 pairs up (layer3 / the 256-wide projections then launch 512 workgroups instead of 256), 128 per pass 20 % slower; results identical
+constexpr int ENC_CHUNK_MAX = 128; // largest settable encode chunk (scratch ~66 MB per pair of a pass: 8.4 GB at 128 - of 288 GB)
 constexpr int DEC_ROWS = 32768;   // query rows per decoder pass (scratch ~9 KB per row)
 constexpr float QSCALE = 0.17677669529663687f;  // 32^-0.5, float(head_dim) ** -0.5 in torch
 
@@ -66,27 +61,72 @@ struct Arena {
 };
 
 thread_local std::string g_create_error;
-int g_head_fuse_max_rows = 0;     // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower at 1000 rows: 63 workgroups each pull all 512 KB of weights; off)
-int g_attn_fuse_max_rows = 1024;  // attention with the out-projection (and, in the decoder, the q projection) fused in, up to this many rows
-int g_pos_table_min_rows = 8192;  // token rows from which the encoder in-projection / decoder K-V projection take pos . W^T from the tables
-int g_coop_tail = 0;              // 1: the fused attention / FFN launches finish their row tiles themselves (coop_tail.h) instead of 24 ln_reduce launches; correct and schedule-independent, but measured SLOWER: 1000.7 vs 823.7 us per forward (+7.4 us per tail: arrive, poll, claim and the sc1 partial reads are four dependent memory-side round trips of 1-2 us each against 1.7 us of dispatch + 2.3 us of ln_reduce) - off
-int g_coop_tail_spin = 4000;      // polls (~0.3 us each) before a member workgroup leaves its share to the tile's last arriver
-int g_bottleneck_max_pairs = 4;   // layer1 bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass (measured: -4.3 % at 1 pair, -1.4 % at 4, 0 at 8, +1.4 % at 32 - the halo recompute of conv1 - tools/ab_bottleneck.py); 0 = never
-int g_ffn_fuse_max_rows = 1024;  // fused FFN block up to this many rows (forward at B=1,Q=1000: 1.064 vs 1.083 ms; slower from ~1300 rows on)
+
+// ---- tuning knobs (KnobId in common.h): name, shipped default, accepted range; a few have a value set instead of a range ----
+struct KnobDesc {
+  const char* name;
+  int def, lo, hi;
+};
+const KnobDesc kKnobs[KN_COUNT] = {
+    {"encode_chunk", 64, 1, ENC_CHUNK_MAX},
+    {"attention_fusion_max_rows", 1024, 0, INT_MAX},
+    {"ffn_fusion_max_rows", 1024, 0, INT_MAX},
+    {"ks3", 1, 0, 1},
+    {"dual_conv", 1, 0, 1},
+    {"fused_stem", 1, 0, 1},
+    {"xcd_mapping", 1, 0, 31},
+    {"attention_fused_splits", 0, 0, 84},
+    {"conv_patch", 1, 0, 1},
+    {"pos_table_min_rows", 8192, 0, INT_MAX},
+    {"attention_wide_occupancy", 3, 2, 3},
+    {"attention_wide_min_rows", 4096, 0, INT_MAX},
+    {"attention_splits", 0, 0, 16},
+    {"conv1x1_dense", 1, 0, 1},
+    {"ws_flags", 2, 0, 3},
+    {"bottleneck_max_pairs", 4, 0, INT_MAX},
+    {"train_attention_form", 0, 0, 3},
+    {"attention_resident", 1, 0, 1},
+#ifdef COTR_EXPERIMENTAL
+    {"head_fusion_max_rows", 0, 0, INT_MAX},
+    {"ffn_preln", 0, 0, 1},
+    {"ffn_tail", 0, 0, 1},
+    {"coop_tail", 0, 0, 1},
+    {"coop_tail_spin", 4000, 0, INT_MAX},
+    {"gemm_ln_min_rows", 1 << 30, 0, INT_MAX},
+#endif
+};
+bool knob_value_ok(int id, int v) {
+  if (v < kKnobs[id].lo || v > kKnobs[id].hi) return false;
+  if (id == KN_XCD_MAPPING) return (v & 3) != 3;
+  if (id == KN_ATTENTION_FUSED_SPLITS) return v == 0 || v == 4 || v == 8 || v == 48 || v == 84;
+  if (id == KN_ATTENTION_SPLITS) return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16;
+  return true;
+}
+KnobSet default_knobs() {
+  KnobSet k;
+  for (int i = 0; i < KN_COUNT; ++i) k.v[i] = kKnobs[i].def;
+  return k;
+}
+// the set of the handle-less op-level entry points (cotr_op_*, cotr_bench_*, cotr_train_*); cotr_set_knob(NULL, ...)
+KnobSet g_process_knobs = default_knobs();
 }  // namespace
+thread_local const KnobSet* cotr_tls_knobs = &g_process_knobs;
 
 struct cotr_ctx {
   int device = 0;
   std::string err;
+  KnobSet knobs = default_knobs();   // this handle's tuning knobs (cotr_set_knob)
   // weights
   float* wbuf = nullptr;
   size_t wfloats = 0;
   bool loaded = false;
   std::vector<ConvW> convs;  // execution order: stem, then per block conv1, conv2, conv3, [downsample]
-  // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
-  // cooperative tails (coop_tail.h): generation-tagged arrival / claim words per row tile, and the launch counter that tags them
+#ifdef COTR_EXPERIMENTAL
+  // cooperative tails (experimental/coop_tail.h): generation-tagged arrival / claim words per row tile, and the launch counter that tags them
   unsigned long long* tail_state = nullptr;
   unsigned long long tail_gen = 0;
+#endif
+  // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
   struct FusedBlock { const float *w2p = nullptr, *w3p = nullptr, *wdp = nullptr; };
   FusedBlock l1_fused[3];
   const float *ip_w = nullptr, *ip_b = nullptr;
@@ -162,8 +202,15 @@ struct DeviceScope {
     if (switched && prev >= 0) (void)hipSetDevice(prev);
   }
 };
+// ... and the handle's knob set, for the launch helpers of every translation unit (knob(), common.h)
+struct KnobScope {
+  const KnobSet* prev;
+  explicit KnobScope(const KnobSet* k) : prev(cotr_tls_knobs) { cotr_tls_knobs = k; }
+  ~KnobScope() { cotr_tls_knobs = prev; }
+};
 #define DEVICE_SCOPE(h)                                                                  \
   DeviceScope dev_scope_((h)->device);                                                   \
+  KnobScope knob_scope_(&(h)->knobs);                                                    \
   do {                                                                                   \
     if (dev_scope_.err != hipSuccess) {                                                  \
       (h)->err = std::string("hipSetDevice: ") + hipGetErrorString(dev_scope_.err);      \
@@ -234,11 +281,6 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
   return COTR_OK;
 }
 
-bool g_fused_stem = true;  // cotr_set_fused_stem
-int g_gemm_ln_min_rows = 1 << 30;   // cotr_set_gemm_ln_min_rows: rows from which a 256-wide projection and the LayerNorm behind it are ONE launch (gemm_ln.hip: 128-row workgroups; sensible from 24576 rows).  OFF: in isolation -5 % (K = 256) / -8 % (K = 1024) against GEMM + layernorm_kernel, in the forward nothing (dense pass 14.74 vs 14.65 ms, 32 pairs x 1000: 11.15 vs 11.08 ms) - the 128 x 256 tile at one wavefront per SIMD loses in the K loop what the saved launch and the 2 x 33 MB of pre-norm traffic (L2 / Infinity-Cache hits anyway) gave
-bool g_ffn_tail = false;   // cotr_set_ffn_tail: measured slower, off
-bool g_ffn_preln = false;  // cotr_set_ffn_preln: the norm before the FFN folded into the fused FFN block (measured neutral, off)
-
 GemmParams base_params() {
   GemmParams p;
   memset(&p, 0, sizeof(p));
@@ -269,89 +311,32 @@ int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float
   return COTR_OK;
 }
 
-CoopTail make_tail(cotr_ctx* h, const float* bias, const float* residual, const float* w, const float* b, const float* post_w,
-                   const float* post_b, float* y) {
-  CoopTail ct;
-  ct.state = h->tail_state;
-  ct.gen = ++h->tail_gen;
-  ct.spin_limit = g_coop_tail_spin;
-  ct.bias = bias; ct.residual = residual; ct.w = w; ct.b = b; ct.post_w = post_w; ct.post_b = post_b; ct.y = y;
-  return ct;
-}
-bool coop_tail_ok(int nch) { return g_coop_tail && (nch == 8 || nch == 16); }
-
-// y = LayerNorm(x . w^T + bias + residual) for a 256-wide projection: one launch from g_gemm_ln_min_rows rows (gemm_ln.hip), else the
-// GEMM into `tmp` and layernorm_kernel - bit-identical either way
-int linear_ln(cotr_ctx* h, const float* x, const float* w, const float* bias, const float* residual, const float* nw, const float* nb,
-              float* tmp, float* y, int M, int K, hipStream_t s) {
-  if (M >= g_gemm_ln_min_rows) {
-    KCHK(h, launch_gemm_ln(x, K, w, bias, residual, D, nw, nb, y, M, K, s), "linear+layernorm");
-    if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear+ln %dx%dx%d", M, D, K); prof_mark(h, nm, s, 2); }
-    return COTR_OK;
-  }
-  if (int r = linear(h, x, nullptr, 0, 1, 0, w, bias, residual, 0, 1.f, 0, tmp, M, D, K, s)) return r;
-  return layernorm(h, tmp, nw, nb, y, M, s);
-}
+#ifdef COTR_EXPERIMENTAL
+#include "experimental/api_exp.inc"   // the measured dead ends: hooks exp_ffn_block / exp_encoder_layer / exp_decoder_layer / exp_decoder_head
+#endif
 
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
-// Up to g_ffn_fuse_max_rows rows: ONE fused launch that keeps the hidden activations on the CU and writes per-chunk
-// partial outputs + ln_reduce (sum, bias, residual, norm); above: linear1, linear2 (+residual), layernorm.
-// `hid` holds max(M*1024, chunks*M*256) floats, `tmp` M*256.
+// Up to knob ffn_fusion_max_rows rows: ONE fused launch that keeps the hidden activations on the CU and writes per-chunk
+// partial outputs + ln_reduce (sum, bias, residual, norm [, a second norm: decoder.norm after the last layer]); above: linear1,
+// linear2 (+residual), layernorm.  `hid` holds max(M*1024, chunks*M*256) floats, `tmp` M*256.  post_w only with M <= the threshold.
 int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, const float* l2w, const float* l2b,
               const float* nw, const float* nb, float* hid, float* tmp, float* y, int M, hipStream_t s,
               const float* post_w = nullptr, const float* post_b = nullptr) {
-  if (post_w != nullptr) {   // (callers check ffn_block_takes_post_norm first)
+#ifdef COTR_EXPERIMENTAL
+  if (const int rx = exp_ffn_block(h, x, l1w, l1b, l2w, l2b, nw, nb, hid, tmp, y, M, s, post_w, post_b)) return rx < 0 ? rx : COTR_OK;
+#endif
+  if (post_w != nullptr || M <= knob(KN_FFN_FUSION_MAX_ROWS)) {
     const int nch = ffn_fused_chunks(M);
-    if (coop_tail_ok(nch)) {
-      KCHK(h, launch_ffn_fused_coop(x, l1w, l1b, l2w, hid, M, nch, make_tail(h, l2b, x, nw, nb, post_w, post_b, y), s), "ffn_fused+tail");
-      if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused+tail+norm %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
-      return COTR_OK;
-    }
     KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
     if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
     KCHK(h, launch_ln_reduce_post(hid, nch, l2b, x, nw, nb, post_w, post_b, y, M, s), "ln_reduce");
-    prof_mark(h, "ln_reduce +norm", s, 2);
-    return COTR_OK;
-  }
-  if (M <= g_ffn_fuse_max_rows) {
-    const int nch = ffn_fused_chunks(M);
-    if (g_ffn_tail) {  // partial sums + bias + residual + LayerNorm by the last workgroup of each row tile: one launch
-      KCHK(h, launch_ffn_fused_ln(x, l1w, l1b, l2w, hid, M, nch, l2b, x, nw, nb, y, s), "ffn_fused_ln");
-      if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused+ln %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
-      return COTR_OK;
-    }
-    if (coop_tail_ok(nch)) {
-      KCHK(h, launch_ffn_fused_coop(x, l1w, l1b, l2w, hid, M, nch, make_tail(h, l2b, x, nw, nb, nullptr, nullptr, y), s), "ffn_fused+tail");
-      if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused+tail %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
-      return COTR_OK;
-    }
-    KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
-    if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
-    KCHK(h, launch_ln_reduce(hid, nch, l2b, x, nw, nb, y, M, s), "ln_reduce");
-    prof_mark(h, "ln_reduce", s, 2);
+    prof_mark(h, post_w ? "ln_reduce +norm" : "ln_reduce", s, 2);
     return COTR_OK;
   }
   int r;
   if ((r = linear(h, x, nullptr, 0, 1, 0, l1w, l1b, nullptr, 1, 1.f, 0, hid, M, FFN, D, s))) return r;
-  return linear_ln(h, hid, l2w, l2b, x, nw, nb, tmp, y, M, FFN, s);
-}
-
-// y = LN_post(x1 + FFN(x1)) with x1 = LN_pre(xpre): the norm after the attention sub-layer folded into the fused FFN block
-// (its only consumers are the FFN input and the FFN residual), so that norm never gets its own launch.  x1buf / tmp are
-// scratch for the unfused fallback (more than g_ffn_fuse_max_rows rows).
-int ffn_block_pre(cotr_ctx* h, const float* xpre, const float* pre_w, const float* pre_b, const float* l1w, const float* l1b,
-                  const float* l2w, const float* l2b, const float* nw, const float* nb, float* hid, float* x1buf, float* tmp,
-                  float* y, int M, hipStream_t s) {
-  if (g_ffn_preln && !g_ffn_tail && M <= g_ffn_fuse_max_rows) {
-    const int nch = ffn_fused_chunks(M);
-    KCHK(h, launch_ffn_fused_pre(xpre, pre_w, pre_b, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
-    if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused ln+%d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
-    KCHK(h, launch_ln_reduce_pre(hid, nch, l2b, xpre, pre_w, pre_b, nw, nb, y, M, s), "ln_reduce");
-    prof_mark(h, "ln_reduce", s, 2);
-    return COTR_OK;
-  }
-  if (int r = layernorm(h, xpre, pre_w, pre_b, x1buf, M, s)) return r;
-  return ffn_block(h, x1buf, l1w, l1b, l2w, l2b, nw, nb, hid, tmp, y, M, s);
+  if ((r = linear(h, hid, nullptr, 0, 1, 0, l2w, l2b, x, 0, 1.f, 0, tmp, M, D, FFN, s))) return r;
+  return layernorm(h, tmp, nw, nb, y, M, s);
 }
 
 GemmParams conv_params(const ConvW& c, const float* x, const float* residual, int relu, float* y, int B, int Hin, int Win) {
@@ -368,14 +353,12 @@ GemmParams conv_params(const ConvW& c, const float* x, const float* residual, in
   return p;
 }
 
-bool g_dual_conv = true;  // cotr_set_dual_conv
-
 // Entry block of a ResNet stage: the downsample branch and conv1 both read the block input (torchvision Bottleneck.forward)
 // and are independent - in the latency-bound regime (a pair or two per pass) they go out as ONE launch whose grid is the
 // tiles of both problems.  Returns 1 if it launched them, 0 if the caller should launch them one by one, < 0 on error.
 int conv_pair(cotr_ctx* h, const ConvW& cd, const ConvW& c1, const float* x, float* yd, float* y1, int B, int Hin, int Win,
               hipStream_t s) {
-  if (!g_dual_conv) return 0;
+  if (!knob(KN_DUAL_CONV)) return 0;
   const GemmParams pd = conv_params(cd, x, nullptr, 0, yd, B, Hin, Win), p1 = conv_params(c1, x, nullptr, 1, y1, B, Hin, Win);
   if (p1.M > 16384) return 0;   // batched: throughput-bound, each problem keeps its own best configuration
   const int cfd = gemm_pick_config(GEMM_CONV, pd), cf1 = gemm_pick_config(GEMM_CONV, p1);
@@ -452,12 +435,14 @@ int cotr_create(cotr_handle* out, int device) {
   }
   cotr_ctx* h = new cotr_ctx();
   h->device = device;
+#ifdef COTR_EXPERIMENTAL
   constexpr size_t kTailBytes = (size_t)1024 * COOP_WORDS * sizeof(unsigned long long);   // <= 1024 rows fused: <= 1024 row tiles
   if (hipMalloc(reinterpret_cast<void**>(&h->tail_state), kTailBytes) != hipSuccess || hipMemset(h->tail_state, 0, kTailBytes) != hipSuccess) {
     g_create_error = "allocating the cooperative-tail state failed";
     delete h;
     return COTR_ERR_HIP;
   }
+#endif
   if (hipMalloc(reinterpret_cast<void**>(&h->pos), (size_t)TOK * D * sizeof(float)) != hipSuccess ||
       launch_pos_table(h->pos, nullptr) != 0 || hipStreamSynchronize(nullptr) != hipSuccess) {
     g_create_error = "building the image position table failed";
@@ -475,7 +460,9 @@ void cotr_destroy(cotr_handle h) {
   prof_reset(h);
   if (h->wbuf) (void)hipFree(h->wbuf);
   if (h->pos) (void)hipFree(h->pos);
+#ifdef COTR_EXPERIMENTAL
   if (h->tail_state) (void)hipFree(h->tail_state);
+#endif
   for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr})
     if (a->ptr && !a->external) (void)hipFree(a->ptr);
   for (auto& kv : h->tap_store)
@@ -714,7 +701,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   float* memory = h->memkv.ptr;
   float* kv = h->memkv.ptr + (size_t)B * TOK * D;
 
-  const int ENC_CHUNK = g_enc_chunk;
+  const int ENC_CHUNK = knob(KN_ENCODE_CHUNK);
   const int Bc_max = B < ENC_CHUNK ? B : ENC_CHUNK;
   // scratch carve (floats per pair)
   const size_t n_stem = (size_t)128 * 256 * 64, n_pool = (size_t)64 * 128 * 64, n_act = (size_t)64 * 128 * 256;
@@ -722,7 +709,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   const size_t per_pair = n_stem + n_pool + 5 * n_act + 6 * n_tok + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
   // per-head partial outputs of the fused attention + out_proj launch (small-row regime only); a buffer of their own: the
   // fused FFN's partials (t_hid) are written with write-through stores right after these were read
-  const size_t n_part = (Bc_max * TOK <= g_attn_fuse_max_rows) ? (size_t)8 * Bc_max * n_tok : 0;
+  const size_t n_part = (Bc_max * TOK <= knob(KN_ATTENTION_FUSION_MAX_ROWS)) ? (size_t)8 * Bc_max * n_tok : 0;
   {
     int r = ensure(h, h->enc_scr, per_pair * Bc_max + n_part);
     if (r) return r;
@@ -752,7 +739,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     const float* img_c = img + (size_t)b0 * 3 * 256 * 512;
     // ---- backbone -------------------------------------------------------------------------
     int ci = 0;
-    if (g_fused_stem && !h->keep_taps) {  // conv1 + bn1 + relu + maxpool in one launch; the 'stem' tap needs the unfused pair
+    if (knob(KN_FUSED_STEM) && !h->keep_taps) {  // conv1 + bn1 + relu + maxpool in one launch; the 'stem' tap needs the unfused pair
       const ConvW& c0 = h->convs[ci++];
       KCHK(h, launch_stem_pool(img_c, c0.w, 160, c0.scale, c0.bias, b_pool, Bc, s), "stem_pool");
       prof_mark(h, "stem_pool conv7x7+bn+relu+maxpool", s, 2);
@@ -777,7 +764,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
         float* y = outbuf[flip];
         flip ^= 1;
         int r;
-        if (st == 0 && Bc <= g_bottleneck_max_pairs && H == 64 && W == 64) {
+        if (st == 0 && Bc <= knob(KN_BOTTLENECK_MAX_PAIRS) && H == 64 && W == 64) {
           // the whole bottleneck - conv1, conv2, conv3, (downsample,) FrozenBN, identity, ReLU - in one launch (bottleneck.hip)
           const ConvW* cd = (b == 0) ? &h->convs[ci++] : nullptr;
           KCHK(h, launch_bottleneck(x, y, Bc, c1.cin, c1.w, h->l1_fused[b].w2p, h->l1_fused[b].w3p, h->l1_fused[b].wdp, c1.scale,
@@ -826,46 +813,41 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     for (size_t li = 0; li < h->enc.size(); ++li) {
       const EncW& e = h->enc[li];
       // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
-      if (M >= g_pos_table_min_rows) {
+      if (M >= knob(KN_POS_TABLE_MIN_ROWS)) {
         if ((r = linear(h, xin, nullptr, 0, 1, 0, e.in_w, e.in_b, h->tab_qkv + li * TOK * 3 * D, 0, QSCALE, D, t_qkv, M, 3 * D, D, s, 0, TOK)))
           return r;
       } else if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
       float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
-      if (n_part != 0 && M <= g_attn_fuse_max_rows && M <= g_ffn_fuse_max_rows && !g_ffn_preln) {
-        // out_proj inside the attention kernel (8 per-head partial outputs), summed + bias + residual + norm1 by ln_reduce
-        if (g_coop_tail) {   // ... and the 8 head workgroups of a query tile do that sum + norm1 themselves (coop_tail.h)
-          const CoopTail ct = make_tail(h, e.out_b, xin, e.n1w, e.n1b, nullptr, nullptr, t_x1);
-          KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
-                                         nullptr, 0, e.out_w, t_part, Bc, TOK, s, &ct), "attention+out_proj+tail");
-          prof_mark(h, "attention+oproj+tail enc", s, 2);
-        } else {
-          KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
-                                         nullptr, 0, e.out_w, t_part, Bc, TOK, s), "attention+out_proj");
-          prof_mark(h, "attention+oproj enc", s, 2);
-          KCHK(h, launch_ln_reduce(t_part, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
-          prof_mark(h, "ln_reduce heads", s, 2);
-        }
-        if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_tmp, y, M, s))) return r;
+      bool fused = n_part != 0 && M <= knob(KN_ATTENTION_FUSION_MAX_ROWS) && M <= knob(KN_FFN_FUSION_MAX_ROWS);
+#ifdef COTR_EXPERIMENTAL
+      if (const int rx = exp_encoder_layer(h, e, xin, y, fused, t_qkv, t_part, t_x1, t_hid, t_tmp, t_ao, Bc, M, s)) {
+        if (rx < 0) return rx;
+        xin = y;
+        continue;
+      }
+#endif
+      if (fused) {
+        // few rows: out_proj inside the attention kernel (8 per-head partial outputs), summed + bias + residual + norm1 by ln_reduce
+        KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
+                                       nullptr, 0, e.out_w, t_part, Bc, TOK, s), "attention+out_proj");
+        prof_mark(h, "attention+oproj enc", s, 2);
+        KCHK(h, launch_ln_reduce(t_part, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
+        prof_mark(h, "ln_reduce heads", s, 2);
       } else {
         KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
         prof_mark(h, "attention enc", s, 2);
-        if (M >= g_gemm_ln_min_rows && !g_ffn_preln) {   // out-projection + residual + norm1 in one launch; the FFN block takes the normed rows
-          if ((r = linear_ln(h, t_ao, e.out_w, e.out_b, xin, e.n1w, e.n1b, t_tmp, t_x1, M, D, s))) return r;
-          if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_ao, y, M, s))) return r;
-        } else {
-          if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
-          if ((r = ffn_block_pre(h, t_tmp, e.n1w, e.n1b, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, t_x1, t_ao, y, M, s)))
-            return r;
-        }
+        if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
+        if ((r = layernorm(h, t_tmp, e.n1w, e.n1b, t_x1, M, s))) return r;
       }
+      if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, fused ? t_tmp : t_ao, y, M, s))) return r;
       xin = y;
     }
     prof_mark(h, "encoder", s);
     // ---- decoder K/V of every layer: k = Wk(memory+pos), v = Wv(memory) (transformer.py:192-195)
     float* kv_c = kv + (size_t)b0 * TOK * KVLD;
     // (the hoisted K/V projection takes the table at any row count: 3072 columns fill the chip with large tiles even at one pair -
-    // 18 -> 14 us there; the encoder in-projections only from g_pos_table_min_rows on)
-    if (g_pos_table_min_rows < (1 << 30)) {
+    // 18 -> 14 us there; the encoder in-projections only from knob pos_table_min_rows on)
+    if (knob(KN_POS_TABLE_MIN_ROWS) < (1 << 30)) {
       if ((r = linear(h, mem_c, nullptr, 0, 1, 0, h->kv_w, h->kv_b, h->tab_kv, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s, 0, TOK))) return r;
     } else if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
     prof_mark(h, "dec_kv", s);
@@ -908,8 +890,8 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
   d.nb_max = B < pairs_per ? B : pairs_per;
   d.Rmax = (size_t)d.nb_max * d.q_chunk;
   d.single_chunk = d.nb_max >= B && d.q_chunk >= Q;
-  const size_t hid_per_row = d.Rmax <= (size_t)g_ffn_fuse_max_rows ? 4 * FFN : FFN;  // fused FFN: up to 16 partial outputs
-  const size_t part_per_row = d.Rmax <= (size_t)g_attn_fuse_max_rows ? 8 * D : 0;  // per-head partials of attention + out_proj
+  const size_t hid_per_row = d.Rmax <= (size_t)knob(KN_FFN_FUSION_MAX_ROWS) ? 4 * FFN : FFN;  // fused FFN: up to 16 partial outputs
+  const size_t part_per_row = d.Rmax <= (size_t)knob(KN_ATTENTION_FUSION_MAX_ROWS) ? 8 * D : 0;  // per-head partials of attention + out_proj
   int r = ensure(h, h->dec_scr, d.Rmax * (7 * D + hid_per_row + part_per_row));
   if (r) return r;
   float* p = h->dec_scr.ptr;
@@ -945,57 +927,50 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   const int KVLD = L * 2 * D;
   const int R = nb * nq;
   int r;
-  const bool fused = d.part != nullptr && R <= g_attn_fuse_max_rows && R <= g_ffn_fuse_max_rows && !g_ffn_preln;
+  bool fused = d.part != nullptr && R <= knob(KN_ATTENTION_FUSION_MAX_ROWS) && R <= knob(KN_FFN_FUSION_MAX_ROWS);
+#ifdef COTR_EXPERIMENTAL
+  fused = fused && !knob(KN_FFN_PRELN);
+#endif
   bool hs_normed = false;
   if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s, fused))) return r;
   // transformer.py:185-201 per layer (cross-attention only, post-norm)
   for (int li = 0; li < L; ++li) {
     const DecW& w = h->dec[li];
+    const float* kl = kv_c + (size_t)li * 2 * D;          // this layer's K (then V) columns of the hoisted projection
+    const float* tgt_in = li == 0 ? nullptr : d.tgt;      // tgt == 0 at layer 0 (transformer.py:54)
+#ifdef COTR_EXPERIMENTAL
+    if (const int rx = exp_decoder_layer(h, w, d, kl, KVLD, tgt_in, fused, li + 1 == L, hs_normed, nb, nq, R, s)) {
+      if (rx < 0) return rx;
+      continue;
+    }
+#endif
     if (fused) {
-      // q = Wq(tgt + query_pos) * 32^-0.5 in the attention kernel's prologue (tgt == 0 at layer 0, transformer.py:54), out_proj
-      // in its epilogue (8 per-head partials), then ln_reduce: sum + bias + residual + norm2; FFN block; 4 launches per layer
-      if (g_coop_tail) {
-        const CoopTail ct = make_tail(h, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, nullptr, nullptr, d.t2);
-        KCHK(h, launch_attention_fused(nullptr, 0, li == 0 ? nullptr : d.tgt, d.qpos, w.q_w, w.q_b, QSCALE,
-                                       kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, nullptr, 0, w.out_w, d.part,
-                                       nb, nq, s, &ct), "q_proj+attention+out_proj+tail");
-        prof_mark(h, "qproj+attention+oproj+tail dec", s, 2);
-      } else {
-        KCHK(h, launch_attention_fused(nullptr, 0, li == 0 ? nullptr : d.tgt, d.qpos, w.q_w, w.q_b, QSCALE,
-                                       kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, nullptr, 0, w.out_w, d.part,
-                                       nb, nq, s), "q_proj+attention+out_proj");
-        prof_mark(h, "qproj+attention+oproj dec", s, 2);
-        KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
-        prof_mark(h, "ln_reduce heads", s, 2);
-      }
-      // last layer: decoder.norm rides in the same ln_reduce launch (its input has no other consumer); pre2 = the normed 'hs'
-      const bool post = li + 1 == L && !g_ffn_tail && R > g_head_fuse_max_rows;
+      // few rows: q = Wq(tgt + query_pos) * 32^-0.5 in the attention kernel's prologue, out_proj in its epilogue (8 per-head
+      // partials), then ln_reduce: sum + bias + residual + norm2; FFN block; 4 launches per layer.  Last layer: decoder.norm rides
+      // in the FFN block's ln_reduce launch (its input has no other consumer); pre2 = the normed 'hs'
+      KCHK(h, launch_attention_fused(nullptr, 0, tgt_in, d.qpos, w.q_w, w.q_b, QSCALE, kl, kl + D, KVLD, nullptr, 0, w.out_w, d.part,
+                                     nb, nq, s), "q_proj+attention+out_proj");
+      prof_mark(h, "qproj+attention+oproj dec", s, 2);
+      KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, tgt_in, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
+      prof_mark(h, "ln_reduce heads", s, 2);
+      const bool post = li + 1 == L;
       if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
                          post ? h->dn_w : nullptr, post ? h->dn_b : nullptr))) return r;
       hs_normed = post;
-      continue;
-    }
-    // q = Wq(tgt + query_pos) * 32^-0.5 ; tgt == 0 at layer 0 (transformer.py:54): computed by dec_prologue
-    if (li > 0 && (r = linear(h, d.tgt, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s))) return r;
-    KCHK(h, launch_attention(d.q, D, kv_c + (size_t)li * 2 * D, kv_c + (size_t)li * 2 * D + D, KVLD, d.ao, D, nb, nq, s),
-         "attention");
-    prof_mark(h, "attention dec", s, 2);
-    if (R >= g_gemm_ln_min_rows && !g_ffn_preln) {
-      if ((r = linear_ln(h, d.ao, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, w.n2w, w.n2b, d.pre2, d.t2, R, D, s))) return r;
+    } else {
+      // q = Wq(tgt + query_pos) * 32^-0.5 (layer 0: computed by dec_prologue)
+      if (li > 0 && (r = linear(h, d.tgt, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s))) return r;
+      KCHK(h, launch_attention(d.q, D, kl, kl + D, KVLD, d.ao, D, nb, nq, s), "attention");
+      prof_mark(h, "attention dec", s, 2);
+      if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, tgt_in, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
+      if ((r = layernorm(h, d.pre2, w.n2w, w.n2b, d.t2, R, s))) return r;
       if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, d.tgt, R, s))) return r;
-      continue;
     }
-    if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, li == 0 ? nullptr : d.tgt, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
-    if ((r = ffn_block_pre(h, d.pre2, w.n2w, w.n2b, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.t2, d.pre3, d.tgt, R, s)))
-      return r;
   }
   // decoder.norm + corr_embed on the last layer only (the reference computes all 6 and keeps [-1])
-  if (R <= g_head_fuse_max_rows) {   // one row-local launch (head.hip); 'hs' is only written for the debug tap
-    KCHK(h, launch_dec_head(d.tgt, h->dn_w, h->dn_b, h->mlp_w[0], h->mlp_b[0], h->mlp_w[1], h->mlp_b[1], h->mlp_w[2], h->mlp_b[2],
-                            h->keep_taps ? d.pre2 : nullptr, odst, nb, nq, Q, s), "dec_head");
-    prof_mark(h, "dec_head norm+mlp", s, 2);
-    return COTR_OK;
-  }
+#ifdef COTR_EXPERIMENTAL
+  if (const int rx = exp_decoder_head(h, d, odst, nb, nq, Q, R, s)) return rx < 0 ? rx : COTR_OK;
+#endif
   if (!hs_normed && (r = layernorm(h, d.tgt, h->dn_w, h->dn_b, d.pre2, R, s))) return r;
   if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s))) return r;
   if ((r = linear(h, d.ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d.q, R, D, D, s))) return r;
@@ -1069,14 +1044,16 @@ int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, i
 int cotr_scratch_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   if (!h || !bytes || B <= 0 || Q < 0) return COTR_ERR_ARG;
   const size_t L = h->dec.empty() ? 6 : h->dec.size();
-  const size_t Bc = B < g_enc_chunk ? B : g_enc_chunk;
+  const int* kn = h->knobs.v;
+  const size_t Bc = B < kn[KN_ENCODE_CHUNK] ? B : kn[KN_ENCODE_CHUNK];
   const size_t per_pair = (size_t)128 * 256 * 64 + (size_t)64 * 128 * 64 + 5 * (size_t)64 * 128 * 256 +
                           6 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
   // Monotone in B and in Q, and an upper bound over the fusion thresholds' settings: a workspace sized for (B, Q) must serve
   // every (B' <= B, Q' <= Q) - whose decoder passes can have MORE rows than (B, Q)'s own (2 x 16000 rows against 1 x 20000)
   // and, below the thresholds, more scratch per row - and flipping a tuning knob must not make a sized workspace too small.
   const size_t R = (size_t)B * Q < (size_t)DEC_ROWS ? (size_t)B * Q : (size_t)DEC_ROWS;
-  const size_t thr_a = g_attn_fuse_max_rows > 1024 ? g_attn_fuse_max_rows : 1024, thr_f = g_ffn_fuse_max_rows > 1024 ? g_ffn_fuse_max_rows : 1024;
+  const size_t thr_a = kn[KN_ATTENTION_FUSION_MAX_ROWS] > 1024 ? kn[KN_ATTENTION_FUSION_MAX_ROWS] : 1024;
+  const size_t thr_f = kn[KN_FFN_FUSION_MAX_ROWS] > 1024 ? kn[KN_FFN_FUSION_MAX_ROWS] : 1024;
   const size_t f_memkv = (size_t)B * TOK * (D + L * 2 * D);
   const size_t enc_rows = Bc * TOK;
   const size_t f_enc = per_pair * Bc + 8 * (enc_rows < thr_a ? enc_rows : thr_a) * D;
@@ -1133,16 +1110,17 @@ int cotr_set_workspace(cotr_handle h, void* ws, size_t bytes, int keep_encode, c
 int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   if (!h || !bytes || B <= 0 || Q < 0) return COTR_ERR_ARG;
   const size_t L = h->dec.empty() ? 6 : h->dec.size();
-  const size_t Bc = B < g_enc_chunk ? B : g_enc_chunk;
+  const int* kn = h->knobs.v;
+  const size_t Bc = B < kn[KN_ENCODE_CHUNK] ? B : kn[KN_ENCODE_CHUNK];
   const size_t per_pair = (size_t)128 * 256 * 64 + (size_t)64 * 128 * 64 + 5 * (size_t)64 * 128 * 256 +
                           6 * (size_t)TOK * D + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
   const size_t q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
   const size_t pairs_per = (Q > 0 && Q < DEC_ROWS) ? (DEC_ROWS / Q) : 1;
   const size_t nb = (size_t)B < pairs_per ? B : pairs_per;
   size_t fl = h->wfloats + (size_t)TOK * D + (size_t)B * TOK * (D + L * 2 * D) + per_pair * Bc +
-              (Bc * TOK <= (size_t)g_attn_fuse_max_rows ? 8 * Bc * TOK * D : 0) +
-              nb * q_chunk * (7 * D + (nb * q_chunk <= (size_t)g_ffn_fuse_max_rows ? 4 * FFN : FFN) +
-                              (nb * q_chunk <= (size_t)g_attn_fuse_max_rows ? 8 * D : 0));
+              (Bc * TOK <= (size_t)kn[KN_ATTENTION_FUSION_MAX_ROWS] ? 8 * Bc * TOK * D : 0) +
+              nb * q_chunk * (7 * D + (nb * q_chunk <= (size_t)kn[KN_FFN_FUSION_MAX_ROWS] ? 4 * FFN : FFN) +
+                              (nb * q_chunk <= (size_t)kn[KN_ATTENTION_FUSION_MAX_ROWS] ? 8 * D : 0));
   *bytes = fl * sizeof(float);
   return COTR_OK;
 }
@@ -1250,12 +1228,14 @@ int cotr_op_attention_fused(const float* q, int ldq, const float* x, const float
                                        static_cast<hipStream_t>(stream)));
 }
 
+#ifdef COTR_EXPERIMENTAL
 int cotr_op_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
                      const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
                      cotr_stream stream) {
   if (!x || !nw || !nb || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out) return COTR_ERR_ARG;
   return op_ret(launch_dec_head(x, nw, nb, w0, b0, w1, b1, w2, b2, hs, out, nb_pairs, nq, q_total, static_cast<hipStream_t>(stream)));
 }
+#endif
 
 int cotr_op_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                       float* y, int rows, cotr_stream stream) {
@@ -1314,144 +1294,14 @@ static int bench_launches(int mode, int cfg, const GemmParams& p, int iters, flo
   return rc;
 }
 
-// ---- process-wide tuning knobs: one registry, so that a caller (tests, tools/ab_knobs.sh) can read a knob back, snapshot all of
-// them and put every one back to its shipped default (cotr_reset_knobs) instead of hand-written "restore" constants ----
-struct Knob {
-  const char* name;
-  int (*set)(int);
-  int def, cur;
-};
-Knob* knob_table(int* n);
-static void knob_record(const char* name, int v) {
-  int n = 0;
-  Knob* k = knob_table(&n);
-  for (int i = 0; i < n; ++i)
-    if (strcmp(k[i].name, name) == 0) k[i].cur = v;
-}
-
 int cotr_gemm_num_configs(void) { return gemm_num_configs(); }
 
-int cotr_set_encode_chunk(int pairs) {
-  if (pairs < 1 || pairs > ENC_CHUNK_MAX) return COTR_ERR_ARG;
-  g_enc_chunk = pairs;
-  knob_record("encode_chunk", pairs);
-  return COTR_OK;
-}
-
-int cotr_set_head_fusion_max_rows(int rows) {
-  g_head_fuse_max_rows = rows < 0 ? 0 : rows;
-  knob_record("head_fusion_max_rows", rows);
-  return COTR_OK;
-}
-
-int cotr_set_attention_fusion_max_rows(int rows) {
-  g_attn_fuse_max_rows = rows < 0 ? 0 : rows;
-  knob_record("attention_fusion_max_rows", rows);
-  return COTR_OK;
-}
-
-int cotr_set_ffn_fusion_max_rows(int rows) {
-  g_ffn_fuse_max_rows = rows < 0 ? 0 : rows;
-  knob_record("ffn_fusion_max_rows", rows);
-  return COTR_OK;
-}
-
-}  // extern "C"
-void set_attention_head_major(int v);  // attention.hip
-void set_ffn_chunk_major(int v);       // ffn.hip
-void set_ffn_write_through(int v);     // ffn.hip
-extern "C" {
-int cotr_set_ffn_preln(int enable) {
-  g_ffn_preln = enable != 0;
-  knob_record("ffn_preln", enable);
-  return COTR_OK;
-}
-
-int cotr_set_ffn_tail(int enable) {
-  g_ffn_tail = enable != 0;
-  knob_record("ffn_tail", enable);
-  return COTR_OK;
-}
-
-int cotr_set_ks3(int enable) {
-  gemm_set_ks3(enable != 0);
-  knob_record("ks3", enable);
-  return COTR_OK;
-}
-
-int cotr_set_dual_conv(int enable) {
-  g_dual_conv = enable != 0;
-  knob_record("dual_conv", enable);
-  return COTR_OK;
-}
-
-int cotr_set_fused_stem(int enable) {
-  g_fused_stem = enable != 0;
-  knob_record("fused_stem", enable);
-  return COTR_OK;
-}
-
-int cotr_set_xcd_mapping(int policy) {
-  if (policy < 0 || policy > 31 || (policy & 3) == 3) return COTR_ERR_ARG;
-  gemm_set_xcd_policy(policy & 3);
-  set_ffn_chunk_major((policy >> 2) & 1);
-  set_attention_head_major((policy >> 3) & 1);
-  set_ffn_write_through(((policy >> 4) & 1) == 0);   // bit 4 set = plain (write-back) stores for the FFN partial outputs
-  knob_record("xcd_mapping", policy);
-  return COTR_OK;
-}
-
-int cotr_set_attention_fused_splits(int ns) {
-  if (ns != 0 && ns != 4 && ns != 8 && ns != 48 && ns != 84) return COTR_ERR_ARG;
-  set_attention_fused_splits(ns);
-  knob_record("attention_fused_splits", ns);
-  return COTR_OK;
-}
-
-int cotr_set_conv_patch(int enable) {
-  gemm_set_patch(enable != 0);
-  knob_record("conv_patch", enable);
-  return COTR_OK;
-}
-
-int cotr_set_coop_tail(int enable) {
-  g_coop_tail = enable != 0;
-  knob_record("coop_tail", g_coop_tail);
-  return COTR_OK;
-}
-int cotr_set_coop_tail_spin(int polls) {
-  g_coop_tail_spin = polls < 0 ? 0 : polls;
-  knob_record("coop_tail_spin", g_coop_tail_spin);
-  return COTR_OK;
-}
-
-int cotr_set_gemm_ln_min_rows(int rows) {
-  g_gemm_ln_min_rows = rows < 0 ? 0 : rows;
-  knob_record("gemm_ln_min_rows", g_gemm_ln_min_rows);
-  return COTR_OK;
-}
+#ifdef COTR_EXPERIMENTAL
 int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const float* residual, const float* ln_w, const float* ln_b,
                       float* y, int M, int K, cotr_stream stream) {
   return op_ret(launch_gemm_ln(x, K, w, bias, residual, 256, ln_w, ln_b, y, M, K, static_cast<hipStream_t>(stream)));
 }
-int cotr_set_attention_resident(int enable) {
-  set_attention_resident(enable);
-  knob_record("attention_resident", enable != 0);
-  return COTR_OK;
-}
-int cotr_set_train_attention_form(int form) {
-  if (form < 0 || form > 3) return COTR_ERR_ARG;
-  train_set_attn_bwd_form(form);
-  knob_record("train_attention_form", form);
-  return COTR_OK;
-}
-
-int cotr_set_bottleneck_max_pairs(int pairs) {
-  g_bottleneck_max_pairs = pairs < 0 ? 0 : pairs;
-  knob_record("bottleneck_max_pairs", g_bottleneck_max_pairs);
-  return COTR_OK;
-}
-
+#endif
 // one layer1 bottleneck from UNPACKED weights (tests): w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wd [256][64] or NULL (device
 // pointers); packs the fragment images on the host and launches bottleneck.hip
 int cotr_op_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2, const float* w3, const float* wd,
@@ -1479,113 +1329,46 @@ int cotr_op_bottleneck(const float* x, float* y, int B, int cin, const float* w1
   return rc;
 }
 
-int cotr_set_ws_flags(int flags) {
-  if (flags < 0 || flags > 3) return COTR_ERR_ARG;
-  gemm_set_ws_flags(flags);
-  knob_record("ws_flags", flags);
+// ---- tuning knobs (KnobId / KnobSet in common.h, kKnobs above): per handle; h == NULL addresses the process-wide set that the
+// handle-less op-level entry points (cotr_op_*, cotr_bench_*, cotr_train_*) read ----
+static int knob_index(const char* name) {
+  if (name)
+    for (int i = 0; i < KN_COUNT; ++i)
+      if (strcmp(kKnobs[i].name, name) == 0) return i;
+  return -1;
+}
+int cotr_knob_count(void) { return KN_COUNT; }
+const char* cotr_knob_name(int i) { return (i >= 0 && i < KN_COUNT) ? kKnobs[i].name : nullptr; }
+int cotr_get_knob(cotr_handle h, const char* name, int* value, int* default_value) {
+  const int i = knob_index(name);
+  if (i < 0) return COTR_ERR_ARG;
+  if (value) *value = (h ? h->knobs : g_process_knobs).v[i];
+  if (default_value) *default_value = kKnobs[i].def;
   return COTR_OK;
 }
-
-int cotr_set_conv1x1_dense(int enable) {
-  gemm_set_conv1x1_dense(enable != 0);
-  knob_record("conv1x1_dense", enable != 0);
+int cotr_set_knob(cotr_handle h, const char* name, int value) {
+  const int i = knob_index(name);
+  if (i < 0) {
+    if (h) h->err = std::string("cotr_set_knob: no knob named ") + (name ? name : "(null)");
+    return COTR_ERR_ARG;
+  }
+  if (!knob_value_ok(i, value)) {
+    if (h) h->err = std::string("cotr_set_knob: value out of range for ") + name;
+    return COTR_ERR_ARG;
+  }
+  (h ? h->knobs : g_process_knobs).v[i] = value;
   return COTR_OK;
 }
-
-int cotr_set_pos_table_min_rows(int rows) {
-  g_pos_table_min_rows = rows < 0 ? 0 : rows;
-  knob_record("pos_table_min_rows", rows);
+int cotr_reset_knobs(cotr_handle h) {
+  (h ? h->knobs : g_process_knobs) = default_knobs();
   return COTR_OK;
 }
-
-int cotr_set_attention_wide_occupancy(int waves_per_simd) {
-  if (waves_per_simd != 2 && waves_per_simd != 3) return COTR_ERR_ARG;
-  set_attention_wide_occupancy(waves_per_simd);
-  knob_record("attention_wide_occupancy", waves_per_simd);
-  return COTR_OK;
-}
-
-int cotr_set_attention_wide_min_rows(int rows) {
-  set_attention_wide_min_rows(rows);
-  knob_record("attention_wide_min_rows", rows);
-  return COTR_OK;
-}
-
-int cotr_set_attention_splits(int ns) {
-  if (ns != 0 && ns != 1 && ns != 2 && ns != 4 && ns != 8 && ns != 16) return COTR_ERR_ARG;
-  set_attention_splits(ns);
-  knob_record("attention_splits", ns);
-  return COTR_OK;
-}
-
-}  // extern "C"
-Knob* knob_table(int* n) {
-  static Knob knobs[] = {
-      {"encode_chunk", cotr_set_encode_chunk, 64, 64},
-      {"head_fusion_max_rows", cotr_set_head_fusion_max_rows, 0, 0},
-      {"attention_fusion_max_rows", cotr_set_attention_fusion_max_rows, 1024, 1024},
-      {"ffn_fusion_max_rows", cotr_set_ffn_fusion_max_rows, 1024, 1024},
-      {"ffn_preln", cotr_set_ffn_preln, 0, 0},
-      {"ffn_tail", cotr_set_ffn_tail, 0, 0},
-      {"ks3", cotr_set_ks3, 1, 1},
-      {"dual_conv", cotr_set_dual_conv, 1, 1},
-      {"fused_stem", cotr_set_fused_stem, 1, 1},
-      {"xcd_mapping", cotr_set_xcd_mapping, 1, 1},
-      {"attention_fused_splits", cotr_set_attention_fused_splits, 0, 0},
-      {"conv_patch", cotr_set_conv_patch, 1, 1},
-      {"pos_table_min_rows", cotr_set_pos_table_min_rows, 8192, 8192},
-      {"attention_wide_occupancy", cotr_set_attention_wide_occupancy, 3, 3},
-      {"attention_wide_min_rows", cotr_set_attention_wide_min_rows, 4096, 4096},
-      {"attention_splits", cotr_set_attention_splits, 0, 0},
-      {"conv1x1_dense", cotr_set_conv1x1_dense, 1, 1},
-      {"ws_flags", cotr_set_ws_flags, 2, 2},
-      {"bottleneck_max_pairs", cotr_set_bottleneck_max_pairs, 4, 4},
-      {"coop_tail", cotr_set_coop_tail, 0, 0},
-      {"coop_tail_spin", cotr_set_coop_tail_spin, 4000, 4000},
-      {"train_attention_form", cotr_set_train_attention_form, 0, 0},
-      {"attention_resident", cotr_set_attention_resident, 1, 1},
-      {"gemm_ln_min_rows", cotr_set_gemm_ln_min_rows, 1 << 30, 1 << 30},
-  };
-  *n = (int)(sizeof(knobs) / sizeof(knobs[0]));
-  return knobs;
-}
-extern "C" {
-int cotr_knob_count(void) {
-  int n = 0;
-  (void)knob_table(&n);
-  return n;
-}
-const char* cotr_knob_name(int i) {
-  int n = 0;
-  Knob* k = knob_table(&n);
-  return (i >= 0 && i < n) ? k[i].name : nullptr;
-}
-int cotr_get_knob(const char* name, int* value, int* default_value) {
-  if (!name) return COTR_ERR_ARG;
-  int n = 0;
-  Knob* k = knob_table(&n);
-  for (int i = 0; i < n; ++i)
-    if (strcmp(k[i].name, name) == 0) {
-      if (value) *value = k[i].cur;
-      if (default_value) *default_value = k[i].def;
-      return COTR_OK;
-    }
-  return COTR_ERR_ARG;
-}
-int cotr_set_knob(const char* name, int value) {
-  if (!name) return COTR_ERR_ARG;
-  int n = 0;
-  Knob* k = knob_table(&n);
-  for (int i = 0; i < n; ++i)
-    if (strcmp(k[i].name, name) == 0) return k[i].set(value);
-  return COTR_ERR_ARG;
-}
-int cotr_reset_knobs(void) {
-  int n = 0, rc = COTR_OK;
-  Knob* k = knob_table(&n);
-  for (int i = 0; i < n; ++i)
-    if (int r = k[i].set(k[i].def)) rc = r;
-  return rc;
+int cotr_is_experimental(void) {
+#ifdef COTR_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 int cotr_bench_linear(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int cfg,
@@ -1811,7 +1594,9 @@ int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const fl
                       const float* ln_b, float* scratch, float* y, int M, cotr_stream stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nch = ffn_fused_chunks(M);
-  if (g_ffn_tail) return op_ret(launch_ffn_fused_ln(x, w1, b1, w2, scratch, M, nch, b2, x, ln_w, ln_b, y, s));
+#ifdef COTR_EXPERIMENTAL
+  if (knob(KN_FFN_TAIL)) return op_ret(launch_ffn_fused_ln(x, w1, b1, w2, scratch, M, nch, b2, x, ln_w, ln_b, y, s));
+#endif
   int r = launch_ffn_fused(x, w1, b1, w2, scratch, M, nch, s);
   if (r == 0) r = launch_ln_reduce(scratch, nch, b2, x, ln_w, ln_b, y, M, s);
   return op_ret(r);

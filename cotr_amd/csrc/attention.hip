@@ -20,7 +20,6 @@
 //   O^T += V_blk^T . P^T 16x v_mfma_f32_32x32x2_f32   (P registers feed the B operand directly)
 // The NS partial (max, sum, O^T) triples are merged through 17 KB of LDS in a fixed order.
 #include "common.h"
-#include "coop_tail.h"
 
 #define ATT_KEYS 512
 #define ATT_HD 32
@@ -45,7 +44,9 @@ struct AttnFuse {
   int rows_total;      // OP: rows of one partial
   int wt;              // OP: write-through (sc1) stores for the partials (read once, by every XCD)
   unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock): cotr_debug_attention_times
+#ifdef COTR_EXPERIMENTAL
   CoopTail ct;         // OP: ct.state != nullptr: the 8 head workgroups of a query tile also sum the partials + bias + residual + LayerNorm
+#endif
 };
 
 template <int NS, int QP, bool OP>   // QP: 0 = q given, 1 = project x, 2 = project x + x2
@@ -277,12 +278,14 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
       if (qo < nq) store_f32x4(pbase + (size_t)qo * 256 + sc, val, fz.wt != 0);
     }
     ATT_STAMP(5);
+#ifdef COTR_EXPERIMENTAL
     if (fz.ct.state != nullptr) {
       __shared__ int coop_flags[2];
       const int rem = nq - qtile * 32;
       coop_tail_run(fz.ct, fz.part, (size_t)fz.rows_total * 256, pair * qtiles + qtile, pair * nq + qtile * 32, rem < 32 ? rem : 32, head, 8,
                     coop_flags);
     }
+#endif
     if (o == nullptr) return;
   }
   for (int i = t; i < 256; i += NS * 64) {  // 32 rows x 128 B, one float4 per thread: coalesced row stores
@@ -584,25 +587,15 @@ __global__ __launch_bounds__(512) void attention_res_kernel(const float* __restr
 // 3 wavefronts per SIMD measured 162-164 us at 32768 query rows against 168-193 for 2 (and 206 for the 32-query kernel).  An in-wave
 // software pipeline pinned with sched_group_barrier (softmax of one tile between the MFMAs of the other) measured the same 164 us:
 // hipcc honours the pattern for the score MFMAs only, and three wavefronts per SIMD already interleave the phases in hardware.
-static int g_att_wide_occ = 3;  // set_attention_wide_occupancy
-void set_attention_wide_occupancy(int v) { g_att_wide_occ = v == 2 ? 2 : 3; }
-static int g_att_wide_head_major = 1;  // set_attention_wide_head_major
-void set_attention_wide_head_major(int v) { g_att_wide_head_major = v != 0; }
-static int g_att_resident = 1;   // K_h / V_h resident in LDS (attention_res_kernel) from attention_wide_min_rows rows and 256 queries per pair
-void set_attention_resident(int v) { g_att_resident = v != 0; }
-static long g_att_wide_min_rows = 4096;  // query rows of a launch from which the 64-query kernel is used (set_attention_wide_min_rows)
-void set_attention_wide_min_rows(long v) { g_att_wide_min_rows = v < 0 ? 0 : v; }
+// knobs: KN_ATTENTION_WIDE_OCCUPANCY (3), KN_ATTENTION_RESIDENT (K_h / V_h resident in LDS from KN_ATTENTION_WIDE_MIN_ROWS rows and
+// 256 queries per pair), KN_ATTENTION_WIDE_MIN_ROWS (4096: query rows of a launch from which the 64-query kernel is used)
+static const int g_att_wide_head_major = 1;
 
 static thread_local unsigned long long* g_att_dbg = nullptr;   // set_attention_debug_times
 void set_attention_debug_times(unsigned long long* p) { g_att_dbg = p; }
-static int g_att_splits = 0;  // 0 = automatic
-static int g_att_fused_splits = 0;  // 0 = default (4); set_attention_fused_splits
-void set_attention_fused_splits(int v) { g_att_fused_splits = (v == 4 || v == 8 || v == 48 || v == 84) ? v : 0; }  // 48 / 84: encoder (q given) / decoder (q projected) separately
-static int g_att_part_wt = 1;  // write-through stores for the out-projection partials (set_attention_part_wt)
-void set_attention_part_wt(int v) { g_att_part_wt = v; }
-static int g_att_head_major = 0;  // measured: -88 MB of fabric traffic per forward, +0.4 % time -> off (cotr_set_xcd_mapping bit 3)
-void set_attention_head_major(int v) { g_att_head_major = v; }
-void set_attention_splits(int ns) { g_att_splits = ns; }
+// knobs: KN_ATTENTION_SPLITS (0 = automatic), KN_ATTENTION_FUSED_SPLITS (0 = 4; 48 / 84: encoder (q given) / decoder (q projected)
+// separately), KN_XCD_MAPPING bit 3 = heads over XCDs (measured: -88 MB of fabric traffic per forward, +0.4 % time -> off)
+static const int g_att_part_wt = 1;  // write-through stores for the out-projection partials
 
 int init_attention_attributes() { return 0; }
 
@@ -610,7 +603,10 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
                      int nb, int nq, hipStream_t s) {
   if (nb <= 0 || nq <= 0) return 0;
   if (ldq % 4 || ldkv % 4 || ldo % 4) return -1;
-  int ns = g_att_splits;
+  int ns = knob(KN_ATTENTION_SPLITS);
+  const int g_att_head_major = (knob(KN_XCD_MAPPING) >> 3) & 1;
+  const long g_att_wide_min_rows = knob(KN_ATTENTION_WIDE_MIN_ROWS);
+  const int g_att_resident = knob(KN_ATTENTION_RESIDENT), g_att_wide_occ = knob(KN_ATTENTION_WIDE_OCCUPANCY) == 2 ? 2 : 3;
   // query tiles per workgroup: 32 (4 per wavefront) when that still gives every CU a workgroup, down to 8 (one per wavefront: K_h / V_h
   // are then fetched for 8 tiles only); fewer than 128 workgroups even so -> the 64-query kernel below
   const int res_tiles = (nq + 31) / 32;
@@ -666,12 +662,21 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
 
 // Attention with the q projection in the prologue (qp: x/x2/wq/bq/qscale, q unused) and / or the output projection in the
 // epilogue (op: partial outputs [8][nb*nq][256] to `part`, o may be nullptr).  4 key splits.
-int launch_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
-                           float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
-                           float* part, int nb, int nq, hipStream_t s, const CoopTail* ct) {
+#ifdef COTR_EXPERIMENTAL
+#define ATT_CT_PARAM , const CoopTail* ct
+#else
+#define ATT_CT_PARAM
+#endif
+static int attention_fused_impl(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                                float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                                float* part, int nb, int nq, hipStream_t s ATT_CT_PARAM) {
   if (nb <= 0 || nq <= 0) return 0;
   const bool qp = wq != nullptr, op = wo != nullptr;
+#ifdef COTR_EXPERIMENTAL
   if (ct != nullptr && !op) return -1;
+#endif
+  const int g_att_head_major = (knob(KN_XCD_MAPPING) >> 3) & 1;
+  const int g_att_fused_splits = knob(KN_ATTENTION_FUSED_SPLITS);
   if (ldkv % 4 || (o && ldo % 4) || (!qp && (q == nullptr || ldq % 4))) return -1;
   if (qp && (bq == nullptr || (x == nullptr && x2 == nullptr))) return -1;
   if (op && part == nullptr) return -1;
@@ -681,7 +686,9 @@ int launch_attention_fused(const float* q, int ldq, const float* x, const float*
   fz.x = x ? x : x2; fz.x2 = x ? x2 : nullptr; fz.wq = wq; fz.bq = bq; fz.qscale = qscale;
   fz.wo = wo; fz.part = part; fz.rows_total = nb * nq; fz.wt = g_att_part_wt;
   fz.dbg = g_att_dbg;
+#ifdef COTR_EXPERIMENTAL
   if (ct != nullptr) fz.ct = *ct;
+#endif
   const int qmode = !qp ? 0 : (fz.x2 ? 2 : 1);
   // 8 key splits (8 wavefronts per workgroup) were tried where 4 leave CUs without a workgroup (the encoder of one pair is
   // 16 query tiles x 8 heads = 128 workgroups on 256 CUs): measured 0.978 vs 0.973 ms per forward, the merge of 8 partial
@@ -704,3 +711,21 @@ int launch_attention_fused(const float* q, int ldq, const float* x, const float*
 #undef ATT_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+
+int launch_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                           float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                           float* part, int nb, int nq, hipStream_t s) {
+#ifdef COTR_EXPERIMENTAL
+  return attention_fused_impl(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, o, ldo, wo, part, nb, nq, s, nullptr);
+#else
+  return attention_fused_impl(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, o, ldo, wo, part, nb, nq, s);
+#endif
+}
+#ifdef COTR_EXPERIMENTAL
+// ... with the cooperative tail (experimental/coop_tail.h): the 8 head workgroups of a query tile finish the tile themselves
+int launch_attention_fused_coop(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                                float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                                float* part, int nb, int nq, hipStream_t s, const CoopTail* ct) {
+  return attention_fused_impl(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, o, ldo, wo, part, nb, nq, s, ct);
+}
+#endif

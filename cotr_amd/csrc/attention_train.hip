@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const float* __rest
 // kernels; 3: the backward in one pass (attn_bwd_fused_kernel); 0 (default): 3 where it is the faster one - enough (pair, head)
 // workgroups to fill the chip and enough query tiles to amortise parking K / V in LDS (encoder self-attention of a training batch:
 // 258 vs 347 us at 32 pairs x 512); with fewer pairs the keys of a head are split over 2 or 4 workgroups (attn_fused_kt) - else 2
-static int g_attn_bwd_form = 0;
+#define g_attn_bwd_form knob(KN_TRAIN_ATTENTION_FORM)
 // key tiles per wavefront of the one-pass backward (4: one workgroup per (pair, head); 2 / 1: two / four workgroups, each leaving a dQ
 // partial in `scratch` that train_sum_parts adds - the decoder's 16 pairs x 200 queries: 128 workgroups would leave half the chip idle),
 // 0: use the two-kernel second form.  The split forms need the scratch buffer and a contiguous dq.
@@ -937,8 +937,6 @@ static int attn_fused_kt(int nb, int nq, int lddq, const float* scratch) {
   if (nb * 32 >= 192 || g_attn_bwd_form == 3) return 1;
   return 0;
 }
-void train_set_attn_bwd_form(int v) { g_attn_bwd_form = (v >= 0 && v <= 3) ? v : 0; }
-int train_get_attn_bwd_form() { return g_attn_bwd_form; }
 
 int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
                         int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s) {

@@ -41,6 +41,50 @@ struct PerDeviceFlag {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Tuning knobs.  ONE set per handle (cotr_ctx::knobs; cotr_set_knob(h, name, value)) plus one process-wide set for the
+// handle-less op-level entry points (cotr_op_*, cotr_bench_*, cotr_train_*: tests and tools; cotr_set_knob(NULL, ...)).  Every
+// ABI call makes its set current for the calling thread (KnobScope, api.hip); the launch helpers read it through knob(): two
+// handles - or two threads - can run with different settings, and a new handle always starts from the shipped defaults.
+// The experimental build (-DCOTR_EXPERIMENTAL, libcotr_hip_exp.so, csrc/experimental/) appends the knobs of the measured dead
+// ends; the product library has neither those knobs nor the code behind them.
+// ---------------------------------------------------------------------------------------------
+enum KnobId {
+  KN_ENCODE_CHUNK,               // pairs per backbone / encoder pass (<= 128).  64: +2-3 % over 32 from 64 pairs up, 128: -20 %
+  KN_ATTENTION_FUSION_MAX_ROWS,  // attention with the out-projection (decoder: + q projection) fused in, up to this many rows
+  KN_FFN_FUSION_MAX_ROWS,        // fused FFN block up to this many rows (slower than the two GEMMs from ~1300 rows on)
+  KN_KS3,                        // three-stage LDS-DMA k-split (config 30) where the table says its two-stage form (24)
+  KN_DUAL_CONV,                  // downsample + conv1 of a stage's entry block as one launch (few pairs)
+  KN_FUSED_STEM,                 // conv1 7x7 + bn + relu + maxpool in one launch
+  KN_XCD_MAPPING,                // bits 0-1: GEMM tiles over XCDs (0 columns, 1 by operand size, 2 rows); bit 2: FFN chunks over XCDs;
+                                 // bit 3: attention heads over XCDs; bit 4: plain (not write-through) stores for the FFN partials
+  KN_ATTENTION_FUSED_SPLITS,     // key splits of the fused attention: 0 (= 4), 4, 8, 48 / 84 (encoder / decoder separately)
+  KN_CONV_PATCH,                 // layer3's 3x3 convolutions load their input patch once (config 31)
+  KN_POS_TABLE_MIN_ROWS,         // token rows from which the encoder in-projections take pos . W^T from the tables
+  KN_ATTENTION_WIDE_OCCUPANCY,   // wavefronts per SIMD of the 64-query attention kernel (2 or 3)
+  KN_ATTENTION_WIDE_MIN_ROWS,    // query rows of a launch from which the 64-query / resident-K/V kernels are used
+  KN_ATTENTION_SPLITS,           // key splits of the plain 32-query attention kernel (0 = automatic)
+  KN_CONV1X1_DENSE,              // 1x1 stride-1 convolutions run the dense instantiation of their configuration
+  KN_WS_FLAGS,                   // wave-specialised large tiles: bit 0 s_setprio(1) around the MFMA loop, bit 1 s_setprio(3) for the loaders
+  KN_BOTTLENECK_MAX_PAIRS,       // layer1 bottlenecks as one launch each up to this many pairs per pass (-4.3 % at 1 pair, +1.4 % at 32)
+  KN_TRAIN_ATTENTION_FORM,       // training attention backward: 0 = by shape, 1-3 = force a form
+  KN_ATTENTION_RESIDENT,         // K_h / V_h resident in LDS (attention_res_kernel) for many rows
+#ifdef COTR_EXPERIMENTAL
+  KN_HEAD_FUSION_MAX_ROWS,       // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower; 0)
+  KN_FFN_PRELN,                  // the norm before the FFN folded into the fused FFN block (measured neutral; 0)
+  KN_FFN_TAIL,                   // last-arriver reduce + LayerNorm inside the fused FFN launch (measured slower; 0)
+  KN_COOP_TAIL,                  // row tiles finished by their own workgroups (coop_tail.h; measured slower; 0)
+  KN_COOP_TAIL_SPIN,             // polls before a member leaves its share to the last arriver
+  KN_GEMM_LN_MIN_ROWS,           // 256-wide projection + LayerNorm as one launch from this many rows (measured neutral; off)
+#endif
+  KN_COUNT
+};
+struct KnobSet {
+  int v[KN_COUNT];
+};
+extern thread_local const KnobSet* cotr_tls_knobs;   // the set of the ABI call in flight on this thread (api.hip)
+static inline int knob(int id) { return cotr_tls_knobs->v[id]; }
+
+// ---------------------------------------------------------------------------------------------
 // C[M,N] = epilogue( A'[M,K] . W[N,K]^T )
 //   A' row m, column k:
 //     mode DENSE : A[m*lda + k]  (+ A2[(m % a2_row_mod)*lda2 + k] when the tile's first column n0
@@ -203,29 +247,16 @@ int launch_gemm_dual_cfg(int mode, int cfg, const GemmParams& p0, const GemmPara
 int launch_gemm_big_dual(int mode, int variant, const GemmParams& p0, const GemmParams& p1, hipStream_t s);
 bool gemm_cfg_supports_dual(int cfg);
 int gemm_num_configs();
-void gemm_set_xcd_policy(int v);  // 0 column tiles over XCDs, 1 by operand size (default), 2 row tiles over XCDs
-bool gemm_cfg_supports_ln(int cfg);
-void gemm_set_ks3(int v);
-void gemm_set_patch(int v);
-void gemm_set_ws_flags(int v);
-void gemm_set_conv1x1_dense(int v);  // 1 (default): 1x1 stride-1 convolutions run the dense instantiation of their configuration  // 1 (default): three-stage LDS-DMA k-split instead of the two-stage one where K >= 768
 const float* gemm_zero_buffer();  // per-DEVICE buffer of zeros (LDS-DMA padding source), on the current device
-// gemm_ln.hip: y [M][256] = LayerNorm(x [M][K] . w [256][K]^T + bias + residual) * ln_w + ln_b, a workgroup owns 128 complete rows
-int launch_gemm_ln(const float* x, int lda, const float* w, const float* bias, const float* residual, int ldr, const float* ln_w,
-                   const float* ln_b, float* y, int M, int K, hipStream_t s);
-
 // softmax(q k^T) v for 8 heads of 32; q rows are [nb][nq], keys/values [nb][512]
 int launch_attention(const float* q, int ldq, const float* k, const float* v, int ldkv, float* o, int ldo,
                      int nb, int nq, hipStream_t s);
 
 // the same with the q projection as prologue (wq != nullptr: q = ((x + x2) . wq_h^T + bq_h) * qscale, `q` unused) and / or the
 // output projection as epilogue (wo != nullptr: per-head partial outputs [8][nb*nq][256] to `part`; `o` may be nullptr)
-struct CoopTail;   // coop_tail.h: the row tile's own workgroups sum the partials + bias + residual + LayerNorm (no ln_reduce launch)
 int launch_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
                            float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
-                           float* part, int nb, int nq, hipStream_t s, const CoopTail* ct = nullptr);
-int launch_ffn_fused_coop(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
-                          const CoopTail& ct, hipStream_t s);
+                           float* part, int nb, int nq, hipStream_t s);
 
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s);
 // lin_sine encoding; point (bi, qi) read from pts[((bi*q_total) + qi)*2], written to row bi*nq+qi
@@ -235,11 +266,6 @@ int launch_maxpool(const float* x, float* y, int B, int Hin, int Win, int C, hip
 // y[(bi*q_total + qi)*2 + j] = x[bi*nq+qi, :] . w[j, :] + b[j]   (last corr_embed layer, 256 -> 2)
 int launch_head2(const float* x, const float* w, const float* b, float* y, int nb, int nq, int q_total,
                  hipStream_t s);
-
-// decoder.norm + corr_embed (256 -> 256 -> 256 -> 2) in one row-local launch (head.hip); hs (normalised rows) optional
-int launch_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
-                    const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
-                    hipStream_t s);
 
 // conv1 7x7/2 + FrozenBN + ReLU + maxpool 3x3/2 in one launch (stem_pool.hip): img NCHW [B,3,256,512] -> [B,64,128,64]
 int launch_stem_pool(const float* img, const float* w, int wk, const float* scale, const float* bias, float* out, int B,
@@ -259,19 +285,10 @@ int launch_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int H
 // fused feed-forward block (ffn.hip) and its reduce + bias + residual + LayerNorm tail (pointwise.hip)
 int ffn_fused_chunks(int M);
 int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch, hipStream_t s);
-// same + the reduce / bias / residual / LayerNorm tail inside the kernel (last-arriving workgroup of a row tile)
-int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
-                        const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
 int launch_ln_reduce_post(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                           const float* post_w, const float* post_b, float* y, int rows, hipStream_t s);
 int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                      float* y, int rows, hipStream_t s);
-// the same two with the LayerNorm that precedes the FFN folded in: X / residual are the PRE-norm rows
-int launch_ffn_fused_pre(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
-                         const float* W2, float* P, int M, int nch, hipStream_t s);
-int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const float* residual, const float* pre_w,
-                         const float* pre_b, const float* w, const float* b, float* y, int rows, hipStream_t s);
-
 // one whole layer1 bottleneck in one launch (bottleneck.hip); w2p / w3p / wdp are the packed fragment arrays (bottleneck_pack_*)
 int launch_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2p, const float* w3p, const float* wdp,
                       const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
@@ -279,3 +296,7 @@ int launch_bottleneck(const float* x, float* y, int B, int cin, const float* w1,
 void bottleneck_pack_w2(const float* w2 /*[64][576]*/, float* w2p /*[36864]*/);
 void bottleneck_pack_w3(const float* w3 /*[256][64]*/, float* w3p /*[16384]*/);
 
+
+#ifdef COTR_EXPERIMENTAL
+#include "experimental/experimental.h"
+#endif

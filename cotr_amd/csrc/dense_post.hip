@@ -10,8 +10,9 @@
 //
 // Float/byte work, HBM/L2-bound, a few MB: no MFMA.  The Pillow part is bit-exact (32-bit float path of
 // src/libImaging/Resample.c: un-quantised double coefficients, double accumulation in tap order, float
-// intermediate after the horizontal pass); compiled with -ffp-contract=off for that.  The grid_sample part
-// follows torch's formulas (bilinear, zeros padding, align_corners=False) in fp32.
+// intermediate after the horizontal pass); compiled with -ffp-contract=off for that.  The grid_sample + norm part
+// reproduces torch's CPU kernels bit for bit (their association and their FMA contractions, spelled out with explicit
+// round-to-nearest intrinsics), so the `con < 0.02` mask and the random draw behind it are the reference's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -29,40 +30,44 @@ __global__ __launch_bounds__(256) void dense_cycle_kernel(const float* __restric
   const int j = idx % NET_W, i = (idx / NET_W) % NET_H, p = idx / (NET_W * NET_H);
   const float* g = pred + (size_t)p * NET_H * NET_W * 2;
   // out_grid = out * 2 - 1  (:138)
-  const float gx = g[(i * NET_W + j) * 2] * 2.f - 1.f;
-  const float gy = g[(i * NET_W + j) * 2 + 1] * 2.f - 1.f;
-  // grid_sample(out_grid as a 2-channel image, out_grid): unnormalise, 4 neighbours, zeros outside
-  const float ix = ((gx + 1.f) * NET_W - 1.f) / 2.f;
-  const float iy = ((gy + 1.f) * NET_H - 1.f) / 2.f;
-  float cx, cy;
-  if (!(ix == ix) || !(iy == iy)) {
-    cx = cy = __builtin_nanf("");
-  } else if (ix < -1.f || ix > (float)NET_W || iy < -1.f || iy > (float)NET_H) {
-    cx = cy = 0.f;                                     // all four neighbours are outside the map
-  } else {
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix;  // (ix - ix_nw), (ix_se - ix)
-    const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
-    const float w[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};   // nw, ne, sw, se
-    const int xs[4] = {x0, x0 + 1, x0, x0 + 1};
-    const int ys[4] = {y0, y0, y0 + 1, y0 + 1};
-    cx = 0.f;
-    cy = 0.f;
+  const float gx = __fsub_rn(__fmul_rn(g[(i * NET_W + j) * 2], 2.f), 1.f);
+  const float gy = __fsub_rn(__fmul_rn(g[(i * NET_W + j) * 2 + 1], 2.f), 1.f);
+  // grid_sample(out_grid as a 2-channel image, out_grid), bilinear / zeros / align_corners=False, in the association of torch's
+  // CPU kernel (aten/src/ATen/native/cpu/GridSamplerKernel.cpp, the path the reference runs: the maps are host tensors there):
+  //   x = (g + 1) * (size / 2) - 0.5 ; w = x - floor(x), e = 1 - w (likewise n, s) ; weights nw = s*e, ne = s*w, sw = n*e, se = n*w ;
+  //   a neighbour outside the map contributes the VALUE 0 (its weight is still multiplied: a NaN / inf coordinate gives NaN) ;
+  //   nw_val*nw + ne_val*ne + sw_val*sw + se_val*se evaluated left to right with every multiply-add contracted into one FMA
+  //   (that is what the shipped AVX2 / AVX512 builds do - pinned bit for bit against torch CPU by tests/test_zoom_engine_cpu.py
+  //   on the C restatement oracle/dense_cycle_ref.c and by the GPU tests on this kernel).
+  const float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f * NET_W), 0.5f);
+  const float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f * NET_H), 0.5f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const float ww = __fsub_rn(ix, fx), we = __fsub_rn(1.f, ww);
+  const float wn = __fsub_rn(iy, fy), wsth = __fsub_rn(1.f, wn);
+  const float w[4] = {__fmul_rn(wsth, we), __fmul_rn(wsth, ww), __fmul_rn(wn, we), __fmul_rn(wn, ww)};   // nw, ne, sw, se
+  // bounds on the float coordinates (a NaN or a coordinate beyond the int range is outside, as torch's converted index is)
+  const bool x_in[2] = {fx >= 0.f && fx <= (float)(NET_W - 1), fx >= -1.f && fx <= (float)(NET_W - 2)};
+  const bool y_in[2] = {fy >= 0.f && fy <= (float)(NET_H - 1), fy >= -1.f && fy <= (float)(NET_H - 2)};
+  const int x0 = x_in[0] || x_in[1] ? (int)fx : 0, y0 = y_in[0] || y_in[1] ? (int)fy : 0;
+  float cx = 0.f, cy = 0.f;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (xs[c] >= 0 && xs[c] < NET_W && ys[c] >= 0 && ys[c] < NET_H) {
-        const float vx = g[(ys[c] * NET_W + xs[c]) * 2] * 2.f - 1.f;
-        const float vy = g[(ys[c] * NET_W + xs[c]) * 2 + 1] * 2.f - 1.f;
-        cx += vx * w[c];
-        cy += vy * w[c];
-      }
+  for (int c = 0; c < 4; ++c) {
+    float vx = 0.f, vy = 0.f;
+    if (x_in[c & 1] && y_in[c >> 1]) {
+      const float* v = g + ((y0 + (c >> 1)) * NET_W + x0 + (c & 1)) * 2;
+      vx = __fsub_rn(__fmul_rn(v[0], 2.f), 1.f);
+      vy = __fsub_rn(__fmul_rn(v[1], 2.f), 1.f);
     }
+    cx = c == 0 ? __fmul_rn(vx, w[0]) : __fmaf_rn(vx, w[c], cx);
+    cy = c == 0 ? __fmul_rn(vy, w[0]) : __fmaf_rn(vy, w[c], cy);
   }
-  // in_grid = q * 2 - 1 with q = (j/512, i/256): exact in fp32
-  const float dx = cx - ((float)j / NET_W * 2.f - 1.f);
-  const float dy = cy - ((float)i / NET_H * 2.f - 1.f);
-  const float err = sqrtf(dx * dx + dy * dy);
+  // in_grid = q * 2 - 1 with q = (j/512, i/256): exact in fp32.  torch.norm(., dim=-1) over the two components on the CPU:
+  // acc = dx*dx ; acc = fma(dy, dy, acc) ; sqrt (correctly rounded)
+  const float dx = __fsub_rn(cx, (float)j / NET_W * 2.f - 1.f);
+  const float dy = __fsub_rn(cy, (float)i / NET_H * 2.f - 1.f);
+  // (float)sqrt((double)x) is the correctly rounded float square root (53 >= 2*24 + 2 bits: the double rounding is harmless);
+  // __fsqrt_rn is v_sqrt_f32 in this toolchain (1 ulp), sqrtf depends on a compiler default
+  const float err = (float)sqrt((double)__fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
   // :140-142  x of the left half lives in the right image and vice versa
   const int half = j >= NET_W / 2;
   const float X = half ? gx * 2.f + 1.f : gx * 2.f - 1.f;

@@ -23,7 +23,7 @@
 // each - device-scope atomics and sc1 accesses are served behind the per-XCD L2s - against 1.7 us of dispatch + 2.3 us of kernel
 // for the ln_reduce launch it replaces.  Off by default (cotr_set_coop_tail); kept as the measured answer to "fewer launches".
 #pragma once
-#include "common.h"
+#include "../common.h"
 
 struct CoopTail {
   unsigned long long* state;   // [row tiles][COOP_WORDS]; nullptr = no tail (separate ln_reduce launch)

@@ -1,0 +1,31 @@
+// Declarations of the MEASURED DEAD ENDS: compiled only into libcotr_hip_exp.so (-DCOTR_EXPERIMENTAL), never into
+// the product library.  Each is correct and tested (tests/test_experimental_gpu.py runs against the experimental library); each lost
+// its A/B on the MI355X and is kept so that the measurement can be repeated.
+//   coop_tail.h      row tiles finished by their own workgroups instead of ln_reduce launches      +7.4 us per tail
+//   head.hip         decoder.norm + corr_embed as one row-local launch                               1.004 vs 0.998 ms
+//   gemm_ln.hip      256-wide projection + LayerNorm as one 128 x 256 tile launch                    nothing inside the forward
+//   ffn tail / preln last-arriver reduce inside the FFN launch; norm1 folded into the FFN block      1.285 vs 1.043 ms; neutral
+//   GEMM configs 28 / 29  three LDS stages in the large-tile kernel                                  within +-5 %
+#pragma once
+#include "coop_tail.h"
+
+int launch_attention_fused_coop(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                                float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                                float* part, int nb, int nq, hipStream_t s, const CoopTail* ct);
+int launch_ffn_fused_coop(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                          const CoopTail& ct, hipStream_t s);
+// fused FFN + the reduce / bias / residual / LayerNorm tail inside the kernel (last-arriving workgroup of a row tile)
+int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                        const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
+// fused FFN / ln_reduce with the LayerNorm that precedes the FFN folded in: X / residual are the PRE-norm rows
+int launch_ffn_fused_pre(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
+                         const float* W2, float* P, int M, int nch, hipStream_t s);
+int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const float* residual, const float* pre_w,
+                         const float* pre_b, const float* w, const float* b, float* y, int rows, hipStream_t s);
+// gemm_ln.hip: y [M][256] = LayerNorm(x [M][K] . w [256][K]^T + bias + residual) * ln_w + ln_b, a workgroup owns 128 complete rows
+int launch_gemm_ln(const float* x, int lda, const float* w, const float* bias, const float* residual, int ldr, const float* ln_w,
+                   const float* ln_b, float* y, int M, int K, hipStream_t s);
+// head.hip: decoder.norm + corr_embed (256 -> 256 -> 256 -> 2) in one row-local launch; hs (normalised rows) optional
+int launch_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
+                    const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
+                    hipStream_t s);

@@ -13,7 +13,7 @@
 // stages), then every wavefront normalises 32 rows the way layernorm_kernel (pointwise.hip) does - a float4 per lane per row, bias and
 // residual added in that order, two-pass statistics by wave shuffles (8 rows at a time) - so the output is bit-identical to
 // gemm + layernorm_kernel (tests/test_ops_gpu.py).
-#include "common.h"
+#include "../common.h"
 
 #define BK 32
 

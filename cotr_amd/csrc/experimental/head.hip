@@ -12,7 +12,7 @@
 // A fragments (activations) come from LDS, B fragments (weights; each element is used once per workgroup) straight from
 // global / L2 in MFMA layout.  Fragment trick as in gemm.hip: a lane reads ONE float4 = 4 consecutive k and feeds element e
 // to the e-th of 4 MFMAs; both operands use the same k permutation.
-#include "common.h"
+#include "../common.h"
 
 #define HD_D 256
 #define HD_LD 260   // padded LDS row

@@ -15,7 +15,6 @@
 #include <string.h>
 
 #include "common.h"
-#include "coop_tail.h"
 
 #define FF_D 256
 #define FF_H 1024
@@ -29,12 +28,14 @@ struct FfnParams {
   const float* W2;   // [256][1024]
   float* P;          // [nch][M][256] partial outputs
   const float* zeros;
+  int M, nch, chunk_major;
+  int wt_partials;   // partial outputs with write-through stores
+  unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock), cotr_debug_ffn_times
+#ifdef COTR_EXPERIMENTAL   // the measured dead ends, libcotr_hip_exp.so only
   // optional LayerNorm applied to the X tile after it landed in LDS: X is then the PRE-norm tensor (x + attention output)
   // and norm1 / norm2 of the layer never needs its own launch (its only consumers are this block and its residual)
   const float* pre_w;
   const float* pre_b;
-  int M, nch, chunk_major;
-  int wt_partials;   // partial outputs with write-through stores
   // tail (optional): the LAST of the nch workgroups of a row tile to finish sums the partial outputs in chunk order, adds
   // bias + residual and applies LayerNorm - what ln_reduce_kernel does in a second launch.  No workgroup waits for
   // another (arrival counter per row tile, reset by the last arriver), the sum order is fixed: same bits as ln_reduce.
@@ -44,8 +45,8 @@ struct FfnParams {
   const float* ln_w;
   const float* ln_b;
   float* Y;          // [M][256]
-  unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock), cotr_debug_ffn_times
   CoopTail ct;       // ct.state != nullptr: the workgroups of a row tile finish it themselves (coop_tail.h) - no ln_reduce launch
+#endif
 };
 
 __device__ __forceinline__ float ffn_wave_sum(float v) {
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   dma_w1(0);
   FFN_STAMP(1);
 
+#ifdef COTR_EXPERIMENTAL
   if (p.pre_w != nullptr) {
     LDS_DMA_WAIT_ALL();
     __syncthreads();                                  // X (and the first W1 sub-chunk) have landed
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
       *reinterpret_cast<f32x4*>(row) = o;
     }
   }
+#endif
 
   f32x16 acc2;
 #pragma unroll
@@ -180,7 +183,10 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   FFN_STAMP(6);
   // partial output block of this wave: rows m0 + (r&3) + 8*(r>>2) + 4*hh, columns 32*wave + l31
   float* out = p.P + (size_t)chunk * p.M * FF_D;
-  if (p.counters == nullptr) {
+#ifdef COTR_EXPERIMENTAL
+  if (p.counters == nullptr)
+#endif
+  {
     // through a wave-private LDS tile (the W1 stage is free: no DMA is in flight after the last sub-chunk and every wave is
     // past its last read of it, barrier "H complete") so that the rows leave as float4 - one instruction = 8 rows x 128 B.
     // Write-through (sc1): the 8-16 MB of partial outputs are read once, by ln_reduce on all XCDs; left dirty in L2 they are
@@ -196,12 +202,15 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
       if (m0 + row < p.M) store_f32x4(out + (size_t)(m0 + row) * FF_D + 32 * wave + sc, val, p.wt_partials != 0);
     }
     FFN_STAMP(7);
+#ifdef COTR_EXPERIMENTAL
     if (p.ct.state != nullptr) {
       __shared__ int coop_flags[2];
       coop_tail_run(p.ct, p.P, (size_t)p.M * FF_D, m0 >> 5, m0, (p.M - m0) < 32 ? (p.M - m0) : 32, chunk, p.nch, coop_flags);
     }
+#endif
     return;
   }
+#ifdef COTR_EXPERIMENTAL
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -254,16 +263,15 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
     *reinterpret_cast<f32x4*>(p.Y + (size_t)row * FF_D + lane * 4) = o;
   }
   if (t == 0) p.counters[tile] = 0;                  // everybody has arrived: ready for the next launch
+#endif
 }
 
 static const size_t kFfnSmem = (size_t)(32 * FF_LD + 64 * FF_LD + 32 * FF_HLD) * sizeof(float);
 
 static thread_local unsigned long long* g_ffn_dbg = nullptr;   // set_ffn_debug_times: phase stamps of the next launches
 void set_ffn_debug_times(unsigned long long* p) { g_ffn_dbg = p; }
-static int g_ffn_wt = 1;  // cotr_set_xcd_mapping bit 4 clears it
-void set_ffn_write_through(int v) { g_ffn_wt = v; }
-static int g_ffn_chunk_major = 0;  // measured: -112 MB of fabric traffic per forward but +2 % time -> off (cotr_set_xcd_mapping bit 2)
-void set_ffn_chunk_major(int v) { g_ffn_chunk_major = v; }
+// knob KN_XCD_MAPPING bit 4 set = plain stores for the partials; bit 2 = hidden-unit chunks over XCDs (measured: -112 MB of fabric
+// traffic per forward but +2 % time -> off)
 
 // hidden-unit chunks per row tile: enough workgroups to cover the 256 CUs, at most 16 partial outputs
 int ffn_fused_chunks(int M) {
@@ -273,6 +281,7 @@ int ffn_fused_chunks(int M) {
   return nch;
 }
 
+#ifdef COTR_EXPERIMENTAL
 // per-device arrival counters of the tail (1024 rows / 32 = at most 32 row tiles are ever fused)
 static int* ffn_counters() {
   static int* c[COTR_MAX_DEVICES] = {};
@@ -285,6 +294,7 @@ static int* ffn_counters() {
   }
   return cd;
 }
+#endif
 
 static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
                            const float* W2, float* P, int M, int nch, const float* b2, const float* residual,
@@ -295,6 +305,7 @@ int launch_ffn_fused(const float* X, const float* W1, const float* b1, const flo
   return launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
 }
 
+#ifdef COTR_EXPERIMENTAL
 // the same with the cooperative tail (coop_tail.h): Y = [post norm] LN(residual + sum of partials + b2) by the row tile's own workgroups
 static thread_local const CoopTail* g_ffn_ct = nullptr;
 int launch_ffn_fused_coop(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
@@ -318,6 +329,7 @@ int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const 
                         hipStream_t s) {
   return launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, b2, residual, ln_w, ln_b, Y, s);
 }
+#endif
 
 static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
                            const float* W2, float* P, int M, int nch, const float* b2, const float* residual,
@@ -332,11 +344,13 @@ static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_
     attr_set.set();
   }
   FfnParams p;
-  p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch; p.chunk_major = g_ffn_chunk_major;
+  p.X = X; p.W1 = W1; p.b1 = b1; p.W2 = W2; p.P = P; p.zeros = gemm_zero_buffer(); p.M = M; p.nch = nch;
+  p.chunk_major = (knob(KN_XCD_MAPPING) >> 2) & 1;
+  p.wt_partials = ((knob(KN_XCD_MAPPING) >> 4) & 1) == 0;
+  p.dbg = g_ffn_dbg;
+#ifdef COTR_EXPERIMENTAL
   p.counters = nullptr; p.b2 = b2; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y;
   p.pre_w = pre_w; p.pre_b = pre_b;
-  p.wt_partials = g_ffn_wt;
-  p.dbg = g_ffn_dbg;
   memset(&p.ct, 0, sizeof(p.ct));
   if (g_ffn_ct != nullptr) p.ct = *g_ffn_ct;
   if (b2 != nullptr) {
@@ -344,6 +358,9 @@ static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_
     p.counters = ffn_counters();
     if (p.counters == nullptr) return -2;
   }
+#else
+  if (pre_w != nullptr || b2 != nullptr) return -1;   // experimental build only
+#endif
   if (p.zeros == nullptr) return -2;
   hipLaunchKernelGGL(ffn_fused_kernel, dim3(((M + 31) / 32) * nch), dim3(512), kFfnSmem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -948,18 +948,16 @@ static double model_cost(const GemmCfg& c, const GemmParams& p) {
   return rounds * (steps * step + 2500.0 + (c.kind != 0 ? 600.0 : 0.0));
 }
 
-static int g_ks3 = 1;  // gemm_set_ks3: use the three-stage LDS-DMA k-split (30) where the measured table says its two-stage form (24)
-void gemm_set_ks3(int v) { g_ks3 = v; }
-static int g_patch = 1;  // gemm_set_patch: 3x3 stride-1 convolutions over 256 channels load their input patch once (31) where the table says 24 / 30
-void gemm_set_patch(int v) { g_patch = v; }
+// knobs KN_KS3: the three-stage LDS-DMA k-split (30) where the measured table says its two-stage form (24); KN_CONV_PATCH: 3x3
+// stride-1 convolutions over 256 channels load their input patch once (31) where the table says 24 / 30
 static int gemm_pick_config_table(int mode, const GemmParams& p);
 
 int gemm_pick_config(int mode, const GemmParams& p) {
   const int cfg = gemm_pick_config_table(mode, p);
   // few workgroups per CU (one pair): the three-stage form hides the DMA latency the two-stage one exposes at every K step
-  if (mode == GEMM_CONV && g_patch && (cfg == 24 || cfg == 30) && cfg_fits(31, p)) return 31;
+  if (mode == GEMM_CONV && knob(KN_CONV_PATCH) && (cfg == 24 || cfg == 30) && cfg_fits(31, p)) return 31;
   // (not for the stride-2 3x3: measured 14.2 us on the two-stage form against 15.3 on the three-stage one, tools/conv_cfgs_in_situ.py)
-  if (cfg == 24 && g_ks3 && p.K >= 3 * 256 && !(mode == GEMM_CONV && p.stride == 2 && p.ksize == 3) && cfg_fits(30, p)) return 30;
+  if (cfg == 24 && knob(KN_KS3) && p.K >= 3 * 256 && !(mode == GEMM_CONV && p.stride == 2 && p.ksize == 3) && cfg_fits(30, p)) return 30;
   return cfg;
 }
 
@@ -996,10 +994,7 @@ static int gemm_pick_config_table(int mode, const GemmParams& p) {
   return best;
 }
 
-static int g_conv1x1_dense = 1;  // gemm_set_conv1x1_dense
-void gemm_set_conv1x1_dense(int v) { g_conv1x1_dense = v; }
-static int g_xcd_policy = 1;  // 0 = column tiles over XCDs always, 1 = by operand size, 2 = row tiles over XCDs always
-void gemm_set_xcd_policy(int v) { g_xcd_policy = v; }
+// knobs KN_CONV1X1_DENSE; KN_XCD_MAPPING bits 0-1: 0 = column tiles over XCDs always, 1 = by operand size, 2 = row tiles over XCDs always
 
 // which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
 static void set_xcd_split(int mode, int cfg, GemmParams& p) {
@@ -1008,7 +1003,7 @@ static void set_xcd_split(int mode, int cfg, GemmParams& p) {
   const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
   const double w_bytes = (double)p.N * p.K * 4.0;
   const bool fits = (p.M + bm - 1) / bm >= 8;
-  p.xcd_msplit = mode != GEMM_STEM && fits && (g_xcd_policy == 2 || (g_xcd_policy == 1 && a_bytes >= 2.0 * w_bytes));
+  p.xcd_msplit = mode != GEMM_STEM && fits && ((knob(KN_XCD_MAPPING) & 3) == 2 || ((knob(KN_XCD_MAPPING) & 3) == 1 && a_bytes >= 2.0 * w_bytes));
 }
 
 int launch_gemm_dual_cfg(int mode, int cfg, const GemmParams& a, const GemmParams& b, hipStream_t s) {
@@ -1039,7 +1034,7 @@ int launch_gemm_cfg(int mode, int cfg, const GemmParams& p0, hipStream_t s) {
       // a 1x1 stride-1 convolution IS the dense product of the pixel rows (row m = pixel m, lda = Cin, no padding): the
       // dense instantiation of the same configuration computes the same sums in the same order without the per-row pixel
       // decomposition - ~640 fewer instructions between workgroup entry and the first load (profiles/r3_prologue_*.txt)
-      if (g_conv1x1_dense && p.ksize == 1 && p.stride == 1 && p.pad == 0 && p.lda == p.Cin && p.lda % 4 == 0)
+      if (knob(KN_CONV1X1_DENSE) && p.ksize == 1 && p.stride == 1 && p.pad == 0 && p.lda == p.Cin && p.lda % 4 == 0)
         return launch_cfg<GEMM_DENSE>(cfg, p, s);
       return launch_cfg<GEMM_CONV>(cfg, p, s);
     case GEMM_STEM:

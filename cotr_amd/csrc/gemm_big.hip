@@ -424,8 +424,7 @@ __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
   gemm_ws_body<TN, MODE>(p, blockIdx.x);
 }
 
-static int g_ws_flags = 2;   // gemm_set_ws_flags: bit 0 = s_setprio(1) around the MFMA wavefronts' loop, bit 1 = s_setprio(3) for the loaders
-void gemm_set_ws_flags(int v) { g_ws_flags = v; }
+// knob KN_WS_FLAGS: bit 0 = s_setprio(1) around the MFMA wavefronts' loop, bit 1 = s_setprio(3) for the loaders
 
 template <int TN, int MODE>
 static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
@@ -446,7 +445,7 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
     attr_set.set();
   }
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
-  p.ws_flags = g_ws_flags;
+  p.ws_flags = knob(KN_WS_FLAGS);
   const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_ws_kernel<TN, MODE>), dim3(tiles), dim3(512), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -527,8 +526,10 @@ int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s) {
   switch (variant) {
     case 0: return d ? launch_big_t<2, GEMM_DENSE, 2>(p, s) : launch_big_t<2, GEMM_CONV, 2>(p, s);
     case 1: return d ? launch_big_t<1, GEMM_DENSE, 2>(p, s) : launch_big_t<1, GEMM_CONV, 2>(p, s);
+#ifdef COTR_EXPERIMENTAL   // configurations 28 / 29 (three LDS stages: within +-5 % of the two-stage kernel, never in the tuned table)
     case 2: return d ? launch_big_t<2, GEMM_DENSE, 3>(p, s) : launch_big_t<2, GEMM_CONV, 3>(p, s);
     case 3: return d ? launch_big_t<1, GEMM_DENSE, 3>(p, s) : launch_big_t<1, GEMM_CONV, 3>(p, s);
+#endif
     case 4: return d ? launch_ws_t<2, GEMM_DENSE>(p, s) : launch_ws_t<2, GEMM_CONV>(p, s);   // wave-specialised 128 x 128
     case 5: return d ? launch_ws_t<1, GEMM_DENSE>(p, s) : launch_ws_t<1, GEMM_CONV>(p, s);   // wave-specialised 128 x 64
     default: return -1;

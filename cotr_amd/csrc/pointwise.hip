@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // LayerNorm of (sum of `np` partial outputs [np][rows][256] + bias + residual): the tail of the fused FFN block
 // (ffn.hip): y = LN(residual + linear2(...)) with linear2's bias (transformer.py:156-158, 199-201).
-// With pre_w != nullptr the residual is LayerNorm(pre_w, pre_b) of the given (pre-norm) row: the norm after the attention
-// sub-layer, whose only consumers are the FFN (ffn_fused_kernel normalises its X tile itself) and this residual.
+// (Experimental build only: with pre_w != nullptr the residual is LayerNorm(pre_w, pre_b) of the given (pre-norm) row: the norm
+// after the attention sub-layer, whose only consumers are the FFN (ffn_fused_kernel normalises its X tile itself) and this residual.)
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ parts, int np, const float* __restrict__ bias,
                                                         const float* __restrict__ residual, const float* __restrict__ pre_w,
                                                         const float* __restrict__ pre_b, const float* __restrict__ w,
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
   f32x4 v = *reinterpret_cast<const f32x4*>(bias + lane * 4);
   f32x4 rr = {0.f, 0.f, 0.f, 0.f};
   if (residual != nullptr) rr = *reinterpret_cast<const f32x4*>(residual + (size_t)row * 256 + lane * 4);
+#ifdef COTR_EXPERIMENTAL
   if (pre_w != nullptr) {
     const float mu = wave_sum(rr[0] + rr[1] + rr[2] + rr[3]) * (1.f / 256.f);
     const f32x4 dd = {rr[0] - mu, rr[1] - mu, rr[2] - mu, rr[3] - mu};
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < 4; ++i) rr[i] = dd[i] * rs * pw[i] + pb[i];
   }
+#endif
   v += rr;
   // the partial rows are independent loads: request 8 at a time and add them in order afterwards (a plain
   // "for c: v += load" is np dependent L2 round trips - the loop is not unrolled for a runtime np); same sum order as before
@@ -101,6 +103,7 @@ int launch_ln_reduce_post(const float* parts, int np, const float* bias, const f
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+#ifdef COTR_EXPERIMENTAL
 int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const float* residual, const float* pre_w,
                          const float* pre_b, const float* w, const float* b, float* y, int rows, hipStream_t s) {
   if (rows <= 0) return 0;
@@ -108,10 +111,11 @@ int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const fl
                      nullptr, nullptr, y, rows);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+#endif
 
 int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                      float* y, int rows, hipStream_t s) {
-  return launch_ln_reduce_pre(parts, np, bias, residual, nullptr, nullptr, w, b, y, rows, s);
+  return launch_ln_reduce_post(parts, np, bias, residual, w, b, nullptr, nullptr, y, rows, s);
 }
 
 int launch_layernorm(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s) {

@@ -76,8 +76,6 @@ int train_head_bwd(const float* dy, const float* h, const float* w2, float* dh, 
 
 // attention_train.hip: softmax(q k^T * qscale) with dropout on the probabilities; q [nb*nq][ldq], k [nb*512][ldk], v [nb*512][ldv]
 // (8 heads x 32); lse [nb*nq][8] = log2-domain log-sum-exp of the scaled scores (for the backward)
-void train_set_attn_bwd_form(int v);
-int train_get_attn_bwd_form();
 int train_attention_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o, int ldo, float* lse,
                         int nb, int nq, float qscale, float p, uint32_t seed, hipStream_t s);
 // dq [nb*nq][lddq], dk [nb*512][lddk], dv [nb*512][lddv]; delta [nb*nq][8] scratch (rowsum(dO * O) per head); o / d_o share ldo

@@ -102,7 +102,7 @@ class PairShardedModel:
             counts = [shard_range(B, world, r)[1] - shard_range(B, world, r)[0] for r in range(world)]
             finish, _ = all_gather_rows(local, counts, self.group)
             return {'pred_corrs': finish()}
-        if world % B == 0:
+        if B > 0 and world % B == 0:
             # fewer pairs than ranks, ranks a multiple of the pairs (the dense initial pass: 1, 2 or 4 patch pairs x 131072 grid
             # queries on 8 GPUs): world / B ranks share one pair - each encodes ONLY that pair and decodes its slice of the
             # pair's queries (queries are independent: no query self-attention, transformer.py:185-201).  Rank order = (pair,
@@ -207,16 +207,55 @@ def sharded_zoom_engine(*args, group=None, **kwargs):
 
 
 def sync_flat_gradients(flat, group=None):
-    """The same exchange for gradients that already ARE one flat buffer (``train_ops.GradSink.flat``: its length is a multiple
-    of 64, so of every world size up to 64): reduce-scatter, 1/N on the local shard, all-gather in place - no packing copies."""
+    """The same exchange for gradients that already ARE one flat buffer (``train_ops.GradSink.flat``): reduce-scatter, 1/N on the
+    local shard, all-gather in place - no packing copies.  The buffer's length is a multiple of 64 floats, which a world size of
+    3, 5, 6 or 7 does not divide: the largest multiple of the world size goes through the two collectives, the (< world) elements
+    behind it through one tiny all-reduce."""
     if not _active(group):
         return
     world = dist.get_world_size(group)
-    assert flat.numel() % world == 0, (flat.numel(), world)
-    shard = torch.empty(flat.numel() // world, dtype=flat.dtype, device=flat.device)
-    dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
-    shard /= world
-    dist.all_gather_into_tensor(flat, shard, group=group)
+    main = flat.numel() // world * world
+    if main:
+        head = flat[:main]
+        shard = torch.empty(main // world, dtype=flat.dtype, device=flat.device)
+        dist.reduce_scatter_tensor(shard, head, op=dist.ReduceOp.SUM, group=group)
+        shard /= world
+        dist.all_gather_into_tensor(head, shard, group=group)
+    if main < flat.numel():
+        tail = flat[main:]
+        dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group)
+        tail /= world
+
+
+def flat_exchange_async(group=None):
+    """-> ``start(flat_slice) -> finish()`` for ``train_ops.GradSink.set_exchange``: the reduce-scatter / (1/N) / all-gather
+    exchange of ``sync_flat_gradients`` on a contiguous slice of the flat gradient buffer, issued on a side stream so that the
+    caller's stream goes on (to the reduction launch of the next slice) while the collectives run; ``finish()`` makes the caller's
+    stream wait for them.  On CPU tensors (gloo tests) the exchange simply runs in ``start``.  Results per element are those of
+    one exchange over the whole buffer: a sum over the same ranks."""
+    def start(piece):
+        if not _active(group):
+            return lambda: None
+        if not piece.is_cuda:
+            sync_flat_gradients(piece, group)
+            return lambda: None
+        cur = torch.cuda.current_stream(piece.device)
+        side = _side_stream(piece.device)
+        side.wait_stream(cur)                                   # the slice's reduction launch is enqueued on `cur`
+        with torch.cuda.stream(side):
+            sync_flat_gradients(piece, group)
+        return lambda: cur.wait_stream(side)
+    return start
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 def sync_gradients_sharded(params, group=None, bucket_elems=1 << 25):

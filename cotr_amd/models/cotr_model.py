@@ -166,6 +166,7 @@ class COTR(nn.Module):
         self._ws = None             # scratch handed to the library (torch caching allocator), see _ensure_workspace
         self._ws_shape = (0, 0)
         self._ws_pins = set()       # ids of captured graphs that have the workspace's addresses baked in (pin_workspace)
+        self._knobs = {}            # tuning knobs of THIS model's handle (set_knob); re-applied when the handle is re-created
 
     # ------------------------------------------------------------------ weight synchronisation
     def _apply(self, fn, *a, **kw):  # .cuda() / .to() / .float() move or replace the storage
@@ -195,6 +196,8 @@ class COTR(nn.Module):
             self._handle, self._handle_device = handle, index
             self._weights_dirty = True
             self._ws, self._ws_shape = None, (0, 0)
+            for name, value in self.__dict__.get('_knobs', {}).items():
+                _lib.set_knob(name, value, handle)
         if self._weights_dirty:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             bad = [k for k, v in sd.items() if v.dtype != torch.float32]
@@ -257,6 +260,7 @@ class COTR(nn.Module):
         state = self.__dict__.copy()
         state['_handle'], state['_handle_device'], state['_weights_dirty'], state['_encoded_batch'] = None, None, True, 0
         state['_ws'], state['_ws_shape'], state['_ws_pins'] = None, (0, 0), set()
+        state['_knobs'] = dict(state.get('_knobs', {}))
         return state
 
     # ------------------------------------------------------------------ the path
@@ -362,6 +366,30 @@ class COTR(nn.Module):
                                         _lib.current_stream_ptr()), self._handle, 'cotr_forward')
         self._encoded_batch = b
         return {'pred_corrs': out}
+
+    # ------------------------------------------------------------------ tuning knobs (per handle: include/cotr_hip.h)
+    def set_knob(self, name, value):
+        """One tuning knob of this model's library handle (cotr_set_knob(h, ...)): other models - and other threads - keep theirs.
+        Remembered, so it survives a move to another GPU; fusion thresholds / encode_chunk change the scratch the library needs,
+        so the workspace is re-sized at the next call."""
+        if self._handle is not None:
+            _lib.set_knob(name, value, self._handle)
+        else:
+            _lib.load_library()
+        self._knobs[name] = int(value)
+        self._ws_shape = (0, 0)
+
+    def knobs(self):
+        """{name: (current, default)} of this model's handle (the shipped defaults + set_knob calls before the handle exists)."""
+        if self._handle is not None:
+            return _lib.knobs(self._handle)
+        return {k: (self._knobs.get(k, v[1]), v[1]) for k, v in _lib.knobs(None).items()}
+
+    def reset_knobs(self):
+        if self._handle is not None:
+            _lib.reset_knobs(self._handle)
+        self._knobs = {}
+        self._ws_shape = (0, 0)
 
     # ------------------------------------------------------------------ test / profiling hooks
     def debug_tap(self, name):

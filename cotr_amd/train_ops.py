@@ -162,6 +162,8 @@ class GradSink:
         self._jobs, self._keep = {}, []
         self.frozen = False                                            # set by GraphedTrainStep after capture
         self.last = (0, 0)                                             # (jobs, sources) of the last flush, for tests / reports
+        self._exchange, self._exchange_parts = None, 1                 # set_exchange(): gradient averaging started from flush()
+        self.last_parts = []                                           # [(lo, hi) element ranges of flat] of the last chunked flush
 
     # -- ownership ------------------------------------------------------------------------------------------------------
     def grad_of(self, w):
@@ -213,17 +215,52 @@ class GradSink:
         if scale is not None:
             self._keep.append(scale)
 
-    def tables(self):
-        """-> (jobs, srcs, nchunks) as numpy record arrays (host side of flush(); also what the CPU test inspects)."""
+    # -- gradient exchange overlapped with the reduction (several ranks) ------------------------------------------------------
+    def set_exchange(self, start, parts=3):
+        """``start(flat_slice) -> finish()`` begins averaging a contiguous slice of ``flat`` over the ranks
+        (``dist.flat_exchange_async``) and returns the callable that waits for it.  With an exchange installed ``flush()`` reduces
+        the gradients in ``parts`` address-ordered ranges of the buffer - one reduction launch each - and starts the exchange of
+        range k right behind its launch, so that it runs (on the collective's own stream) while range k+1 is being reduced; without
+        one the single deferred reduction of a backward pass would leave the whole exchange exposed after it.  Every gradient
+        element still receives the same sources in the same order and the same sum over the ranks: values unchanged.
+        ``set_exchange(None)`` goes back to the single launch."""
+        self._exchange, self._exchange_parts = start, max(1, int(parts)) if start is not None else 1
+
+    def partition(self, parts):
+        """The registered jobs split into <= ``parts`` groups by destination address -> [(lo, hi, [(dst, job)])]: element ranges of
+        ``flat`` cut at gradient boundaries (every parameter's gradient - hence every job's destination - lies in exactly one),
+        of roughly equal size, covering the whole buffer in address order."""
+        total = self.flat.numel()
+        starts = self.offsets + [total]
+        cuts = [0]
+        for k in range(1, parts):
+            want = total * k // parts
+            best = min(starts, key=lambda o: abs(o - want))            # the gradient boundary nearest to an even split
+            if best > cuts[-1] and best < total:
+                cuts.append(best)
+        cuts.append(total)
+        groups = [(lo, hi, []) for lo, hi in zip(cuts[:-1], cuts[1:])]
+        for dst, job in self._jobs.items():
+            el = (dst - self._lo) // 4
+            for lo, hi, items in groups:
+                if lo <= el < hi:
+                    items.append((dst, job))
+                    break
+        return groups
+
+    def tables(self, items=None):
+        """-> (jobs, srcs, nchunks) as numpy record arrays (host side of flush(); also what the CPU test inspects); ``items``: a
+        subset of the registered jobs as [(dst, job)] (one part of a chunked flush), default all."""
         import numpy as np
         job_dt, src_dt = _record_dtypes()
-        nj = len(self._jobs)
-        ns = sum(len(j['srcs']) for j in self._jobs.values())
+        items = list(self._jobs.items()) if items is None else items
+        nj = len(items)
+        ns = sum(len(j['srcs']) for _, j in items)
         jobs, srcs = np.zeros(nj, dtype=job_dt), np.zeros(ns, dtype=src_dt)
         chunk = si = 0
         # the longest per-thread walks first (a LayerNorm weight: ~500 partials per use): they would otherwise be the launch's tail.
         # (Order of the JOBS only - within a job the sources keep autograd's order, so the arithmetic does not change.)
-        order = sorted(self._jobs.items(), key=lambda kv: -sum(n for _, _, n in kv[1]['srcs']))
+        order = sorted(items, key=lambda kv: -sum(n for _, _, n in kv[1]['srcs']))
         for ji, (dst, j) in enumerate(order):
             numel, scale, row_len, cin, taps = j['meta']
             vec = dst % 16 == 0 and numel % 4 == 0 and row_len % 4 == 0 and cin % 4 == 0
@@ -242,34 +279,59 @@ class GradSink:
         counts = np.diff(np.append(jobs['chunk0'], np.uint32(nchunks))).astype(np.int64)
         return np.repeat(np.arange(len(jobs), dtype=np.uint32), counts)
 
+    def _reduce(self, jobs_ptr, srcs_ptr, cmap_ptr, njobs, nchunks):
+        """cotr_train_reduce_jobs on the tables at these device addresses (tests of the host logic replace this)."""
+        lib = _lib.load_library()
+        with _on(self.flat.device):
+            _chk(lib.cotr_train_reduce_jobs(ctypes.c_void_p(jobs_ptr), ctypes.c_void_p(srcs_ptr), ctypes.c_void_p(cmap_ptr), njobs,
+                                            nchunks, _sp()), 'cotr_train_reduce_jobs')
+
     def flush(self):
-        """One launch: every registered partial is summed into its gradient.  The partial buffers are released afterwards (the
-        caching allocator is stream-ordered: they are not reused before the launch has run)."""
+        """Every registered partial is summed into its gradient: ONE launch - or, with an exchange installed (set_exchange), one
+        launch per address range of the buffer, each followed by the start of that range's exchange between the ranks; returns
+        when all exchanges have been waited for (stream-ordered).  The tables of all launches go up in one copy.  The partial
+        buffers are released afterwards (the caching allocator is stream-ordered: they are not reused before the launches ran)."""
+        self.last_parts = []
         if not self._jobs:
             self.last = (0, 0)
+            if self._exchange is not None:                             # every rank must still take part in the collectives
+                self._exchange(self.flat)()
+                self.last_parts = [(0, self.flat.numel())]
             return
         import numpy as np
-        jobs, srcs, nchunks = self.tables()
-        cmap = self.chunk_map(jobs, nchunks)
-        jb, sb, cb = jobs.nbytes, srcs.nbytes, cmap.nbytes
-        assert jb + sb + cb <= self._host.numel(), 'GradSink capacity exceeded'
         capturing = self.flat.is_cuda and torch.cuda.is_current_stream_capturing()
+        chunked = self._exchange is not None and not capturing and not self.frozen
+        groups = self.partition(self._exchange_parts) if chunked else [(0, self.flat.numel(), list(self._jobs.items()))]
+        tabs, off = [], 0
+        for lo, hi, items in groups:
+            jobs, srcs, nchunks = self.tables(items)
+            cmap = self.chunk_map(jobs, nchunks)
+            tabs.append((lo, hi, jobs, srcs, cmap, nchunks, off))
+            off += (jobs.nbytes + srcs.nbytes + cmap.nbytes + 15) // 16 * 16
+        assert off <= self._host.numel(), 'GradSink capacity exceeded'
         if self._uploaded is not None and not capturing:
             self._uploaded.synchronize()                               # the previous upload has left the pinned buffer
         host = self._host.numpy()
-        host[:jb] = jobs.view(np.uint8)
-        host[jb:jb + sb] = srcs.view(np.uint8)
-        host[jb + sb:jb + sb + cb] = cmap.view(np.uint8)
-        self._dev[:jb + sb + cb].copy_(self._host[:jb + sb + cb], non_blocking=True)
+        for lo, hi, jobs, srcs, cmap, nchunks, o in tabs:
+            jb, sb, cb = jobs.nbytes, srcs.nbytes, cmap.nbytes
+            host[o:o + jb] = jobs.view(np.uint8)
+            host[o + jb:o + jb + sb] = srcs.view(np.uint8)
+            host[o + jb + sb:o + jb + sb + cb] = cmap.view(np.uint8)
+        self._dev[:off].copy_(self._host[:off], non_blocking=True)
         if self.flat.is_cuda and not capturing:
             self._uploaded = torch.cuda.Event()
             self._uploaded.record()
-        lib = _lib.load_library()
-        with _on(self.flat.device):
-            base = self._dev.data_ptr()
-            _chk(lib.cotr_train_reduce_jobs(ctypes.c_void_p(base), ctypes.c_void_p(base + jb), ctypes.c_void_p(base + jb + sb), len(jobs),
-                                            nchunks, _sp()), 'cotr_train_reduce_jobs')
-        self.last = (len(jobs), len(srcs))
+        base = self._dev.data_ptr()
+        finish = []
+        for lo, hi, jobs, srcs, cmap, nchunks, o in tabs:
+            if len(jobs):
+                self._reduce(base + o, base + o + jobs.nbytes, base + o + jobs.nbytes + srcs.nbytes, len(jobs), nchunks)
+            if chunked:
+                finish.append(self._exchange(self.flat[lo:hi]))        # runs beside the next range's reduction launch
+                self.last_parts.append((lo, hi))
+        for f in finish:
+            f()
+        self.last = (sum(len(t[2]) for t in tabs), sum(len(t[3]) for t in tabs))
         self._jobs, self._keep = {}, []
 
     def discard(self):
@@ -621,6 +683,15 @@ def col_blocks(x, row_blocks, col_blocks_):
     return res
 
 
+def _claim_grad_dst(t):
+    """The in-place gradient destination ColBlocks attached to this block view, for its FIRST consumer; None afterwards."""
+    dst = getattr(t, '_grad_dst', None) if t is not None else None
+    if dst is None or getattr(t, '_grad_dst_claimed', False):
+        return None
+    t._grad_dst_claimed = True
+    return dst
+
+
 class Attention(torch.autograd.Function):
     """o = dropout(softmax(q k^T * scale)) v per head - the core of nn.MultiheadAttention (transformer.py:149-153, 192-195).
     ``qk`` given: q and k are the two column halves of one [rows, 512] tensor (encoder self-attention: one projection launch
@@ -642,7 +713,11 @@ class Attention(torch.autograd.Function):
             q_t, k_t, ldq = q.contiguous(), _rows_view(k), 256
             ldk = k_t.stride(0)
             k_ptr = _P(k_t)
-        ctx.k_dst, ctx.v_dst = getattr(k, '_grad_dst', None), getattr(v, '_grad_dst', None)
+        # A block's gradient destination can be written in place by ONE consumer only: the first Attention to use a k / v block
+        # claims it, a second consumer of the same block (decode_train called twice with one kv list) gets no destination, returns
+        # a fresh dk / dv, and autograd adds the two before ColBlocks.backward copies the sum in - instead of the second write
+        # silently replacing the first.
+        ctx.k_dst, ctx.v_dst = _claim_grad_dst(k), _claim_grad_dst(v)
         v = _rows_view(v)
         ldv = v.stride(0)
         rows = nb * nq

@@ -428,8 +428,10 @@ def compute_loss(model, img, query, target, cycle_consis=True, bidirectional=Tru
         cycle = torch.stack([cycle[..., 0] - 0.5, cycle[..., 1]], dim=-1)
     mask = torch.norm(cycle - query, dim=-1) < 10 / MAX_SIZE
     if branch_free:
-        sel = mask.unsqueeze(-1).to(cycle.dtype)
-        loss = loss + (((cycle - query) ** 2) * sel).sum() / (2.0 * sel.sum()).clamp(min=1.0)
+        # select BEFORE squaring: a NaN / inf in an entry the mask rejects must not reach the sum (NaN * 0 is NaN) nor its
+        # gradient - cycle[mask] in the reference excludes such entries from both (its norm compares False: rejected)
+        diff = torch.where(mask.unsqueeze(-1), cycle - query, torch.zeros_like(cycle))
+        loss = loss + (diff ** 2).sum() / (2.0 * mask.sum()).clamp(min=1.0)
     elif mask.sum() > 0:
         loss = loss + F.mse_loss(cycle[mask], query[mask])
     return loss, pred
@@ -679,10 +681,22 @@ def train_batch(model, optim, img, query, target, cycle_consis=True, bidirection
     else:
         optim.zero_grad()
 
+    # several ranks + a sink: the gradient exchange starts from inside the sink's flush - the buffer is reduced in 3 address-ordered
+    # ranges, each range's reduce-scatter / all-gather issued right behind its reduction launch (dist.flat_exchange_async), so the
+    # exchange overlaps the rest of the reduction instead of following it.  (With a deferred NaN check the exchange of a step that
+    # turns out to be skipped has already run - on every rank alike, so the collectives stay matched - and is simply not used.)
+    exchange_in_flush = distributed and sink is not None and dist.get_world_size(group) > 1
+
     def backward(loss):
         if sink is not None:
-            with sink.collect():
-                loss.backward()
+            if exchange_in_flush:
+                from .dist import flat_exchange_async
+                sink.set_exchange(flat_exchange_async(group), parts=3)
+            try:
+                with sink.collect():
+                    loss.backward()
+            finally:
+                sink.set_exchange(None)
         else:
             loss.backward()
 
@@ -709,8 +723,9 @@ def train_batch(model, optim, img, query, target, cycle_consis=True, bidirection
             return value, pred.detach()                  # (the sink's buffer is zeroed at the start of the next step)
         optim.zero_grad()
     elif distributed and sink is not None:
-        from .dist import sync_flat_gradients
-        sync_flat_gradients(sink.flat, group)
+        if not exchange_in_flush:                        # (world size 1: the exchange is the identity; kept for the RCCL tests)
+            from .dist import sync_flat_gradients
+            sync_flat_gradients(sink.flat, group)
     elif distributed:
         sync_gradients([p for g in optim.param_groups for p in g['params']], group)
     optim.step()

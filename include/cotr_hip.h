@@ -39,7 +39,8 @@
 extern "C" {
 #endif
 
-#define COTR_HIP_ABI_VERSION 1
+#define COTR_HIP_ABI_VERSION 2   /* 2: tuning knobs per handle (cotr_set_knob(h, ...)), the cotr_set_<knob>(int) functions are gone;
+                                  cotr_train_attention_bwd takes a scratch argument; experiments live in libcotr_hip_exp.so */
 
 #define COTR_OK 0
 #define COTR_ERR_ARG (-1)    /* bad argument (null pointer, bad shape)                     */
@@ -154,10 +155,6 @@ int cotr_op_attention(const float* q, int ldq, const float* k, const float* v, i
 int cotr_op_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
                             float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
                             float* part, int nb, int nq, cotr_stream stream);
-/* decoder tail: out[b][q][0..1] = corr_embed(LayerNorm(x)) for x [nb_pairs*nq, 256]; hs (optional) receives the normalised rows */
-int cotr_op_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
-                     const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
-                     cotr_stream stream);
 /* y = LayerNorm(sum_c parts[c] + bias + residual) over rows of 256; parts [np][rows][256]; residual may be NULL */
 int cotr_op_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                       float* y, int rows, cotr_stream stream);
@@ -306,118 +303,59 @@ int cotr_dense_merge(const float* maps, const int32_t* boxes, int n_pairs, int s
  * of the squared images back to the image shape (sparse_engine.py:124-129). */
 int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd, int Wd, cotr_stream stream);
 
-/* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests -------------------
- * The cotr_set_* functions WITHOUT a handle argument below are PROCESS-WIDE tuning / experiment switches
- * (they change which kernels every handle of the process launches); they are not part of the drop-in
- * boundary and a binding never needs them. */
+/* ---- tuning knobs -------------------------------------------------------------------------------------------
+ * Named integer switches that choose between launch schedules / kernel variants with the SAME results (bit-identical unless a
+ * knob's line says otherwise).  They are not part of the drop-in boundary: a binding never needs them.  ONE SET PER HANDLE:
+ * cotr_set_knob(h, ...) affects only that handle's cotr_encode / cotr_decode / cotr_forward / cotr_backbone calls (two handles, or
+ * two threads, can differ); a new handle starts from the shipped defaults.  h == NULL addresses the process-wide set read by the
+ * handle-less op-level entry points below (cotr_op_*, cotr_bench_*, cotr_train_*: tests and tools).  count / name enumerate the
+ * knobs, get returns the current and the shipped default value, reset puts every knob of that set back to its default; a value
+ * outside a knob's range is refused with COTR_ERR_ARG.
+ *
+ *   encode_chunk               pairs per backbone / encoder pass inside cotr_encode (1..128, default 64; 64 is +2-3 % over 32 from 64
+ *                              pairs up, 128 is -20 %).  Scratch of a pass is ~66 MB per pair: set BEFORE sizing a caller-supplied
+ *                              workspace (cotr_scratch_bytes uses the handle's value)
+ *   attention_fusion_max_rows  up to this many rows (default 1024; 0 = never) the attention kernel also does the output projection
+ *                              (per-head partials summed + bias + residual + LayerNorm by one ln_reduce launch) and, in the
+ *                              decoder, the q projection of its own queries
+ *   ffn_fusion_max_rows        the fused FFN block (ffn.hip) for at most this many rows (default 1024; 0 = never)
+ *   ks3                        1 (default): K-deep small-M GEMMs the table gives to the two-stage LDS-DMA k-split run its three-stage form
+ *   dual_conv                  1 (default): downsample + conv1 of a ResNet stage's entry block as one launch at few pairs
+ *   fused_stem                 1 (default): conv1 + bn1 + relu + maxpool as one launch (stem_pool.hip)
+ *   xcd_mapping                workgroup -> XCD mapping, a bit field (default 1): bits 0-1 GEMM / conv tiles (0 = column tiles over the
+ *                              8 XCDs, 2 = row tiles, 1 = per launch by operand size); bit 2 fused FFN: hidden-unit chunks over XCDs;
+ *                              bit 3 attention: heads over XCDs; bit 4 fused FFN: plain instead of write-through partial stores
+ *   attention_fused_splits     key splits of the fused attention: 0 (default = 4), 4, 8, 48 / 84 (encoder / decoder separately)
+ *   conv_patch                 1 (default): layer3's 3x3 convolutions at few pairs load their input patch once
+ *   pos_table_min_rows         token rows from which the encoder in-projections take pos . W^T from tables built at cotr_load_weights
+ *                              (default 8192; >= 2^30 also turns the K/V projection's table off; +1 fp32 addition per output)
+ *   attention_wide_min_rows    query rows of a launch from which the 64-query / resident-K/V attention kernels are used (default 4096)
+ *   attention_wide_occupancy   wavefronts per SIMD of the 64-query kernel: 3 (default) or 2
+ *   attention_splits           key splits of the plain attention kernel: 0 (automatic), 1, 2, 4, 8, 16
+ *   attention_resident         1 (default): K_h / V_h resident in LDS for many rows (attention_res_kernel)
+ *   conv1x1_dense              1 (default): a 1x1 stride-1 convolution is launched as the dense product of its pixel rows
+ *   ws_flags                   wave-specialised large tiles (configurations 40 / 41): bit 0 priority for the MFMA wavefronts' loop,
+ *                              bit 1 (default) for the loaders
+ *   bottleneck_max_pairs       layer1's bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass (default 4)
+ *   train_attention_form       training attention backward: 0 (default) = by shape, 1-3 = force the first / second / one-pass form
+ * libcotr_hip_exp.so (the experimental build, -DCOTR_EXPERIMENTAL) adds the knobs of the measured dead ends, all off by default:
+ *   head_fusion_max_rows, ffn_preln, ffn_tail, coop_tail, coop_tail_spin, gemm_ln_min_rows  (cotr_amd/csrc/experimental/experimental.h) */
+int cotr_knob_count(void);
+const char* cotr_knob_name(int i);
+int cotr_get_knob(cotr_handle h, const char* name, int* value, int* default_value);
+int cotr_set_knob(cotr_handle h, const char* name, int value);
+int cotr_reset_knobs(cotr_handle h);
+/* 1 in libcotr_hip_exp.so, 0 in the product library */
+int cotr_is_experimental(void);
+
+/* ---- GEMM configuration tuning (tools/tune_gemm.py) and per-config tests ------------------- */
 int cotr_gemm_num_configs(void);
-/* pairs per backbone/encoder pass inside cotr_encode (1..128, default 64): larger passes fill the CUs better (64 per pass: +2-3 %
- * over 32 from 64 pairs up; 128: -20 %).  The scratch of a pass is ~66 MB per pair: set this BEFORE sizing a caller-supplied
- * workspace (cotr_scratch_bytes uses the current value; a workspace sized for a smaller chunk is refused with an error, not overrun) */
-int cotr_set_encode_chunk(int pairs);
-/* up to this many rows (default 2048; 0 = never) decoder.norm + corr_embed run as ONE row-local launch (head.hip) instead
- * of layernorm + two linears + the 256 -> 2 head */
-int cotr_set_head_fusion_max_rows(int rows);
-/* up to this many rows (default 1024; 0 = never) the attention kernel also does the output projection (per-head partial
- * outputs summed + bias + residual + LayerNorm by one ln_reduce launch) and, in the decoder, the q projection of its own
- * queries: 5 (encoder) / 4 (decoder) launches per transformer layer instead of 6 */
-int cotr_set_attention_fusion_max_rows(int rows);
-/* the fused FFN block (ffn.hip) is used for GEMMs with at most this many rows (default 1024); 0 = never */
-int cotr_set_ffn_fusion_max_rows(int rows);
-/* 1: where the fused FFN block is used, the LayerNorm that precedes it (norm1 of an encoder layer, norm2 of a decoder
- * layer: transformer.py:155,198) is applied inside it - to the X tile in LDS and to the residual row in ln_reduce - instead of
- * in a launch of its own (bit-identical, 12 launches fewer at one pair, but measured time-neutral: 1.041 vs 1.036 ms);
- * 0 (default): separate layernorm launch */
-int cotr_set_ffn_preln(int enable);
-/* 1: the fused FFN kernel also sums its partial outputs and applies bias + residual + LayerNorm (last-arriving workgroup
- * of each row tile; same bits as the separate ln_reduce launch); 0 (default): two launches - the single-launch form
- * measured SLOWER (one CU has to pull the 512 KB of partials of its row tile), see DESIGN.md 4b */
-int cotr_set_ffn_tail(int enable);
-/* 1 (default): K-deep (K >= 768) small-M GEMMs / convolutions that the measured table gives to the two-stage LDS-DMA k-split
- * kernel run on its three-stage form (two tiles of DMA in flight across the barrier, counted vmcnt); 0: two stages */
-int cotr_set_ks3(int enable);
-/* 1 (default): in the entry block of each ResNet stage the downsample convolution and conv1 (both read the block input) go
- * out as one launch at up to two pairs per pass; 0: two launches */
-int cotr_set_dual_conv(int enable);
-/* 1 (default): conv1 + bn1 + relu + maxpool of the ResNet stem as one launch (stem_pool.hip); 0: implicit-GEMM stem + separate
- * max-pool kernel (also used whenever debug taps are on: the 'stem' tap is the un-pooled conv output) */
-int cotr_set_fused_stem(int enable);
-/* workgroup -> XCD mapping (which operand crosses the fabric once chip-wide instead of once per XCD), a bit field:
- *   bits 0-1  GEMM / conv kernels: 0 = column tiles spread over the 8 XCDs (weights once, activations per XCD),
- *             2 = row tiles spread over the XCDs (the other way round), 1 = per launch by operand size
- *   bit 2     fused FFN: hidden-unit chunks spread over the XCDs (W1/W2 once) instead of row tiles
- *   bit 3     attention: heads spread over the XCDs (K_h/V_h once) instead of query tiles
- *   bit 4     fused FFN: plain write-back stores for the partial outputs instead of the default write-through (sc1) ones
- * Experiments / profiling only; see DESIGN.md for the measured trade-off. */
-int cotr_set_xcd_mapping(int policy);
-/* key splits of the FUSED attention variants (q-projection prologue / out-projection epilogue): 4, 8, or 0 = default (4; 8 measured
- * slower even on the 128-workgroup encoder grid of one pair) */
-int cotr_set_attention_fused_splits(int ns);
-/* 3x3 stride-1 convolutions over 256 input channels (layer3) at few pairs: load the 3 x 34 input pixels of a 32-pixel output
- * row segment once and read the nine taps from that patch, instead of nine shifted A tiles (default on) */
-int cotr_set_conv_patch(int enable);
-/* encoder in-projections and the hoisted decoder K/V projection over at least this many token rows take the pos . W^T term
- * from tables computed at cotr_load_weights (a row-periodic residual of a plain GEMM on the LDS-DMA large-tile kernel) instead of
- * adding pos to the activations in a register prologue; default 8192 (16 pairs).  The K/V projection (3072 columns) takes its table
- * at any row count unless rows >= 2^30 is set here (= tables off) */
-int cotr_set_pos_table_min_rows(int rows);
-/* launches with at least this many query rows (pairs x queries) use the 64-queries-per-workgroup attention kernel (two query
- * tiles per wavefront share every K/V fragment); bit-identical results; default 4096; only when attention_splits is automatic */
-int cotr_set_attention_wide_min_rows(int rows);
-/* register budget of that kernel: 3 wavefronts per SIMD with Q parked in LDS (default), or 2 with Q in registers */
-int cotr_set_attention_wide_occupancy(int waves_per_simd);
-/* key splits (wavefronts per workgroup) of the attention kernel: 1, 2, 4, 8, 16, or 0 = automatic */
-int cotr_set_attention_splits(int ns);
-/* 1 (default): a 1x1 stride-1 convolution is launched as the dense product of its pixel rows (same configuration, same
- * summation order, bit-identical) - the dense kernels skip the per-row pixel decomposition of the convolution prologue */
-int cotr_set_conv1x1_dense(int enable);
-/* 1: the launches that leave per-workgroup partial outputs of a row tile (the fused FFN block: one per hidden-unit chunk; attention
- * with the out-projection fused in: one per head) also sum them, add bias + residual and apply LayerNorm - each workgroup of a row
- * tile for its own share of the rows, the tile's last-arriving workgroup for every share nobody claimed (coop_tail.h: bounded waits
- * only, bit-identical to the separate ln_reduce launch) - 24 launches fewer per forward at one pair.  0 (default): ln_reduce
- * launches - the cooperative form measured slower (1.001 vs 0.824 ms per forward: every device-scope atomic / sc1 round trip of the
- * hand-off costs 1-2 us on this chip, four of them per tail against 1.7 us of dispatch + 2.3 us of ln_reduce) */
-int cotr_set_coop_tail(int enable);
-/* polls of the tile's arrival word before a workgroup leaves its share to the last arriver (default 4000, ~0.3 us each; 0 = never
- * wait: the last arriver finishes the whole tile - the schedule-independence test) */
-int cotr_set_coop_tail_spin(int polls);
-/* training attention kernels: 1 = the first form (wavefronts split the walk over the other side's tiles, partial results reduced through
- * LDS at the end); 2 = a wavefront owns its queries (forward, dQ) or its keys (dK / dV) and walks the other side's tiles, which the
- * workgroup shares through LDS; 3 = forward as 2, the backward in ONE pass (K / V of a head parked in LDS, dS transposed through LDS for
- * the dQ product: 5 matrix products instead of 7); 0 (default) = 3 where it is faster (>= 24 pairs, >= 256 queries), else 2 */
-int cotr_set_train_attention_form(int form);
-/* attention over many query rows (>= attention_wide_min_rows rows, >= 256 queries per pair): 1 (default) = K_h / V_h of a head resident in
- * LDS for a whole chunk of query tiles (attention_res_kernel), 0 = the 64-query kernel that re-fetches them per workgroup; bit-identical */
-int cotr_set_attention_resident(int enable);
-/* rows from which a 256-wide projection followed by a LayerNorm (attention out-projection + norm, linear2 + norm) is ONE launch
- * (gemm_ln.hip: a workgroup owns 128 complete rows; bit-identical to the two-launch form).  Default: off (1 << 30) - measured equal
- * to the two launches inside the forward; 24576 is the value it was measured with */
-int cotr_set_gemm_ln_min_rows(int rows);
-/* y [M][256] = LayerNorm(x [M][K] . w [256][K]^T + bias + residual [M][256]) * ln_w + ln_b in one launch (op-level entry for the tests) */
-int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const float* residual, const float* ln_w, const float* ln_b,
-                      float* y, int M, int K, cotr_stream stream);
-/* layer1's bottlenecks (conv1 1x1 -> conv2 3x3 -> conv3 1x1 + identity / downsample, FrozenBN, ReLU: torchvision
- * Bottleneck.forward, COTR/models/backbone.py:46-56) run as ONE launch each (bottleneck.hip) for passes of up to this many pairs
- * (default 4: the latency-bound regime - at 8 pairs it is time-neutral, above that the halo recompute of conv1 loses; 0 = never):
- * 9 launches of layer1 become 3 */
-int cotr_set_bottleneck_max_pairs(int pairs);
 /* one layer1 bottleneck from unpacked device weights (tests): x [B][64][128][cin] -> y [B][64][128][256]; cin = 64 with the
  * downsample branch (wd != NULL) or 256 without; w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wd [256][64]; s* / b* FrozenBN
  * scale / bias per output channel */
 int cotr_op_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2, const float* w3, const float* wd,
                        const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,
                        const float* sd, const float* bd, cotr_stream stream);
-/* wave-specialised large-tile GEMM (configurations 40 / 41: 4 loader + 4 MFMA wavefronts): bit 0 = raised issue priority around
- * the MFMA wavefronts' loop, bit 1 (default) = raised priority for the loader wavefronts */
-int cotr_set_ws_flags(int flags);
-/* The process-wide switches above as a registry (name = the part after cotr_set_): count / name enumerate them, get returns
- * the current and the shipped default value, set is cotr_set_<name>(value), reset puts EVERY switch back to its default.
- * Tests and A/B tools snapshot and restore through these instead of hand-written constants. */
-int cotr_knob_count(void);
-const char* cotr_knob_name(int i);
-int cotr_get_knob(const char* name, int* value, int* default_value);
-int cotr_set_knob(const char* name, int value);
-int cotr_reset_knobs(void);
 /* microseconds per launch of one shape under config `cfg` (-1: the library's own choice), measured
  * with HIP events around a captured graph of `iters` launches on a private stream */
 int cotr_bench_linear(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int cfg,
@@ -445,6 +383,17 @@ int cotr_debug_conv_times(const float* x, const float* w, const float* scale, co
 int cotr_op_conv_dual_cfg(const float* x, const float* w0, const float* scale0, const float* bias0, int relu0, float* y0, int Cout0,
                           int ksize0, int stride0, const float* w1, const float* scale1, const float* bias1, int relu1, float* y1,
                           int Cout1, int ksize1, int stride1, int B, int Hin, int Win, int Cin, int cfg, cotr_stream stream);
+
+/* ---- libcotr_hip_exp.so only (COTR_EXPERIMENTAL): op-level entry points of two measured dead ends ---- */
+#ifdef COTR_EXPERIMENTAL
+/* decoder tail: out[b][q][0..1] = corr_embed(LayerNorm(x)) for x [nb_pairs*nq, 256]; hs (optional) receives the normalised rows */
+int cotr_op_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
+                     const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
+                     cotr_stream stream);
+/* y [M][256] = LayerNorm(x [M][K] . w [256][K]^T + bias + residual [M][256]) * ln_w + ln_b in one launch (op-level entry for the tests) */
+int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const float* residual, const float* ln_w, const float* ln_b,
+                      float* y, int M, int K, cotr_stream stream);
+#endif
 
 #ifdef __cplusplus
 }

@@ -19,10 +19,11 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _library_knobs_back_to_default(request):
-    """The library's tuning switches (cotr_set_*) are process-wide.  A GPU test that flips one must not leak it into the tests
-    that follow (round 2: a hand-written "restore" constant left the whole rest of the suite on a non-shipped kernel), so after
-    every GPU test every switch is put back to its shipped default through the library's own registry (cotr_reset_knobs) and
-    the registry is checked to report exactly the defaults."""
+    """Tuning knobs live in the library handle of each model (cotr_set_knob(h, ...)); the handle-less op-level entry points
+    (cotr_op_*, cotr_train_*) read ONE process-wide set (cotr_set_knob(NULL, ...)).  A GPU test that flips a process-wide knob must
+    not leak it into the tests that follow (round 2: a hand-written "restore" constant left the rest of the suite on a non-shipped
+    kernel): after every GPU test that set is reset through the library's own registry and checked to report exactly the
+    defaults; models cached across tests (tests/test_parity_gpu.py) are checked the same way."""
     yield
     if request.node.get_closest_marker('gpu') is None:
         return
@@ -31,4 +32,8 @@ def _library_knobs_back_to_default(request):
         return
     _lib.reset_knobs()
     off = {k: v for k, v in _lib.knobs().items() if v[0] != v[1]}
-    assert not off, f'knobs not at their defaults after reset: {off}'
+    assert not off, f'process-wide knobs not at their defaults after reset: {off}'
+    mod = sys.modules.get('tests.test_parity_gpu')
+    for m in (getattr(mod, '_models', {}) if mod else {}).values():
+        off = {k: v for k, v in m.knobs().items() if v[0] != v[1]}
+        assert not off, f'a cached model was left with non-default knobs: {off}'

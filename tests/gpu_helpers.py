@@ -1,6 +1,7 @@
 """Shared helpers of the GPU parity tests: layout conversions between the reference's
 NCHW / sequence-first tensors and the library's NHWC side-by-side / batch-major ones,
 and thin wrappers over the cotr_op_* entry points."""
+import contextlib
 import ctypes
 
 import torch
@@ -68,3 +69,15 @@ def op_conv(x_sbs, w_packed, scale, bias, residual, relu, cout, k, stride):
 
 def pack_conv_weight(w):  # [Cout,Cin,k,k] -> [Cout,k,k,Cin]
     return w.permute(0, 2, 3, 1).contiguous()
+
+
+@contextlib.contextmanager
+def model_knobs(model, **knobs):
+    """Tuning knobs of ONE model's library handle (cotr_set_knob(h, ...)) for the duration of a with-block; always put back to
+    the shipped defaults afterwards (models are cached across tests)."""
+    try:
+        for name, value in knobs.items():
+            model.set_knob(name, value)
+        yield model
+    finally:
+        model.reset_knobs()

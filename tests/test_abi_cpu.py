@@ -10,7 +10,7 @@ import torch
 
 import cotr_amd
 from cotr_amd import _lib
-from cotr_amd.build import LIB, build_library
+from cotr_amd.build import LIB, LIB_EXP, build_library
 from cotr_amd.models import build_model, NestedTensor
 from cotr_amd.models.spec import state_spec
 from cotr_amd.utils.synth import synth_state_dict
@@ -18,22 +18,39 @@ from cotr_amd.utils.synth import synth_state_dict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
+def declared_functions(experimental=False):
+    """function names include/cotr_hip.h declares; the #ifdef COTR_EXPERIMENTAL block only for the experimental library"""
     src = open(os.path.join(ROOT, 'include', 'cotr_hip.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    if not experimental:
+        src = re.sub(r'#ifdef COTR_EXPERIMENTAL.*?#endif', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(cotr_[a-z0-9_]+)\s*\(', src)))
 
 
+def exported_functions(path):
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if ' T cotr_' in l)
+
+
 def test_library_builds_and_exports_every_declared_symbol():
+    """Both ways round, for both libraries: every declared function is exported and every exported cotr_* function is declared
+    (the experimental library = the product's declarations + the #ifdef COTR_EXPERIMENTAL block)."""
     build_library()
-    assert os.path.exists(LIB)
-    lib = ctypes.CDLL(LIB)
-    names = declared_functions()
-    assert len(names) >= 20
-    for n in names:
-        assert hasattr(lib, n), f'{n} declared in include/cotr_hip.h but not exported'
-    assert set(_lib.EXPORTED_SYMBOLS) <= set(names)          # the ctypes binding binds only declared symbols
-    assert _lib.load_library().cotr_abi_version() == 1
+    build_library(experimental=True)
+    for path, experimental in ((LIB, False), (LIB_EXP, True)):
+        assert os.path.exists(path)
+        names = declared_functions(experimental)
+        assert len(names) >= 20
+        assert exported_functions(path) == names, (set(names) ^ set(exported_functions(path)))
+    assert set(_lib.EXPORTED_SYMBOLS) <= set(declared_functions())          # the ctypes binding binds only declared symbols
+    assert set(_lib.EXPERIMENTAL_SYMBOLS) == set(declared_functions(True)) - set(declared_functions())
+    assert _lib.load_library().cotr_abi_version() == _lib.ABI_VERSION == 2
+    src = open(os.path.join(ROOT, 'include', 'cotr_hip.h')).read()
+    assert re.search(r'#define COTR_HIP_ABI_VERSION 2\b', src)
+    # none of the former process-wide setters survives (ABI 2: knobs are per handle)
+    assert not [n for n in exported_functions(LIB) if n.startswith('cotr_set_') and n not in
+                ('cotr_set_knob', 'cotr_set_workspace', 'cotr_set_debug_taps', 'cotr_set_profiling')]
 
 
 def test_error_paths_without_a_gpu():
@@ -93,20 +110,75 @@ def test_no_cpu_fallback_and_shape_contract():
 
 
 def test_knob_registry_round_trip_without_a_gpu():
-    """cotr_set_* switches are process-wide; the registry (cotr_knob_count / _name / get / set / reset) is what tests and A/B
-    tools snapshot and restore through.  Setting and resetting needs no device."""
+    """Knobs live in a registry per library handle (cotr_set_knob(h, ...)); handle NULL is the process-wide set the handle-less
+    op-level entry points read.  count / name / get / set / reset need no device; the model object remembers knobs set before
+    its handle exists.  The product library does not know the knobs of the measured dead ends."""
     k0 = _lib.knobs()
-    assert len(k0) >= 17 and all(cur == dflt for cur, dflt in k0.values())
-    assert k0['head_fusion_max_rows'] == (0, 0) and k0['attention_fusion_max_rows'] == (1024, 1024)
+    assert len(k0) == 18 and all(cur == dflt for cur, dflt in k0.values())
+    assert k0['attention_fusion_max_rows'] == (1024, 1024) and k0['encode_chunk'] == (64, 64)
+    for exp_only in ('head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail', 'coop_tail_spin', 'gemm_ln_min_rows'):
+        assert exp_only not in k0
     try:
-        _lib.set_knob('head_fusion_max_rows', 2048)
         _lib.set_knob('conv1x1_dense', 0)
-        assert _lib.load_library().cotr_set_ffn_fusion_max_rows(0) == 0      # the direct setters record too
+        _lib.set_knob('ffn_fusion_max_rows', 0)
         k1 = _lib.knobs()
-        assert k1['head_fusion_max_rows'] == (2048, 0) and k1['conv1x1_dense'] == (0, 1) and k1['ffn_fusion_max_rows'] == (0, 1024)
+        assert k1['conv1x1_dense'] == (0, 1) and k1['ffn_fusion_max_rows'] == (0, 1024)
         with pytest.raises(_lib.CotrHipError):
             _lib.set_knob('no_such_knob', 1)
-        assert _lib.load_library().cotr_set_knob(b'xcd_mapping', 3) != 0    # the setter's own range check applies
+        with pytest.raises(_lib.CotrHipError):
+            _lib.set_knob('coop_tail', 1)
+        for name, bad in (('xcd_mapping', 3), ('xcd_mapping', 32), ('encode_chunk', 0), ('encode_chunk', 129), ('attention_splits', 3),
+                          ('attention_fused_splits', 5), ('ks3', 2), ('attention_wide_occupancy', 4), ('ffn_fusion_max_rows', -1)):
+            assert _lib.load_library().cotr_set_knob(None, name.encode(), bad) != 0, (name, bad)
+        assert _lib.knobs() == k1                           # a refused value changes nothing
     finally:
         _lib.reset_knobs()
     assert _lib.knobs() == k0
+    m = build_model(cotr_amd.default_args())                # no handle yet (CPU): remembered, applied when the handle is created
+    m.set_knob('encode_chunk', 32)
+    assert m.knobs()['encode_chunk'] == (32, 64) and _lib.knobs()['encode_chunk'] == (64, 64)
+    m.reset_knobs()
+    assert m.knobs()['encode_chunk'] == (64, 64)
+
+
+def test_experimental_library_has_the_dead_ends_and_their_knobs():
+    """libcotr_hip_exp.so (python -m cotr_amd.build --experimental): same ABI version, cotr_is_experimental() = 1, six more knobs
+    (all at 'off'), two more op-level entry points.  Opened next to the product library with plain ctypes (RTLD_LOCAL)."""
+    build_library(experimental=True)
+    lib = ctypes.CDLL(LIB_EXP)
+    assert lib.cotr_abi_version() == 2 and lib.cotr_is_experimental() == 1
+    assert _lib.load_library().cotr_is_experimental() == 0
+    lib.cotr_knob_name.restype = ctypes.c_char_p
+    names = [lib.cotr_knob_name(i).decode() for i in range(lib.cotr_knob_count())]
+    assert names[:18] == list(_lib.knobs()) and names[18:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
+                                                                 'coop_tail_spin', 'gemm_ln_min_rows']
+    for n, want in (('head_fusion_max_rows', 0), ('ffn_preln', 0), ('ffn_tail', 0), ('coop_tail', 0), ('gemm_ln_min_rows', 1 << 30)):
+        cur, dflt = ctypes.c_int(), ctypes.c_int()
+        assert lib.cotr_get_knob(None, n.encode(), ctypes.byref(cur), ctypes.byref(dflt)) == 0 and cur.value == dflt.value == want
+
+
+def test_first_run_kit_applies_the_one_line_switch(tmp_path):
+    """tools/first_run_check.py --patch on a copy of the reference's COTR/models/__init__.py (authoring container only: the
+    reference is not on the GPU box): the switch of INTEGRATION.md section 1 goes in, the original is kept, a second run is a
+    no-op, and the patched module resolves build_model to the cotr_amd binding."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import sys
+    src = '/root/reference/COTR/models/__init__.py'
+    if not os.path.exists(src):
+        pytest.skip('no reference checkout here')
+    pkg = tmp_path / 'COTR' / 'models'
+    pkg.mkdir(parents=True)
+    shutil.copy(src, pkg / '__init__.py')
+    tool = os.path.join(ROOT, 'tools', 'first_run_check.py')
+    for _ in range(2):
+        subprocess.run([sys.executable, tool, '--patch', str(pkg / '__init__.py')], check=True, cwd=ROOT)
+    assert (pkg / '__init__.py.orig').read_text() == open(src).read()
+    patched = (pkg / '__init__.py').read_text()
+    assert 'from cotr_amd.models import build_model' in patched and 'from .cotr_model import build' in patched
+    spec = importlib.util.spec_from_file_location('patched_models', pkg / '__init__.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)                                    # cotr_amd is importable here: the try branch wins
+    from cotr_amd.models import build_model as ours
+    assert mod.build_model is ours

@@ -41,3 +41,23 @@ def test_bench_batch_workload_shards_pairs_and_gathers_inside_the_timed_region()
 def test_bench_single_rank_dry_run():
     line = _run(['--dry-run', '--backend', 'gloo'], _clean_env())
     assert line['n_gpus'] == 1 and line['gathered_rows'] == 1
+
+
+def test_bench_dense_workload_shards_the_queries_of_one_pair():
+    """--workload dense: ONE pair x the query grid, the QUERIES sharded over the ranks through dist.PairShardedModel (each rank
+    encodes the pair, decodes its slice), all-gather inside the timed region, strong scaling; the gathered prediction equals
+    the unsharded one and the line says which ranks / devices the communicator really had."""
+    line = _run(['--gpus', '2', '--workload', 'dense', '--backend', 'gloo', '--dry-run'], _clean_env())
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['dry_run'] is True
+    assert line['dense_check'] == {'equals_unsharded': True, 'queries_this_rank': 516, 'queries_total': 1031}
+    assert line['gathered_rows'] == 1031
+    assert line['rccl_ranks'] == 2 and line['backend'] == 'gloo'
+    assert [r['rank'] for r in line['ranks']] == [0, 1] and len({r['pid'] for r in line['ranks']}) == 2
+    assert all(r['name'] == 'cpu' for r in line['ranks'])
+
+
+def test_every_multi_rank_line_names_its_ranks():
+    line = _run(['--gpus', '2', '--steps', '2', '--warmup', '0', '--backend', 'gloo', '--dry-run'], _clean_env())
+    assert line['rccl_ranks'] == 2 and len(line['ranks']) == 2
+    single = _run(['--workload', 'dense', '--dry-run', '--backend', 'gloo'], _clean_env())
+    assert single['rccl_ranks'] == 1 and single['dense_check']['queries_this_rank'] == 1031

@@ -180,3 +180,106 @@ def test_sharded_zoom_engine_equals_reference_engine(tmp_path, golden_dir):
         port = s.getsockname()[1]
     mp.spawn(_engine_worker, args=(2, port, golden_dir, str(tmp_path)), nprocs=2, join=True)
     assert all(torch.load(os.path.join(str(tmp_path), f'e{r}.pt')) for r in range(2))
+
+
+# ---- gradient exchange: chunked GradSink flush with the exchange started behind every chunk (train_ops.GradSink.set_exchange) ----
+def _cpu_reduce_jobs(jobs_ptr, srcs_ptr, cmap_ptr, njobs, nchunks):
+    """What cotr_train_reduce_jobs does for plain jobs (no scale, no re-layout), on host memory: dst[i] += sum over the job's
+    sources (in order), over each source's partials (in order).  Stand-in for the HIP launch in the CPU test of the HOST logic."""
+    import ctypes
+    import numpy as np
+    from cotr_amd import train_ops as T
+    job_dt, src_dt = T._record_dtypes()
+    jobs = np.frombuffer((ctypes.c_char * (njobs * job_dt.itemsize)).from_address(jobs_ptr), dtype=job_dt)
+    nsrc = int(max(j['first_src'] + j['n_src'] for j in jobs))
+    srcs = np.frombuffer((ctypes.c_char * (nsrc * src_dt.itemsize)).from_address(srcs_ptr), dtype=src_dt)
+    cmap = np.frombuffer((ctypes.c_char * (nchunks * 4)).from_address(cmap_ptr), dtype=np.uint32)
+    assert sorted(set(cmap.tolist())) == list(range(njobs))              # every job has its chunks
+    for j in jobs:
+        n = int(j['numel'])
+        assert j['scale'] == 0 and j['taps'] == 1
+        dst = np.frombuffer((ctypes.c_char * (n * 4)).from_address(int(j['dst'])), dtype=np.float32)
+        acc = dst.copy()
+        for sidx in range(int(j['first_src']), int(j['first_src'] + j['n_src'])):
+            sr = srcs[sidx]
+            for p in range(int(sr['nparts'])):
+                part = np.frombuffer((ctypes.c_char * (n * 4)).from_address(int(sr['part']) + p * int(sr['pstride']) * 4), dtype=np.float32)
+                acc = acc + part
+        dst[:] = acc
+
+
+def _worker_sink(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cotr_amd import train_ops as T
+    from cotr_amd.dist import flat_exchange_async, sync_flat_gradients
+    shapes = [(256, 1024), (256,), (1000, 37), (64, 64), (5,), (768, 256), (3, 3)]
+
+    def run(chunked):
+        params = [torch.nn.Parameter(torch.zeros(*s)) for s in shapes]
+        sink = T.GradSink(params)
+        sink._reduce = _cpu_reduce_jobs
+        g = torch.Generator().manual_seed(100 + rank)
+        keep = []
+        for use in range(2):                                            # every parameter is used twice, like a cycle pass
+            for p in params:
+                nparts = 1 + (p.numel() % 3)
+                part = torch.randn(nparts * p.numel(), generator=g)
+                keep.append(part)
+                sink.add(p.grad.view(-1), part, 0, nparts, p.numel(), p.numel())
+        started = []
+        if chunked:
+            base = flat_exchange_async(None)
+
+            def start(piece):
+                started.append((int((piece.data_ptr() - sink.flat.data_ptr()) // 4), piece.numel()))
+                return base(piece)
+            sink.set_exchange(start, parts=3)
+            sink.flush()
+            sink.set_exchange(None)
+        else:
+            sink.flush()
+            sync_flat_gradients(sink.flat, None)
+        return sink.flat.clone(), started, sink.last_parts, sink.last
+
+    one, _, _, last_one = run(False)
+    three, started, parts, last_three = run(True)
+    torch.save({'one': one, 'three': three, 'started': started, 'parts': parts, 'last': (last_one, last_three)},
+               os.path.join(out_dir, f's{rank}.pt'))
+    # an odd world size does not divide the buffer (a multiple of 64 floats): the tail goes through its own tiny all-reduce
+    odd = torch.arange(64 * 5 + 0, dtype=torch.float32) * (rank + 1)
+    sync_flat_gradients(odd, None)
+    torch.save(odd, os.path.join(out_dir, f'odd{rank}.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_chunked_sink_flush_with_exchange_equals_flush_then_exchange(tmp_path, world):
+    """GradSink.flush() with an exchange installed (training.train_batch on several ranks): the buffer is reduced in three
+    address-ordered ranges cut at gradient boundaries, each range's reduce-scatter / all-gather started right behind its reduction;
+    the averaged gradients are those of ONE reduction followed by ONE exchange of the whole buffer - bit for bit on two ranks, to
+    one rounding of the rank sum's association on three - and identical on every rank.
+    World size 3 does not divide the ranges: sync_flat_gradients' tail path."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_sink, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f's{r}.pt') for r in range(world)]
+    total = res[0]['one'].numel()
+    for r in res:
+        assert torch.equal(r['one'], res[0]['one'])                      # every rank holds the same average
+        if world == 2:
+            assert torch.equal(r['three'], r['one'])                     # chunked = unchunked, bit for bit (a + b is commutative)
+        else:
+            # three ranks: WHICH rank's partial sum a reduce-scatter element passes through depends on the element's position in
+            # the exchanged buffer ((a + b) + c here, (b + c) + a there), and the chunked exchange moves those positions: the same
+            # sum over the same ranks in another association - one rounding apart, as between any two collective algorithms
+            assert torch.allclose(r['three'], r['one'], rtol=1e-6, atol=2e-6)
+        assert float(r['one'].abs().max()) > 0
+        assert len(r['parts']) == 3 and r['parts'][0][0] == 0 and r['parts'][-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(r['parts'], r['parts'][1:]))
+        assert r['started'] == [(lo, hi - lo) for lo, hi in r['parts']]  # one exchange per range, in address order
+        assert r['last'][0] == r['last'][1] == (7, 14)                   # the same 7 jobs / 14 sources either way
+    want = sum(torch.arange(64 * 5, dtype=torch.float32) * (r + 1) for r in range(world)) / world
+    for r in range(world):
+        assert torch.allclose(torch.load(tmp_path / f'odd{r}.pt'), want, rtol=1e-6, atol=0)

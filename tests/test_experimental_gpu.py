@@ -1,0 +1,305 @@
+"""The MEASURED DEAD ENDS (cotr_amd/csrc/experimental/: cooperative tails, fused decoder head, GEMM + LayerNorm tile, FFN tail /
+pre-norm, large-tile configurations 28 / 29) live in libcotr_hip_exp.so only.  These are their tests; they run in a process that
+loaded the experimental library (COTR_HIP_EXPERIMENTAL=1) - tests/test_experimental_runner_gpu.py starts that process from the
+ordinary `pytest -m gpu` run, so one GPU test run covers both libraries.  With every experimental knob at its default the
+experimental library runs exactly the product schedule (first test)."""
+import importlib.util
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cotr_amd
+from cotr_amd import _lib
+from cotr_amd.models import build_model
+from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+from oracle import cotr_oracle
+from tests import gpu_helpers as G
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not _lib.experimental_selected(), reason='needs COTR_HIP_EXPERIMENTAL=1 (libcotr_hip_exp.so)')]
+
+_spec = importlib.util.spec_from_file_location(
+    'make_golden', os.path.join(os.path.dirname(__file__), 'golden', 'make_golden.py'))
+make_golden = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(make_golden)
+
+PX_BAR = 1e-3
+SHAPE_NOISE_PX = 3e-4
+_models = {}
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def hip_model(seed=0, gain=1.0):
+    key = (seed, gain)
+    if key not in _models:
+        m = build_model(cotr_amd.default_args()).cuda().eval()
+        m.load_state_dict(synth_state_dict(seed, attn_gain=gain))
+        _models[key] = m
+    return _models[key]
+
+
+def test_experimental_library_is_loaded_and_defaults_to_the_product_schedule(golden_dir):
+    lib = _lib.load_library()
+    assert lib.cotr_is_experimental() == 1 and os.path.basename(_lib.library_path()) == 'libcotr_hip_exp.so'
+    for k in ('head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail', 'coop_tail_spin', 'gemm_ln_min_rows'):
+        assert k in _lib.knobs()
+    g = np.load(os.path.join(golden_dir, 'primary_b1_q1000.npz'))
+    sd, img, qs = make_golden.case_inputs('primary_b1_q1000')
+    wseed, gain = make_golden.CASES['primary_b1_q1000'][:2]
+    m = hip_model(wseed, gain)
+    m.set_profiling(2)
+    out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    torch.cuda.synchronize()
+    launches = len(m.get_profile())
+    m.set_profiling(0)
+    assert cotr_oracle.px_err(out, torch.from_numpy(g['pred_f32'])) < PX_BAR
+    assert launches <= 94, launches                       # the product's launch count at one pair x 1000 queries
+
+
+def test_large_tile_three_stage_configurations():
+    """configurations 28 / 29 (three LDS stages, two tiles of LDS-DMA in flight across a raw s_barrier): bit-identical to 26 / 27."""
+    lib = _lib.load_library()
+    d = G.dev()
+    g = _g(5)
+    for M, N, K in [(4133, 1024, 256), (65536, 512, 128)]:
+        x, w = torch.randn(M, K, generator=g).to(d), (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d)
+        b, r = torch.randn(N, generator=g).to(d), torch.randn(M, N, generator=g).to(d)
+        outs = {}
+        for cfg in (26, 27, 28, 29):
+            y = torch.full((M, N), float('nan'), device=d)
+            assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(r), 1, G.P(y), M, N, K, cfg, G.sptr()) == 0
+            outs[cfg] = y
+        assert torch.equal(outs[28], outs[26]) and torch.equal(outs[29], outs[27])
+
+
+def test_fused_and_unfused_decoder_head_agree():
+    """decoder.norm + corr_embed as ONE row-local launch (experimental/head.hip, knob head_fusion_max_rows = 2048; off by default because
+    it measured slower at 1000 rows) against the shipped tail (decoder.norm inside the last ln_reduce, two GEMMs, head2_kernel):
+    two different launch sequences, same function.  The knob is read back, and the conftest fixture resets it afterwards."""
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(2, 100, seed=19)
+    m = hip_model()
+    assert m.knobs()['head_fusion_max_rows'] == (0, 0)         # the default: not fused
+    plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    m.set_knob('head_fusion_max_rows', 2048)
+    assert m.knobs()['head_fusion_max_rows'][0] == 2048
+    fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    m.reset_knobs()
+    again = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    assert not torch.equal(fused, plain)                       # really two different launch sequences
+    assert torch.equal(again, plain)                           # the reset put the shipped path back, bit for bit
+    assert cotr_oracle.px_err(fused, plain) < SHAPE_NOISE_PX
+    ref = cotr_oracle.cotr_forward(sd, img, qs)
+    assert cotr_oracle.px_err(fused, ref) < PX_BAR and cotr_oracle.px_err(plain, ref) < PX_BAR
+
+
+@pytest.mark.parametrize('b,q', [(1, 1000), (2, 77), (1, 1), (3, 333)])
+def test_cooperative_tail_is_bit_identical_to_the_ln_reduce_launches(b, q):
+    """coop_tail.h: the fused attention / FFN launches sum their per-head / per-chunk partial outputs, add bias + residual and
+    apply LayerNorm themselves (each workgroup of a row tile its own share of the rows; the tile's last arriver every share
+    nobody claimed) instead of 24 ln_reduce launches.  Same arithmetic in the same order: the prediction must equal the two-launch
+    form BIT FOR BIT - with the normal bounded wait, and with no waiting at all (coop_tail_spin = 0: every tile is finished by its
+    last-arriving workgroup alone, the path a non-resident or timed-out member takes) - for row counts that are and are not
+    multiples of the 32-row tile, and on repeated calls (the arrival / claim words are generation-tagged, never reset)."""
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(b, q, seed=23)
+    img, qs = img.cuda(), qs.cuda()
+    m = hip_model()
+    assert m.knobs()['coop_tail'] == (0, 0)                    # off by default: measured slower than the launches it removes
+    plain = m(img, qs)['pred_corrs'].clone()
+    m.set_knob('coop_tail', 1)
+    coop = [m(img, qs)['pred_corrs'].clone() for _ in range(3)]
+    m.set_knob('coop_tail_spin', 0)
+    nowait = [m(img, qs)['pred_corrs'].clone() for _ in range(2)]
+    m.reset_knobs()
+    assert all(torch.equal(c, plain) for c in coop), 'cooperative tail differs from the ln_reduce launches'
+    assert all(torch.equal(c, plain) for c in nowait), 'last-arriver-only tail differs from the ln_reduce launches'
+    ref = cotr_oracle.cotr_forward(sd, img.cpu(), qs.cpu())
+    assert cotr_oracle.px_err(plain.cpu(), ref) < PX_BAR
+
+
+def test_cooperative_tail_with_several_forwards_in_flight():
+    """Three handles on three streams, forwards interleaving on the GPU: member workgroups of a row tile may then be late or not
+    resident while others wait - the protocol never waits without bound and the last arriver finishes what is left, so every
+    stream's result equals the single-stream result bit for bit (also with a spin limit so short that members give up)."""
+    from cotr_amd import _lib
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(1, 1000, seed=29)
+    img, qs = img.cuda(), qs.cuda()
+    models = []
+    for _ in range(3):
+        m = build_model(cotr_amd.default_args()).cuda().eval()
+        m.load_state_dict(sd)
+        models.append(m)
+    want = models[0](img, qs)['pred_corrs'].clone()
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in models]
+    for m in models:
+        m.set_knob('coop_tail', 1)
+    for spin in (4000, 3):
+        for m in models:
+            m.set_knob('coop_tail_spin', spin)
+        outs = []
+        for it in range(12):
+            for m, st in zip(models, streams):
+                with torch.cuda.stream(st):
+                    outs.append(m(img, qs)['pred_corrs'])
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, want) for o in outs), spin
+
+
+
+
+def test_norm_folded_into_the_ffn_block_is_bit_identical():
+    """knob ffn_preln: the LayerNorm after the attention sub-layer applied inside the fused FFN block (to the X tile in LDS
+    and to the residual row in ln_reduce) instead of in its own launch - same arithmetic, same bits, 12 launches fewer."""
+    img, qs = synth_inputs(1, 1000, seed=31)
+    m = hip_model()
+    try:
+        outs = []
+        m.set_knob('attention_fusion_max_rows', 0)                 # the experiment belongs to the six-launch layer
+        for on in (0, 1):
+            m.set_knob('ffn_preln', on)
+            outs.append(m(img.cuda(), qs.cuda())['pred_corrs'].clone())
+            m.set_profiling(2)
+            m(img.cuda(), qs.cuda())
+            torch.cuda.synchronize()
+            outs.append(len(m.get_profile()))
+            m.set_profiling(0)
+    finally:
+        m.reset_knobs()
+    assert torch.equal(outs[0], outs[2])
+    assert outs[1] - outs[3] == 12, (outs[1], outs[3])
+
+
+
+
+@pytest.mark.parametrize('name', ['ragged_b2_q257', 'engine_b4_q1'])
+def test_projection_plus_layernorm_in_one_launch(name, golden_dir):
+    """gemm_ln.hip (the attention out-projection / linear2 with the LayerNorm behind them as ONE launch, taken from 24576 rows up)
+    forced onto small golden cases (knob gemm_ln_min_rows = 0, with the many-row forms of everything else so that the unfused
+    GEMM + layernorm sequence is the one it replaces): the same MFMA sequence per output element and layernorm_kernel's arithmetic
+    per row; the golden's bar."""
+    from cotr_amd import _lib
+    wseed, gain = make_golden.CASES[name][:2]
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    sd, img, qs = make_golden.case_inputs(name)
+    m = hip_model(wseed, gain)
+    outs = []
+    for min_rows in (1 << 30, 0):
+        m.set_knob('attention_fusion_max_rows', 0)         # the unfused (many-row) layer sequence
+        m.set_knob('ffn_fusion_max_rows', 0)
+        m.set_knob('gemm_ln_min_rows', min_rows)
+        outs.append(m(img.cuda(), qs.cuda())['pred_corrs'].cpu())
+    m.reset_knobs()
+    # (at these row counts the unfused GEMMs run on split-K / wave-private configurations with another k order: agreement to rounding;
+    # the bit-identity against the large-tile GEMM + layernorm_kernel at the shapes where the fusion is used is tests/test_ops_gpu.py's)
+    ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), torch.from_numpy(g['pred_f64']))
+    assert cotr_oracle.px_err(outs[1], outs[0]) < max(SHAPE_NOISE_PX, 3 * ref_gap)
+    assert cotr_oracle.px_err(outs[1], torch.from_numpy(g['pred_f64'])) < max(PX_BAR, 3 * ref_gap)
+
+
+@pytest.mark.parametrize('nb,nq,q_total', [(1, 1000, 1000), (3, 7, 11), (1, 1, 1), (2, 16, 16)])
+def test_decoder_head_in_one_launch(nb, nq, q_total):
+    """dec_head_kernel = decoder.norm + corr_embed (transformer.py:110-111, position_encoding.py:23-26) on 16-row tiles
+    with v_mfma_f32_16x16x4_f32, predictions scattered to out[b][q] of a larger [nb, q_total, 2] tensor; vs fp64 torch."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(nb * 31 + nq)
+    R = nb * nq
+    x = torch.randn(R, 256, generator=g) * 2 + 0.3
+    nw, nbias = torch.rand(256, generator=g) + 0.5, 0.1 * torch.randn(256, generator=g)
+    w0, b0 = torch.randn(256, 256, generator=g) / 16, 0.1 * torch.randn(256, generator=g)
+    w1, b1 = torch.randn(256, 256, generator=g) / 16, 0.1 * torch.randn(256, generator=g)
+    w2, b2 = torch.randn(2, 256, generator=g) / 16, torch.randn(2, generator=g)
+    hs_ref = F.layer_norm(x.double(), (256,), nw.double(), nbias.double())
+    h = F.relu(F.linear(F.relu(F.linear(hs_ref, w0.double(), b0.double())), w1.double(), b1.double()))
+    ref = F.linear(h, w2.double(), b2.double()).view(nb, nq, 2)
+    d = G.dev()
+    t = [v.to(d) for v in (x, nw, nbias, w0, b0, w1, b1, w2, b2)]
+    hs = torch.full((R, 256), float('nan'), device=d)
+    out = torch.full((nb, q_total, 2), float('nan'), device=d)
+    assert lib.cotr_op_dec_head(*[G.P(v) for v in t], G.P(hs), G.P(out), nb, nq, q_total, G.sptr()) == 0
+    assert G.rel_err(hs, hs_ref) < 1e-5
+    assert G.rel_err(out[:, :nq], ref) < 3e-5
+    assert torch.isnan(out[:, nq:]).all()                      # rows of other query chunks are not touched
+    out2 = torch.full((nb, q_total, 2), float('nan'), device=d)
+    assert lib.cotr_op_dec_head(*[G.P(v) for v in t], None, G.P(out2), nb, nq, q_total, G.sptr()) == 0
+    assert torch.equal(out2[:, :nq], out[:, :nq])              # the hs tap is optional
+    if R > 2:                                                  # a NaN row stays in its row
+        xn = t[0].clone()
+        xn[1] = float('nan')
+        assert lib.cotr_op_dec_head(G.P(xn), *[G.P(v) for v in t[1:]], None, G.P(out2), nb, nq, q_total, G.sptr()) == 0
+        flat, flat0 = out2[:, :nq].reshape(R, 2), out[:, :nq].reshape(R, 2)
+        keep = torch.arange(R, device=d) != 1
+        assert torch.isnan(flat[1]).all() and torch.equal(flat[keep], flat0[keep])
+
+
+
+
+def test_ffn_tail_equals_separate_reduce_launch():
+    """The in-kernel tail of the fused FFN (last-arriving workgroup of a row tile sums the partial outputs in chunk order,
+    adds bias + residual, LayerNorm) gives the SAME BITS as the separate ln_reduce launch, launch after launch with
+    changing inputs (stale partials of the previous launch in another XCD's L2 would show up here)."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    d = G.dev()
+    g = _g(77)
+    for M in (512, 1000, 33):
+        w1, b1 = (torch.randn(1024, 256, generator=g) / 16).to(d), (torch.randn(1024, generator=g) * 0.1).to(d)
+        w2, b2 = (torch.randn(256, 1024, generator=g) / 32).to(d), (torch.randn(256, generator=g) * 0.1).to(d)
+        lw, lb = (torch.rand(256, generator=g) + 0.5).to(d), (torch.randn(256, generator=g) * 0.1).to(d)
+        scratch = torch.empty(lib.cotr_op_ffn_chunks(M) * M * 256, device=d)
+        xs = [torch.randn(M, 256, generator=g).to(d) for _ in range(12)]
+        outs = {}
+        try:
+            for tail in (0, 1):
+                _lib.set_knob('ffn_tail', tail)
+                ys = []
+                for x in xs:                                   # back to back on the stream, same scratch and counters
+                    y = torch.empty(M, 256, device=d)
+                    assert lib.cotr_op_ffn_block(G.P(x), G.P(w1), G.P(b1), G.P(w2), G.P(b2), G.P(lw), G.P(lb), G.P(scratch),
+                                                 G.P(y), M, G.sptr()) == 0
+                    ys.append(y)
+                torch.cuda.synchronize()
+                outs[tail] = ys
+        finally:
+            _lib.set_knob('ffn_tail', 0)
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b), M
+
+
+
+
+@pytest.mark.parametrize('M,K,res', [(1000, 256, True), (32768, 256, True), (4099, 1024, True), (130, 256, False), (128, 32, True)])
+def test_linear_plus_layernorm_kernel(M, K, res):
+    """gemm_ln_kernel: y = LayerNorm(x . w^T + bias + residual) with a workgroup owning 128 complete rows, against the large-tile GEMM
+    (config 26: the same k order) followed by layernorm_kernel - bit-identical - and against torch in fp64."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(M + K)
+    d = G.dev()
+    x = torch.randn(M, K, generator=g).to(d)
+    w = (torch.randn(256, K, generator=g) / K ** 0.5).to(d)
+    b = torch.randn(256, generator=g).to(d)
+    r = torch.randn(M, 256, generator=g).to(d) if res else None
+    lw, lb = (torch.rand(256, generator=g) + 0.5).to(d), torch.randn(256, generator=g).to(d)
+    y = torch.full((M + 1, 256), 7.0, device=d)
+    assert lib.cotr_op_linear_ln(G.P(x), G.P(w), G.P(b), G.P(r) if res else None, G.P(lw), G.P(lb), G.P(y), M, K, G.sptr()) == 0
+    assert bool((y[M] == 7.0).all())                     # nothing behind the last row
+    tmp, y2 = torch.empty(M, 256, device=d), torch.empty(M, 256, device=d)
+    assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(r) if res else None, 0, G.P(tmp), M, 256, K, 26, G.sptr()) == 0
+    assert lib.cotr_op_layernorm(G.P(tmp), G.P(lw), G.P(lb), G.P(y2), M, G.sptr()) == 0
+    assert torch.equal(y[:M], y2), float((y[:M] - y2).abs().max())
+    pre = x.double().cpu() @ w.double().cpu().t() + b.double().cpu() + (r.double().cpu() if res else 0)
+    ref = F.layer_norm(pre, (256,), lw.double().cpu(), lb.double().cpu(), 1e-5)
+    assert G.rel_err(y[:M], ref) < 2e-5

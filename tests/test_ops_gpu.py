@@ -145,11 +145,9 @@ def test_attention_softmax_extremes(case):
     o = torch.full((nb * nq, 256), float('nan'), device=d)
     lib = _lib.load_library()
     for ns in (0, 1, 2, 8):                            # automatic (4 key splits) and explicit split counts
-        assert lib.cotr_set_attention_splits(ns) == 0
-        try:
-            rc = lib.cotr_op_attention(G.P(q.to(d)), 256, G.P(kv), G.P(kv[:, 256:]), 512, G.P(o), 256, nb, nq, G.sptr())
-        finally:
-            lib.cotr_set_attention_splits(0)
+        _lib.set_knob('attention_splits', ns)            # (process-wide set: cotr_op_* have no handle; the conftest fixture resets it)
+        rc = lib.cotr_op_attention(G.P(q.to(d)), 256, G.P(kv), G.P(kv[:, 256:]), 512, G.P(o), 256, nb, nq, G.sptr())
+        _lib.set_knob('attention_splits', 0)
         assert rc == 0
         assert torch.isfinite(o).all(), (case, ns)
         # one-hot rows amplify the fp32 rounding of the logits (|logit| * 2^-24 absolute) into the weights
@@ -176,19 +174,14 @@ def test_attention_wide_kernel_is_bit_identical(nb, nq, occ):
     d = G.dev()
     qd, kvd = q.to(d), kv.to(d)
     outs = []
-    try:
-        for min_rows in (1 << 30, 0):
-            assert lib.cotr_set_attention_wide_min_rows(min_rows) == 0
-            assert lib.cotr_set_attention_wide_occupancy(occ) == 0
-            assert lib.cotr_set_attention_resident(0) == 0
-            o = torch.full((nb * nq + 1, 256), float('nan'), device=d)      # one guard row behind the output
-            assert lib.cotr_op_attention(G.P(qd), 256, G.P(kvd), G.P(kvd[:, 256:]), 512, G.P(o), 256, nb, nq, G.sptr()) == 0
-            assert torch.isnan(o[-1]).all()
-            outs.append(o[:-1])
-    finally:
-        lib.cotr_set_attention_wide_min_rows(4096)
-        lib.cotr_set_attention_wide_occupancy(3)
-        lib.cotr_set_attention_resident(1)
+    for min_rows in (1 << 30, 0):
+        _lib.set_knob('attention_wide_min_rows', min_rows)
+        _lib.set_knob('attention_wide_occupancy', occ)
+        _lib.set_knob('attention_resident', 0)
+        o = torch.full((nb * nq + 1, 256), float('nan'), device=d)      # one guard row behind the output
+        assert lib.cotr_op_attention(G.P(qd), 256, G.P(kvd), G.P(kvd[:, 256:]), 512, G.P(o), 256, nb, nq, G.sptr()) == 0
+        assert torch.isnan(o[-1]).all()
+        outs.append(o[:-1])
     assert torch.equal(outs[0], outs[1])
     assert G.rel_err(outs[1], ref) < 2e-5
 
@@ -225,10 +218,9 @@ def test_attention_resident_kernel_is_bit_identical(nb, nq):
 @pytest.fixture
 def fused_splits(request):
     from cotr_amd import _lib
-    lib = _lib.load_library()
-    assert lib.cotr_set_attention_fused_splits(request.param) == 0
+    _lib.set_knob('attention_fused_splits', request.param)
     yield request.param
-    lib.cotr_set_attention_fused_splits(0)
+    _lib.set_knob('attention_fused_splits', 0)
 
 
 @pytest.mark.parametrize('fused_splits', [4, 8], indirect=True)
@@ -303,42 +295,6 @@ def test_attention_with_fused_projections(nb, nq, fused_splits):
         assert torch.equal(o1[keep], o[keep]) and not torch.isnan(part[:, keep]).any()
 
 
-@pytest.mark.parametrize('nb,nq,q_total', [(1, 1000, 1000), (3, 7, 11), (1, 1, 1), (2, 16, 16)])
-def test_decoder_head_in_one_launch(nb, nq, q_total):
-    """dec_head_kernel = decoder.norm + corr_embed (transformer.py:110-111, position_encoding.py:23-26) on 16-row tiles
-    with v_mfma_f32_16x16x4_f32, predictions scattered to out[b][q] of a larger [nb, q_total, 2] tensor; vs fp64 torch."""
-    from cotr_amd import _lib
-    lib = _lib.load_library()
-    g = _g(nb * 31 + nq)
-    R = nb * nq
-    x = torch.randn(R, 256, generator=g) * 2 + 0.3
-    nw, nbias = torch.rand(256, generator=g) + 0.5, 0.1 * torch.randn(256, generator=g)
-    w0, b0 = torch.randn(256, 256, generator=g) / 16, 0.1 * torch.randn(256, generator=g)
-    w1, b1 = torch.randn(256, 256, generator=g) / 16, 0.1 * torch.randn(256, generator=g)
-    w2, b2 = torch.randn(2, 256, generator=g) / 16, torch.randn(2, generator=g)
-    hs_ref = F.layer_norm(x.double(), (256,), nw.double(), nbias.double())
-    h = F.relu(F.linear(F.relu(F.linear(hs_ref, w0.double(), b0.double())), w1.double(), b1.double()))
-    ref = F.linear(h, w2.double(), b2.double()).view(nb, nq, 2)
-    d = G.dev()
-    t = [v.to(d) for v in (x, nw, nbias, w0, b0, w1, b1, w2, b2)]
-    hs = torch.full((R, 256), float('nan'), device=d)
-    out = torch.full((nb, q_total, 2), float('nan'), device=d)
-    assert lib.cotr_op_dec_head(*[G.P(v) for v in t], G.P(hs), G.P(out), nb, nq, q_total, G.sptr()) == 0
-    assert G.rel_err(hs, hs_ref) < 1e-5
-    assert G.rel_err(out[:, :nq], ref) < 3e-5
-    assert torch.isnan(out[:, nq:]).all()                      # rows of other query chunks are not touched
-    out2 = torch.full((nb, q_total, 2), float('nan'), device=d)
-    assert lib.cotr_op_dec_head(*[G.P(v) for v in t], None, G.P(out2), nb, nq, q_total, G.sptr()) == 0
-    assert torch.equal(out2[:, :nq], out[:, :nq])              # the hs tap is optional
-    if R > 2:                                                  # a NaN row stays in its row
-        xn = t[0].clone()
-        xn[1] = float('nan')
-        assert lib.cotr_op_dec_head(G.P(xn), *[G.P(v) for v in t[1:]], None, G.P(out2), nb, nq, q_total, G.sptr()) == 0
-        flat, flat0 = out2[:, :nq].reshape(R, 2), out[:, :nq].reshape(R, 2)
-        keep = torch.arange(R, device=d) != 1
-        assert torch.isnan(flat[1]).all() and torch.equal(flat[keep], flat0[keep])
-
-
 @pytest.mark.parametrize('rows', [1001, 8192 + 13])
 def test_layernorm(rows):
     """(the row after the last one must stay untouched)"""
@@ -388,38 +344,6 @@ def test_fused_ffn_block(M):
     assert lib.cotr_op_ffn_block(*[G.P(v) for v in t], G.P(scratch), G.P(y), M, G.sptr()) == 0
     e = G.rel_err(y, ref)
     assert e < 2e-5, e
-
-
-def test_ffn_tail_equals_separate_reduce_launch():
-    """The in-kernel tail of the fused FFN (last-arriving workgroup of a row tile sums the partial outputs in chunk order,
-    adds bias + residual, LayerNorm) gives the SAME BITS as the separate ln_reduce launch, launch after launch with
-    changing inputs (stale partials of the previous launch in another XCD's L2 would show up here)."""
-    from cotr_amd import _lib
-    lib = _lib.load_library()
-    d = G.dev()
-    g = _g(77)
-    for M in (512, 1000, 33):
-        w1, b1 = (torch.randn(1024, 256, generator=g) / 16).to(d), (torch.randn(1024, generator=g) * 0.1).to(d)
-        w2, b2 = (torch.randn(256, 1024, generator=g) / 32).to(d), (torch.randn(256, generator=g) * 0.1).to(d)
-        lw, lb = (torch.rand(256, generator=g) + 0.5).to(d), (torch.randn(256, generator=g) * 0.1).to(d)
-        scratch = torch.empty(lib.cotr_op_ffn_chunks(M) * M * 256, device=d)
-        xs = [torch.randn(M, 256, generator=g).to(d) for _ in range(12)]
-        outs = {}
-        try:
-            for tail in (0, 1):
-                assert lib.cotr_set_ffn_tail(tail) == 0
-                ys = []
-                for x in xs:                                   # back to back on the stream, same scratch and counters
-                    y = torch.empty(M, 256, device=d)
-                    assert lib.cotr_op_ffn_block(G.P(x), G.P(w1), G.P(b1), G.P(w2), G.P(b2), G.P(lw), G.P(lb), G.P(scratch),
-                                                 G.P(y), M, G.sptr()) == 0
-                    ys.append(y)
-                torch.cuda.synchronize()
-                outs[tail] = ys
-        finally:
-            lib.cotr_set_ffn_tail(0)
-        for a, b in zip(outs[0], outs[1]):
-            assert torch.equal(a, b), M
 
 
 # ---- every launch configuration of the GEMM / implicit-GEMM kernels on the same problem -----------------------------
@@ -621,28 +545,3 @@ def test_large_tile_configs_are_repeatable():
         for ws, base in ((40, 26), (41, 27)):
             if ws in first and base in first:
                 assert torch.equal(first[ws], first[base]), (ws, base, M, N, K)
-
-
-@pytest.mark.parametrize('M,K,res', [(1000, 256, True), (32768, 256, True), (4099, 1024, True), (130, 256, False), (128, 32, True)])
-def test_linear_plus_layernorm_kernel(M, K, res):
-    """gemm_ln_kernel: y = LayerNorm(x . w^T + bias + residual) with a workgroup owning 128 complete rows, against the large-tile GEMM
-    (config 26: the same k order) followed by layernorm_kernel - bit-identical - and against torch in fp64."""
-    from cotr_amd import _lib
-    lib = _lib.load_library()
-    g = _g(M + K)
-    d = G.dev()
-    x = torch.randn(M, K, generator=g).to(d)
-    w = (torch.randn(256, K, generator=g) / K ** 0.5).to(d)
-    b = torch.randn(256, generator=g).to(d)
-    r = torch.randn(M, 256, generator=g).to(d) if res else None
-    lw, lb = (torch.rand(256, generator=g) + 0.5).to(d), torch.randn(256, generator=g).to(d)
-    y = torch.full((M + 1, 256), 7.0, device=d)
-    assert lib.cotr_op_linear_ln(G.P(x), G.P(w), G.P(b), G.P(r) if res else None, G.P(lw), G.P(lb), G.P(y), M, K, G.sptr()) == 0
-    assert bool((y[M] == 7.0).all())                     # nothing behind the last row
-    tmp, y2 = torch.empty(M, 256, device=d), torch.empty(M, 256, device=d)
-    assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(r) if res else None, 0, G.P(tmp), M, 256, K, 26, G.sptr()) == 0
-    assert lib.cotr_op_layernorm(G.P(tmp), G.P(lw), G.P(lb), G.P(y2), M, G.sptr()) == 0
-    assert torch.equal(y[:M], y2), float((y[:M] - y2).abs().max())
-    pre = x.double().cpu() @ w.double().cpu().t() + b.double().cpu() + (r.double().cpu() if res else 0)
-    ref = F.layer_norm(pre, (256,), lw.double().cpu(), lb.double().cpu(), 1e-5)
-    assert G.rel_err(y[:M], ref) < 2e-5

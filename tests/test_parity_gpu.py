@@ -63,21 +63,13 @@ def test_pos_tables_and_wide_attention_on_the_golden_cases(name, golden_dir):
     """The many-rows forms - pos . W^T taken from the tables of cotr_load_weights as a row-periodic residual of the in-projection
     GEMMs (instead of adding pos to the activations, transformer.py:147-153,192-195) and the 64-query attention kernel - forced onto
     the small golden cases of the reference: same bars as the default path."""
-    from cotr_amd import _lib
-    lib = _lib.load_library()
     wseed, gain = make_golden.CASES[name][:2]
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     sd, img, qs = make_golden.case_inputs(name)
     m = hip_model(wseed, gain)
     base = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    try:
-        assert lib.cotr_set_pos_table_min_rows(0) == 0 and lib.cotr_set_attention_wide_min_rows(0) == 0
-        assert lib.cotr_set_attention_fusion_max_rows(0) == 0
+    with G.model_knobs(m, pos_table_min_rows=0, attention_wide_min_rows=0, attention_fusion_max_rows=0):
         out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    finally:
-        lib.cotr_set_pos_table_min_rows(8192)
-        lib.cotr_set_attention_wide_min_rows(4096)
-        lib.cotr_set_attention_fusion_max_rows(1024)
     ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), torch.from_numpy(g['pred_f64']))
     bar = max(PX_BAR, 3 * ref_gap)
     assert cotr_oracle.px_err(out, torch.from_numpy(g['pred_f64'])) < bar
@@ -115,13 +107,14 @@ def test_engine_batch_shape_b32_q1():
 
 
 def test_encode_chunking_b40():
-    """More pairs than one backbone pass (cotr_set_encode_chunk: 64 by default, 32 here so that 40 pairs take two passes):
+    """More pairs than one backbone pass (knob encode_chunk: 64 by default, 32 here so that 40 pairs take two passes):
     results must not depend on the chunking."""
-    from cotr_amd import _lib
     sd = synth_state_dict(0)
     img, qs = synth_inputs(40, 3, seed=10)
-    _lib.set_knob('encode_chunk', 32)              # (before the model sizes its workspace; the conftest fixture resets it)
-    m = hip_model()
+    m = build_model(cotr_amd.default_args()).cuda().eval()        # a model of its own: the knob is per handle
+    m.load_state_dict(sd)
+    m.set_knob('encode_chunk', 32)
+    assert m.knobs()['encode_chunk'] == (32, 64) and hip_model().knobs()['encode_chunk'] == (64, 64)
     out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
     tail = m(img[33:35].cuda(), qs[33:35].cuda())['pred_corrs'].cpu()
     # pairs never interact; only the fp32 summation order differs (the GEMM launch configuration, hence the
@@ -197,134 +190,43 @@ def test_state_dict_round_trip_and_reload():
 
 
 def test_fused_and_unfused_ffn_paths_agree():
-    """The fused FFN block (default up to 3072 rows) and the three-launch path compute the same function."""
-    from cotr_amd import _lib
+    """The fused FFN block (default up to 1024 rows) and the three-launch path compute the same function."""
     sd = synth_state_dict(0)
     img, qs = synth_inputs(2, 300, seed=15)
     m = hip_model()
     fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    lib = _lib.load_library()
-    try:
-        assert lib.cotr_set_ffn_fusion_max_rows(0) == 0
+    with G.model_knobs(m, ffn_fusion_max_rows=0):
         plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    finally:
-        lib.cotr_set_ffn_fusion_max_rows(1024)
+    assert not torch.equal(fused, plain)                       # really two different launch sequences
     assert cotr_oracle.px_err(fused, plain) < SHAPE_NOISE_PX
     assert cotr_oracle.px_err(plain, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
 
 
 def test_fused_and_unfused_attention_paths_agree():
     """Default up to 1024 rows: attention with the out projection (and, in the decoder, the q projection) inside the
-    kernel + ln_reduce; cotr_set_attention_fusion_max_rows(0) = the six-launch layer.  Same function, different fp32
+    kernel + ln_reduce; knob attention_fusion_max_rows = 0 is the six-launch layer.  Same function, different fp32
     summation order; both within the bar of the oracle."""
-    from cotr_amd import _lib
     sd = synth_state_dict(0)
     img, qs = synth_inputs(2, 300, seed=17)
     m = hip_model()
     fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    lib = _lib.load_library()
-    try:
-        assert lib.cotr_set_attention_fusion_max_rows(0) == 0
+    with G.model_knobs(m, attention_fusion_max_rows=0):
         plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    finally:
-        lib.cotr_set_attention_fusion_max_rows(1024)
     assert not torch.equal(fused, plain)                       # really two different launch sequences
     assert cotr_oracle.px_err(fused, plain) < SHAPE_NOISE_PX
     ref = cotr_oracle.cotr_forward(sd, img, qs)
     assert cotr_oracle.px_err(plain, ref) < PX_BAR and cotr_oracle.px_err(fused, ref) < PX_BAR
 
 
-def test_fused_and_unfused_decoder_head_agree():
-    """decoder.norm + corr_embed as ONE row-local launch (head.hip, cotr_set_head_fusion_max_rows(2048); off by default because
-    it measured slower at 1000 rows) against the shipped tail (decoder.norm inside the last ln_reduce, two GEMMs, head2_kernel):
-    two different launch sequences, same function.  The knob is read back, and the conftest fixture resets it afterwards."""
-    from cotr_amd import _lib
-    sd = synth_state_dict(0)
-    img, qs = synth_inputs(2, 100, seed=19)
-    m = hip_model()
-    assert _lib.knobs()['head_fusion_max_rows'] == (0, 0)      # the shipped default: not fused
-    plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    _lib.set_knob('head_fusion_max_rows', 2048)
-    assert _lib.knobs()['head_fusion_max_rows'][0] == 2048
-    fused = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    _lib.reset_knobs()
-    again = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    assert not torch.equal(fused, plain)                       # really two different launch sequences
-    assert torch.equal(again, plain)                           # the reset put the shipped path back, bit for bit
-    assert cotr_oracle.px_err(fused, plain) < SHAPE_NOISE_PX
-    ref = cotr_oracle.cotr_forward(sd, img, qs)
-    assert cotr_oracle.px_err(fused, ref) < PX_BAR and cotr_oracle.px_err(plain, ref) < PX_BAR
-
-
-@pytest.mark.parametrize('b,q', [(1, 1000), (2, 77), (1, 1), (3, 333)])
-def test_cooperative_tail_is_bit_identical_to_the_ln_reduce_launches(b, q):
-    """coop_tail.h: the fused attention / FFN launches sum their per-head / per-chunk partial outputs, add bias + residual and
-    apply LayerNorm themselves (each workgroup of a row tile its own share of the rows; the tile's last arriver every share
-    nobody claimed) instead of 24 ln_reduce launches.  Same arithmetic in the same order: the prediction must equal the two-launch
-    form BIT FOR BIT - with the normal bounded wait, and with no waiting at all (coop_tail_spin = 0: every tile is finished by its
-    last-arriving workgroup alone, the path a non-resident or timed-out member takes) - for row counts that are and are not
-    multiples of the 32-row tile, and on repeated calls (the arrival / claim words are generation-tagged, never reset)."""
-    from cotr_amd import _lib
-    sd = synth_state_dict(0)
-    img, qs = synth_inputs(b, q, seed=23)
-    img, qs = img.cuda(), qs.cuda()
-    m = hip_model()
-    assert _lib.knobs()['coop_tail'] == (0, 0)                 # off by default: measured slower than the launches it removes
-    plain = m(img, qs)['pred_corrs'].clone()
-    _lib.set_knob('coop_tail', 1)
-    coop = [m(img, qs)['pred_corrs'].clone() for _ in range(3)]
-    _lib.set_knob('coop_tail_spin', 0)
-    nowait = [m(img, qs)['pred_corrs'].clone() for _ in range(2)]
-    _lib.reset_knobs()
-    assert all(torch.equal(c, plain) for c in coop), 'cooperative tail differs from the ln_reduce launches'
-    assert all(torch.equal(c, plain) for c in nowait), 'last-arriver-only tail differs from the ln_reduce launches'
-    ref = cotr_oracle.cotr_forward(sd, img.cpu(), qs.cpu())
-    assert cotr_oracle.px_err(plain.cpu(), ref) < PX_BAR
-
-
-def test_cooperative_tail_with_several_forwards_in_flight():
-    """Three handles on three streams, forwards interleaving on the GPU: member workgroups of a row tile may then be late or not
-    resident while others wait - the protocol never waits without bound and the last arriver finishes what is left, so every
-    stream's result equals the single-stream result bit for bit (also with a spin limit so short that members give up)."""
-    from cotr_amd import _lib
-    sd = synth_state_dict(0)
-    img, qs = synth_inputs(1, 1000, seed=29)
-    img, qs = img.cuda(), qs.cuda()
-    models = []
-    for _ in range(3):
-        m = build_model(cotr_amd.default_args()).cuda().eval()
-        m.load_state_dict(sd)
-        models.append(m)
-    want = models[0](img, qs)['pred_corrs'].clone()
-    torch.cuda.synchronize()
-    streams = [torch.cuda.Stream() for _ in models]
-    _lib.set_knob('coop_tail', 1)
-    for spin in (4000, 3):
-        _lib.set_knob('coop_tail_spin', spin)
-        outs = []
-        for it in range(12):
-            for m, st in zip(models, streams):
-                with torch.cuda.stream(st):
-                    outs.append(m(img, qs)['pred_corrs'])
-        torch.cuda.synchronize()
-        assert all(torch.equal(o, want) for o in outs), spin
-    _lib.reset_knobs()
-
-
 def test_dual_conv_launch_is_bit_identical_to_two_launches():
     """The entry blocks' downsample + conv1 in one launch compute exactly what the two launches compute when the
     configuration is the same; end to end the two schedules agree to launch-configuration rounding."""
-    from cotr_amd import _lib
     sd = synth_state_dict(0)
     img, qs = synth_inputs(1, 64, seed=18)
     m = hip_model()
     dual = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    lib = _lib.load_library()
-    try:
-        assert lib.cotr_set_dual_conv(0) == 0
+    with G.model_knobs(m, dual_conv=0):
         plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    finally:
-        lib.cotr_set_dual_conv(1)
     assert cotr_oracle.px_err(dual, plain) < SHAPE_NOISE_PX
     assert cotr_oracle.px_err(dual, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
 
@@ -437,31 +339,6 @@ def test_config3_256_pairs_x_1000_queries():
     assert cotr_oracle.px_err(out[100:101, :64].cpu(), ref) < PX_BAR
 
 
-def test_norm_folded_into_the_ffn_block_is_bit_identical():
-    """cotr_set_ffn_preln: the LayerNorm after the attention sub-layer applied inside the fused FFN block (to the X tile in LDS
-    and to the residual row in ln_reduce) instead of in its own launch - same arithmetic, same bits, 12 launches fewer."""
-    from cotr_amd import _lib
-    lib = _lib.load_library()
-    img, qs = synth_inputs(1, 1000, seed=31)
-    m = hip_model()
-    try:
-        outs = []
-        assert lib.cotr_set_attention_fusion_max_rows(0) == 0      # the experiment belongs to the six-launch layer
-        for on in (0, 1):
-            assert lib.cotr_set_ffn_preln(on) == 0
-            outs.append(m(img.cuda(), qs.cuda())['pred_corrs'].clone())
-            m.set_profiling(2)
-            m(img.cuda(), qs.cuda())
-            torch.cuda.synchronize()
-            outs.append(len(m.get_profile()))
-            m.set_profiling(0)
-    finally:
-        lib.cotr_set_ffn_preln(0)
-        lib.cotr_set_attention_fusion_max_rows(1024)
-    assert torch.equal(outs[0], outs[2])
-    assert outs[1] - outs[3] == 12, (outs[1], outs[3])
-
-
 def test_backbone_entry_points_match_the_stage_taps():
     """cotr_backbone / cotr_backbone_upto (the frozen part of the backbone in the training step) return exactly the layer1 /
     layer2 / layer3 activations the full encode produces (debug taps), in NHWC over the side-by-side pair."""
@@ -492,26 +369,30 @@ def test_backbone_entry_points_match_the_stage_taps():
     assert lib.cotr_backbone_upto(m._handle, img_d.data_ptr(), 3, 4, out.data_ptr(), _lib.current_stream_ptr()) != 0
 
 
-@pytest.mark.parametrize('name', ['ragged_b2_q257', 'engine_b4_q1'])
-def test_projection_plus_layernorm_in_one_launch(name, golden_dir):
-    """gemm_ln.hip (the attention out-projection / linear2 with the LayerNorm behind them as ONE launch, taken from 24576 rows up)
-    forced onto small golden cases (cotr_set_gemm_ln_min_rows(0), with the many-row forms of everything else so that the unfused
-    GEMM + layernorm sequence is the one it replaces): the same MFMA sequence per output element and layernorm_kernel's arithmetic
-    per row; the golden's bar."""
+def test_knobs_are_per_handle():
+    """Two models = two library handles: a knob set on one (cotr_set_knob(h, ...)) changes that handle's launch schedule only -
+    the other keeps the shipped path bit for bit, also when their calls alternate; a knob the library does not have is refused."""
     from cotr_amd import _lib
-    wseed, gain = make_golden.CASES[name][:2]
-    g = np.load(os.path.join(golden_dir, name + '.npz'))
-    sd, img, qs = make_golden.case_inputs(name)
-    m = hip_model(wseed, gain)
-    outs = []
-    for min_rows in (1 << 30, 0):
-        _lib.set_knob('attention_fusion_max_rows', 0)      # the unfused (many-row) layer sequence
-        _lib.set_knob('ffn_fusion_max_rows', 0)
-        _lib.set_knob('gemm_ln_min_rows', min_rows)
-        outs.append(m(img.cuda(), qs.cuda())['pred_corrs'].cpu())
-    _lib.reset_knobs()
-    # (at these row counts the unfused GEMMs run on split-K / wave-private configurations with another k order: agreement to rounding;
-    # the bit-identity against the large-tile GEMM + layernorm_kernel at the shapes where the fusion is used is tests/test_ops_gpu.py's)
-    ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), torch.from_numpy(g['pred_f64']))
-    assert cotr_oracle.px_err(outs[1], outs[0]) < max(SHAPE_NOISE_PX, 3 * ref_gap)
-    assert cotr_oracle.px_err(outs[1], torch.from_numpy(g['pred_f64'])) < max(PX_BAR, 3 * ref_gap)
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(1, 300, seed=33)
+    img, qs = img.cuda(), qs.cuda()
+    a, b = (build_model(cotr_amd.default_args()).cuda().eval() for _ in range(2))
+    a.load_state_dict(sd)
+    b.load_state_dict(sd)
+    base = a(img, qs)['pred_corrs'].clone()
+    assert torch.equal(b(img, qs)['pred_corrs'], base)
+    b.set_knob('attention_fusion_max_rows', 0)
+    b.set_knob('ffn_fusion_max_rows', 0)
+    outs = [(a(img, qs)['pred_corrs'].clone(), b(img, qs)['pred_corrs'].clone()) for _ in range(3)]
+    assert all(torch.equal(x, base) for x, _ in outs)
+    assert all(not torch.equal(y, base) and torch.equal(y, outs[0][1]) for _, y in outs)
+    assert cotr_oracle.px_err(outs[0][1].cpu(), base.cpu()) < SHAPE_NOISE_PX
+    assert a.knobs()['ffn_fusion_max_rows'] == (1024, 1024) and b.knobs()['ffn_fusion_max_rows'] == (0, 1024)
+    assert _lib.knobs()['ffn_fusion_max_rows'] == (1024, 1024)           # the process-wide set is a third, untouched one
+    b.reset_knobs()
+    assert torch.equal(b(img, qs)['pred_corrs'], base)
+    with pytest.raises(_lib.CotrHipError):
+        b.set_knob('no_such_knob', 1)
+    if not _lib.experimental_selected():
+        with pytest.raises(_lib.CotrHipError):
+            b.set_knob('coop_tail', 1)                                   # the measured dead ends are not in the product library

@@ -109,7 +109,7 @@ def test_packed_in_projection_slices():
                                           (12, 64, False), (7, 40, False)])
 def test_attention_forward_backward(nb, nq, packed, form):
     """attn_train_fwd / attn_bwd_dq / attn_bwd_dkv (recompute-softmax backward) vs softmax attention under torch autograd; both
-    forms of the kernels (cotr_set_train_attention_form; 0 = the shipped choice: the one-pass backward from 24 pairs x 256 queries up, the
+    forms of the kernels (knob train_attention_form; 0 = the shipped choice: the one-pass backward from 24 pairs x 256 queries up, the
     two-kernel second form below)."""
     from cotr_amd import _lib
     _lib.set_knob('train_attention_form', form)
@@ -162,6 +162,36 @@ def test_attention_backward_forms_agree_with_dropout(nb, nq, packed):
     for other in res[1:]:
         for a, b in zip(res[0], other):                          # output, then the gradients
             assert _rel(b, a) < 2e-5
+
+
+def test_kv_block_used_by_two_attention_calls_sums_the_gradients():
+    """ColBlocks hands every K / V column block an in-place gradient destination; it is claimed by the FIRST Attention that uses
+    the block.  A second consumer of the same block (decode_train called twice with one kv list) must ADD its dk / dv, not
+    overwrite the first one's: the gradient of the wide projection equals the one computed with separate, copied blocks."""
+    nb, nq = 2, 40
+    g = _g(77)
+    scale = 32 ** -0.5
+    wide = torch.randn(nb * 512, 1024, generator=g)                  # two layers' K | V columns
+    q1, q2 = torch.randn(nb * nq, 256, generator=g), torch.randn(nb * nq, 256, generator=g)
+    d1, d2 = torch.randn(nb * nq, 256, generator=g).cuda(), torch.randn(nb * nq, 256, generator=g).cuda()
+
+    def run(shared):
+        x = _leaf(wide)
+        qa, qb = _leaf(q1), _leaf(q2)
+        if shared:
+            blocks = T.col_blocks(x, 1, 4)[0]                        # K0 V0 K1 V1 as views with gradient destinations
+            k0, v0 = blocks[0], blocks[1]
+            o1 = T.Attention.apply(None, qa, k0, v0, nb, nq, scale, 0.0)
+            o2 = T.Attention.apply(None, qb, k0, v0, nb, nq, scale, 0.0)      # the SAME block objects a second time
+        else:
+            o1 = T.Attention.apply(None, qa, x[:, 0:256].contiguous(), x[:, 256:512].contiguous(), nb, nq, scale, 0.0)
+            o2 = T.Attention.apply(None, qb, x[:, 0:256].contiguous(), x[:, 256:512].contiguous(), nb, nq, scale, 0.0)
+        loss = (o1 * d1).sum() + (o2 * d2).sum()
+        return torch.autograd.grad(loss, [x, qa, qb])
+    gs, gp = run(True), run(False)
+    assert float(gp[0][:, :512].abs().max()) > 0 and float(gs[0][:, 512:].abs().max()) == 0     # unused blocks: zero
+    for a, b in zip(gs, gp):
+        assert _rel(a, b) < 1e-5
 
 
 def test_attention_dropout_statistics_and_determinism():

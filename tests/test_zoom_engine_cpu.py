@@ -267,3 +267,37 @@ def test_default_cropper_fails_loudly_without_gpu_or_with_wrong_images():
         eng.refine(img_a.astype(np.float32), img_b, [[10.0, 10.0]], [[12.0, 12.0]], 1.0, 1.0, [0.5], 1)
     with pytest.raises(ValueError):
         eng.refine(img_a[..., 0], img_b, [[10.0, 10.0]], [[12.0, 12.0]], 1.0, 1.0, [0.5], 1)
+
+
+@pytest.mark.parametrize('kind', ['unit', 'outside', 'near_identity', 'special'])
+def test_c_cycle_restatement_equals_torch_cpu(kind):
+    """oracle/dense_cycle_ref.c (the plain-C statement of torch-CPU's grid_sample + norm association, which
+    cotr_amd/csrc/dense_post.hip reproduces on the device) against the reference's own three lines run through torch CPU
+    (oracle/dense_post.cycle_maps <- inference_helper.py:137-139): the cycle-error map bit for bit, NaNs in the same places."""
+    from oracle.build_c import dense_cycle_ref
+    from oracle.dense_post import cycle_maps
+    rng = np.random.default_rng(17)
+    if kind == 'unit':
+        g = rng.random((256, 512, 2), dtype=np.float32)
+    elif kind == 'outside':                                   # far outside [0,1]: zero padding, the -1 border cell
+        g = (rng.random((256, 512, 2), dtype=np.float32) * 1.4 - 0.2).astype(np.float32)
+    elif kind == 'near_identity':                             # what a trained model answers: the query grid + noise
+        jj, ii = np.meshgrid(np.arange(512), np.arange(256))
+        g = (np.stack([jj / 512, ii / 256], -1) + rng.normal(0, 0.01, (256, 512, 2))).astype(np.float32)
+    else:
+        g = rng.random((256, 512, 2), dtype=np.float32)
+        flat = g.reshape(-1, 2)
+        special = [np.nan, np.inf, -np.inf, 1e30, -1e30, 3e9, -3e9, 0.0, 1.0, -1 / 512, 513 / 512, 0.5 / 512, 1 - 0.5 / 512,
+                   1 + 0.5 / 512, -0.5 / 512, -1.5 / 512, 2.0 ** 31 / 512, 5.0, -3.0]
+        k = 0
+        for a in special:
+            for b in [0.3, np.nan, np.inf, -1e30, 1 + 0.5 / 256, -0.5 / 256]:
+                flat[k] = (a, b)
+                flat[k + 7] = (b, a)
+                k += 14
+    _, err = dense_cycle_ref(g[None])
+    left, right = cycle_maps(g)
+    want = np.concatenate([left, right], axis=1)[..., 2]
+    assert np.array_equal(err[0], want, equal_nan=True)
+    if kind == 'special':
+        assert np.isnan(want).sum() > 50

@@ -86,30 +86,32 @@ DENSE_CASES = ['engine_dense_default', 'engine_dense_default_c3', 'engine_dense_
 
 
 @pytest.mark.parametrize('name', DENSE_CASES)
-def test_default_path_device_crops_equal_host_crops(name, golden_dir):
-    """Whole default path with the HIP crop kernel == the same engine with Pillow crops on the host, bit for bit, and
-    == the reference engine's golden output.  The post-processing is the host restatement here (it contains torch's CPU
-    grid_sample, so the golden comparison allows for a different CPU's rounding: the maps to 1e-5, the final list
-    exactly only if the maps were exact); the device post-processing has its own tests below."""
+def test_default_path_on_the_device_equals_the_reference_engine(name, golden_dir):
+    """The DEFAULT ZoomEngine - crops cut by the HIP kernel AND the dense pass post-processed on the device (cotr_dense_cycle
+    reproduces torch-CPU's grid_sample + norm bit for bit, cotr_dense_merge Pillow's mode-'F' resize) - against the golden
+    output of the reference's own engine (cotr_flow maps by digest, then the task list drawn from them: correspondences and
+    identifiers bit for bit), and against the same engine with Pillow crops + the host post-processing recipe."""
     from tests.engine_fixtures import CyclicFakeModel, digest
     from tests.test_zoom_engine_cpu import run_dense_case, FLOW_KEYS
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     img_a, img_b = synthetic_pair(int(g['meta'][0]))
-    dev = ZoomEngine(CyclicFakeModel().cuda(), max_pairs=64, make_dense_post=dense_post.host_dense_post_factory)
+    dev = ZoomEngine(CyclicFakeModel().cuda(), max_pairs=64)
+    assert dev.make_dense_post.__name__ == '_DeviceDensePost' and dev.make_cropper.__name__ == '_DeviceCropper'
     host = ZoomEngine(CyclicFakeModel(), max_pairs=64, make_cropper=pil_cropper_factory,
                       make_dense_post=dense_post.host_dense_post_factory)
     flow_d, flow_h = dev.flow(img_a, img_b), host.flow(img_a, img_b)
-    exact = True
     for k, d, h in zip(FLOW_KEYS, flow_d, flow_h):
-        tol = 1e-2 if 'resample' in k else 0            # the warp runs through torch on the GPU in one, on the CPU in the other
-        assert np.abs(d - h).max() <= tol, k
-        assert np.allclose(d[::9, ::9], g['flow_' + k], rtol=0, atol=1e-5 if 'resample' not in k else 1e-2), k
-        exact &= 'resample' in k or digest(d) == g['sha_' + k].tobytes()
+        if 'resample' in k:                              # the warp runs through torch on the GPU in one, on the CPU in the other
+            assert np.abs(d - h).max() <= 1e-2, k
+            assert np.allclose(d[::9, ::9], g['flow_' + k], rtol=0, atol=1e-2), k
+            continue
+        assert np.array_equal(d, h), k
+        assert np.array_equal(d[::9, ::9], g['flow_' + k]), k
+        assert digest(d) == g['sha_' + k].tobytes(), k
     out_d, out_h = run_dense_case(g, dev), run_dense_case(g, host)
     for d, h in zip(out_d, out_h):
         assert np.array_equal(d, h)
-    if exact:
-        assert np.array_equal(out_d[0], g['corrs']) and np.array_equal(ids(out_d[1]), g['idx'])
+    assert np.array_equal(out_d[0], g['corrs']) and np.array_equal(ids(out_d[1]), g['idx'])
 
 
 def _dense_inputs(seed, rough):
@@ -135,8 +137,8 @@ def _dense_inputs(seed, rough):
 
 @pytest.mark.parametrize('rough', [False, True])
 def test_dense_cycle_kernel_vs_host_recipe(rough):
-    """cotr_dense_cycle vs torch-CPU grid_sample + numpy (oracle/dense_post.py <- inference_helper.py:137-158).
-    fp32 formulas evaluated in a different order: 1e-6 on the normalised coordinates and on the cycle error."""
+    """cotr_dense_cycle vs torch-CPU grid_sample + norm + numpy (oracle/dense_post.py <- inference_helper.py:137-158):
+    bit for bit (the kernel follows the association and the FMA contractions of torch's CPU kernels)."""
     from cotr_amd.inference.zoom_engine import _DeviceDensePost, _patch_affines
     from cotr_amd import _lib
     img_a, img_b, pairs, pred = _dense_inputs(11, rough)
@@ -154,8 +156,36 @@ def test_dense_cycle_kernel_vs_host_recipe(rough):
         c_j[..., :2] = c_j[..., :2] @ t_j[:2, :2] + t_j[:, 2]
         want = np.concatenate([c_i, c_j], axis=1)
         assert np.array_equal(got[k][..., :2], want[..., :2])             # re-centring + affine: exact
-        err = np.abs(got[k][..., 2] - want[..., 2])
-        assert err.max() < 2e-6 * max(1.0, np.abs(want[..., 2]).max()), err.max()
+        assert np.array_equal(got[k][..., 2], want[..., 2], equal_nan=True)   # cycle error: torch-CPU's bits
+
+
+def test_dense_cycle_kernel_special_coordinates():
+    """NaN / inf / beyond-int-range / far-outside / exactly-on-the-border answers: the same bits (and the same NaNs) as
+    torch-CPU's grid_sample + norm (a NaN or inf coordinate poisons the sample: the weights are multiplied into the zero the
+    out-of-map neighbours contribute; a merely huge one samples zeros)."""
+    from cotr_amd import _lib
+    rng = np.random.default_rng(3)
+    g = rng.random((2, 256, 512, 2), dtype=np.float32)
+    special = [np.nan, np.inf, -np.inf, 1e30, -1e30, 3e9, -3e9, 0.0, 1.0, -1 / 512, 513 / 512, 0.5 / 512, 1 - 0.5 / 512,
+               1 + 0.5 / 512, -0.5 / 512, -1.5 / 512, 2.0 ** 31 / 512, 5.0, -3.0]
+    k = 0
+    flat = g.reshape(-1, 2)
+    for a in special:
+        for b in [0.3, np.nan, np.inf, -1e30, 1 + 0.5 / 256, -0.5 / 256]:
+            flat[k] = (a, b)
+            flat[k + 7] = (b, a)
+            k += 14
+    lib = _lib.load_library()
+    aff = torch.tensor([[[1.0, 0, 0, 0, 1, 0]] * 2] * 2, dtype=torch.float64).cuda()
+    maps = torch.empty((2, 256, 512, 3), device='cuda')
+    _lib.check(lib.cotr_dense_cycle(torch.from_numpy(g).cuda().data_ptr(), 2, aff.data_ptr(), maps.data_ptr(),
+                                    _lib.current_stream_ptr()), None, 'cotr_dense_cycle')
+    got = maps.cpu().numpy()[..., 2]
+    for p in range(2):
+        l, r = dense_post.cycle_maps(g[p])
+        want = np.concatenate([l, r], axis=1)[..., 2]
+        assert np.isnan(want).sum() > (50 if p == 0 else -1)          # the special values sit in the first pair
+        assert np.array_equal(got[p], want, equal_nan=True)
 
 
 @pytest.mark.parametrize('shapes', [((300, 420), (350, 330)), ((256, 256), (200, 390)), ((783, 1064), (1053, 689))])
@@ -191,20 +221,20 @@ def test_dense_merge_kernel_is_pillow_exact(shapes):
 
 
 def test_device_dense_post_end_to_end():
-    """Default ZoomEngine (device crops + device post-processing) vs the host recipe on the same prediction: cycle
-    error map to 2e-6; flow identical except where two overlapping patches tie to within that noise."""
+    """Default ZoomEngine (device crops + device post-processing) vs the host recipe on the same prediction: all four maps
+    bit for bit, hence the same confident-pixel mask, the same random draw and the same correspondences."""
     from tests.engine_fixtures import CyclicFakeModel
     img_a, img_b = synthetic_pair(12)
     dev = ZoomEngine(CyclicFakeModel().cuda())
     host = ZoomEngine(CyclicFakeModel().cuda(), make_dense_post=dense_post.host_dense_post_factory)
     d, h = dev.flow(img_a, img_b), host.flow(img_a, img_b)
-    for k in (1, 4):
-        assert np.abs(d[k] - h[k]).max() < 2e-6
-    for k in (0, 3):
-        bad = np.abs(d[k] - h[k]).max(axis=-1) > 2e-6
-        assert bad.mean() < 5e-3          # overlapping patches whose errors tie to within the noise swap winners
+    for k in (0, 1, 3, 4):
+        assert np.array_equal(d[k], h[k]), k
     np.random.seed(0)
     corrs = dev.cotr_corr_multiscale_with_cycle_consistency(img_a, img_b, ZOOMS, 1, max_corrs=20)
+    np.random.seed(0)
+    corrs_h = host.cotr_corr_multiscale_with_cycle_consistency(img_a, img_b, ZOOMS, 1, max_corrs=20)
+    assert np.array_equal(corrs, corrs_h)
     assert corrs.shape == (20, 4) and np.isfinite(corrs).all()
     assert (corrs[:, 0] < img_a.shape[1]).all() and (corrs[:, 2] < img_b.shape[1]).all() and (corrs > 0).all()
 
@@ -277,13 +307,14 @@ def test_stretching_mode_on_device():
 def test_faster_sparse_engine_with_device_crops_matches_the_reference_class(name, golden_dir):
     """The goldens of the reference's own FasterSparseEngine (pilots, squads, np.random.permutation order, zero-padded grouped
     model calls, the fallback loop) reproduced with every crop pair cut by the HIP kernel (Pillow-exact, so the fake model sees
-    the reference's pixels): correspondences, identifiers, crop bookkeeping and the model-call shapes, bit for bit.  The dense
-    initial pass keeps the host post-processing recipe here (the device one differs from torch-CPU's grid_sample in the last
-    bits, which can flip a borderline 'confident' pixel and with it the random draw - it has its own map-wise tests above)."""
+    the reference's pixels) AND the dense initial pass post-processed on the device (bit-exact cycle-error maps, so the
+    'confident' mask and the np.random.choice draw behind it are the reference's): correspondences, identifiers, crop
+    bookkeeping and the model-call shapes, bit for bit."""
     from tests.test_zoom_engine_cpu import FASTER_CASES, run_faster_case
     g = np.load(os.path.join(golden_dir, name + '.npz'))
-    (corrs, idx), eng, model = run_faster_case(name, g, False, on_device=True, make_dense_post=dense_post.host_dense_post_factory)
+    (corrs, idx), eng, model = run_faster_case(name, g, False, on_device=True)
     assert next(model.parameters()).is_cuda and eng.make_cropper.__name__ == '_DeviceCropper'
+    assert eng.make_dense_post.__name__ == '_DeviceDensePost'
     assert np.array_equal(np.asarray(corrs, dtype=np.float64).reshape(-1, 4), g['corrs'])
     assert np.array_equal(ids(idx), g['idx'])
     assert eng.total_tasks - 4 == int(g['total_tasks'])

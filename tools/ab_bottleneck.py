@@ -1,4 +1,4 @@
-"""A/B of the fused layer1 bottleneck (cotr_set_bottleneck_max_pairs) across batch sizes: ms per forward with it off / on.  GPU box."""
+"""A/B of the fused layer1 bottleneck (knob bottleneck_max_pairs) across batch sizes: ms per forward with it off / on.  GPU box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,7 +23,7 @@ def t(b, q, n):
         best = min(best, e0.elapsed_time(e1) / n)
     return best
 for b, q, n in [(1, 1000, 100), (2, 1000, 50), (4, 1000, 30), (8, 1000, 20), (16, 1, 10), (32, 1, 10), (32, 1000, 5)]:
-    _lib.set_knob('bottleneck_max_pairs', 0); off = t(b, q, n)
-    _lib.set_knob('bottleneck_max_pairs', 64); on = t(b, q, n)
+    model.set_knob('bottleneck_max_pairs', 0); off = t(b, q, n)
+    model.set_knob('bottleneck_max_pairs', 64); on = t(b, q, n)
     print(f'B={b:3d} Q={q:5d}: unfused {off:8.3f} ms  fused {on:8.3f} ms  ({100 * (on - off) / off:+.1f} %)', flush=True)
-_lib.reset_knobs()
+model.reset_knobs()

@@ -19,10 +19,10 @@ sptr = _lib.current_stream_ptr()
 
 def setv(name):
     if name == 'narrow':
-        lib.cotr_set_attention_wide_min_rows(1 << 30)
+        _lib.set_knob('attention_wide_min_rows', 1 << 30)
     else:
-        lib.cotr_set_attention_wide_min_rows(0)
-        assert lib.cotr_set_attention_wide_occupancy(int(name[4:])) == 0
+        _lib.set_knob('attention_wide_min_rows', 0)
+        _lib.set_knob('attention_wide_occupancy', int(name[4:]))
 
 
 shapes = [(32, 1000), (32, 512), (4, 8192), (1, 32768), (3, 77)]
@@ -54,5 +54,4 @@ for nb, nq in shapes:
                                                                   '  DIFFERS max %.3e' % (outs[vn] - outs['narrow']).abs().max().item())
         print('nb %3d nq %6d  %-8s %9.2f us  %6.1f TFLOP/s  (%.3f of 157.3)%s' % (nb, nq, vn, us, fl / us * 1e-6, fl / us * 1e-6 / 157.3, same),
               flush=True)
-lib.cotr_set_attention_wide_min_rows(4096)
-lib.cotr_set_attention_wide_occupancy(3)
+_lib.reset_knobs()

@@ -23,7 +23,7 @@ for tag, nb, nq in (('encoder, 32 pairs', 32, 512), ('decoder chunk, dense pass'
     ref = None
     row = []
     for ns in (1, 2, 4, 8, 16):
-        assert lib.cotr_set_attention_splits(ns) == 0
+        _lib.set_knob('attention_splits', ns)
         sp = _lib.current_stream_ptr()
         call = lambda: lib.cotr_op_attention(P(q), 256, P(k), P(v), 256, P(o), 256, nb, nq, sp)
         assert call() == 0
@@ -31,7 +31,7 @@ for tag, nb, nq in (('encoder, 32 pairs', 32, 512), ('decoder chunk, dense pass'
         if ref is None: ref = o.clone()
         err = float((o - ref).abs().max())
         row.append((ns, timeit(call), err))
-    lib.cotr_set_attention_splits(0)
+    _lib.set_knob('attention_splits', 0)
     flop = nb * nq * 512 * 32 * 2 * 2 * 8
     print(f'{tag:28s} nb={nb:3d} nq={nq:6d}: ' + '  '.join(f'ns{ns}: {t:7.1f}us' for ns, t, _ in row) +
           f'   best {flop / min(t for _, t, _ in row) / 1e6:6.1f} TFLOP/s  max|diff vs ns1| {max(e for _, _, e in row):.1e}', flush=True)

@@ -16,7 +16,7 @@ def main():
     shapes = [(1, 1000), (1, 4000), (2, 257), (4, 1000), (32, 1000)]
     shapes = [(1, 1000), (1, 2500), (2, 257), (4, 500), (6, 400), (8, 1000), (32, 1)]
     for ns in [0, 3072]:
-        lib.cotr_set_ffn_fusion_max_rows(ns)
+        m.set_knob('ffn_fusion_max_rows', ns)
         for (b, q) in shapes:
             img, qs = synth_inputs(b, q, seed=1)
             img, qs = img.cuda(), qs.cuda()

@@ -15,7 +15,7 @@ for name, B, H, W, cin, cout, k, st in [('l3 conv2 3x3 16384x256x2304', 32, 16, 
     sc, bi = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
     y = torch.empty(B, H // st, 2 * (W // st), cout, device=dev)
     for cfg, flags in ((26, 0), (27, 0), (40, 0), (40, 2), (41, 0), (41, 2)):
-        lib.cotr_set_ws_flags(flags)
+        _lib.set_knob('ws_flags', flags)
         if lib.cotr_op_conv_cfg(P(x), P(w), P(sc), P(bi), None, 1, P(y), B, H, W, cin, cout, k, st, cfg, sp) != 0:
             print(name, cfg, 'declined'); continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
