@@ -97,6 +97,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"coop_tail", 0, 0, 1},
     {"coop_tail_spin", 4000, 0, INT_MAX},
     {"gemm_ln_min_rows", 1 << 30, 0, INT_MAX},
+    {"l2_warm", 0, 0, 3},
 #endif
 };
 bool knob_value_ok(int id, int v) {
@@ -835,6 +836,9 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
         KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
                                        nullptr, 0, e.out_w, t_part, Bc, TOK, s), "attention+out_proj");
         prof_mark(h, "attention+oproj enc", s, 2);
+#ifdef COTR_EXPERIMENTAL
+        if (knob(KN_L2_WARM) & 1) set_ln_reduce_warm(e.l1w, (size_t)FFN * D * 4, e.l2w, (size_t)FFN * D * 4);   // the FFN block is next
+#endif
         KCHK(h, launch_ln_reduce(t_part, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
         prof_mark(h, "ln_reduce heads", s, 2);
       } else {
@@ -955,9 +959,16 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       KCHK(h, launch_attention_fused(nullptr, 0, tgt_in, d.qpos, w.q_w, w.q_b, QSCALE, kl, kl + D, KVLD, nullptr, 0, w.out_w, d.part,
                                      nb, nq, s), "q_proj+attention+out_proj");
       prof_mark(h, "qproj+attention+oproj dec", s, 2);
+#ifdef COTR_EXPERIMENTAL
+      if (knob(KN_L2_WARM) & 1) set_ln_reduce_warm(w.l1w, (size_t)FFN * D * 4, w.l2w, (size_t)FFN * D * 4);     // the FFN block is next
+#endif
       KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, tgt_in, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
       prof_mark(h, "ln_reduce heads", s, 2);
       const bool post = li + 1 == L;
+#ifdef COTR_EXPERIMENTAL
+      if ((knob(KN_L2_WARM) & 2) && !post)   // ... and the FFN block's own ln_reduce warms the next layer's attention weights
+        set_ln_reduce_warm(h->dec[li + 1].q_w, (size_t)D * D * 4, h->dec[li + 1].out_w, (size_t)D * D * 4);
+#endif
       if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
                          post ? h->dn_w : nullptr, post ? h->dn_b : nullptr))) return r;
       hs_normed = post;

@@ -75,6 +75,7 @@ enum KnobId {
   KN_COOP_TAIL,                  // row tiles finished by their own workgroups (coop_tail.h; measured slower; 0)
   KN_COOP_TAIL_SPIN,             // polls before a member leaves its share to the last arriver
   KN_GEMM_LN_MIN_ROWS,           // 256-wide projection + LayerNorm as one launch from this many rows (measured neutral; off)
+  KN_L2_WARM,                    // ln_reduce launches also touch the next launch's weights (weights-ahead L2 warmer; bit 0 FFN weights, bit 1 attention weights; measured slower)
 #endif
   KN_COUNT
 };

@@ -31,6 +31,8 @@ int launch_gemm_ln(const float* x, int lda, const float* w, const float* bias, c
 int launch_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
                     const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
                     hipStream_t s);
+// pointwise.hip: the next ln_reduce launch also pulls two regions (the next launch's weights) through every XCD's L2 (knob l2_warm)
+void set_ln_reduce_warm(const float* p0, size_t bytes0, const float* p1, size_t bytes1);
 // gemm_pp.hip: persistent ping-pong large tiles (1 = 128 x 64 staged write-out, 3 = 128 x 64 LDS-free write-out)
 int launch_gemm_pp(int mode, int variant, const GemmParams& p, hipStream_t s);
 int gemm_pp_workgroups();   // persistent workgroups per launch on the current device

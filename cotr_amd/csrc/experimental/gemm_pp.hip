@@ -162,21 +162,12 @@ __global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // the K steps of the other group's tile - not in one burst: with every CU in the same phase a burst is 16 MB of stores chip-wide
   // in two K steps (measured: the first version, which wrote a 32-row block per step, had a LARGER fixed cost per tile than the
   // one-tile-per-workgroup kernel).  The residual row of item i+1 is requested while item i is processed (4 registers).
-  constexpr int NITEMS = 2 * NIT;
-  f32x4 res = {0.f, 0.f, 0.f, 0.f}, sc, bi, cs;
+  // (2 * NIT items per tile: RPI rows x 32 TN columns each)
+  f32x4 sc, bi, cs;
   int pend_m0 = 0, pend_n0 = 0;           // the tile this group still has to write out
   bool pending = false;
   int item_acc = 0, item_next = 0;        // the write-out schedule of the pending tile
 
-  auto residual_of = [&](int item, int m0, int n0) -> f32x4 {   // rows of epilogue item `item` (block item / NIT, rows (item % NIT) * RPI + er)
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (p.residual && item < NITEMS) {
-      const int m = m0 + wm * 64 + (item / NIT) * 32 + (item % NIT) * RPI + er;
-      const int mr = m < p.M ? (p.res_row_mod > 0 ? fastmod(m, p.fd_resrow) : m) : 0;
-      r = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mr * p.ldr + n0 + wn * 32 * TN + ec);
-    }
-    return r;
-  };
   // Items are processed in PIECES of PIECE consecutive items of one 32-row block with compile-time structure: all staging reads of
   // the piece are issued together and waited for once, then the arithmetic, then the stores.  (Item by item - read, wait, compute,
   // store - the write-out is a chain of LDS round trips that a low-priority wavefront beside an MFMA wavefront gets through at

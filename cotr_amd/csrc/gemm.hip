@@ -747,6 +747,8 @@ static const GemmCfg kCfgs[] = {
 #ifdef COTR_EXPERIMENTAL   // (experimental/gemm_pp.hip: measured slower than 26 / 27, libcotr_hip_exp.so only)
     {9, 0, 2, 1},   // 42 persistent ping-pong 128x64
     {9, 0, 2, 1},   // 43 persistent ping-pong 128x64, LDS-free write-out
+    {5, 0, 2, 2},   // 44 large tile 128x128 (26) with the LDS-free epilogue: dword stores straight from the accumulators
+    {5, 0, 2, 1},   // 45 large tile 128x64 (27) with the LDS-free epilogue
 #endif
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -866,6 +868,8 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
 #ifdef COTR_EXPERIMENTAL
     case 42: return launch_gemm_pp(MODE, 1, p, s);
     case 43: return launch_gemm_pp(MODE, 3, p, s);
+    case 44: return launch_gemm_big(MODE, 6, p, s);
+    case 45: return launch_gemm_big(MODE, 7, p, s);
 #endif
     case 40: return launch_gemm_big(MODE, 4, p, s);
     case 41: return launch_gemm_big(MODE, 5, p, s);

@@ -24,7 +24,10 @@
 // NST = LDS stages: 2 = every barrier drains the LDS-DMA queue (vmcnt(0)); 3 = ring with TWO tiles in flight: the wait before
 // the barrier of step t is a counted vmcnt that covers tile t only, tile t+1 stays in flight across the barrier (raw s_barrier,
 // no fence: __syncthreads() would drain the queue) and tile t+2 is requested right after it.
-template <int TN, int MODE, int NST>
+// DIRECT (experiment, configurations 44 / 45): the epilogue stores straight from the accumulators - a wave store = rows r and r + 4 of a
+// 32-column block = two full 128-B lines - instead of staging 32 rows at a time through LDS for float4 row stores: no LDS round trip, no
+// barrier between the K loop and the epilogue, 4x the store instructions.  Same arithmetic per element: bit-identical.
+template <int TN, int MODE, int NST, bool DIRECT = false>
 __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage
@@ -119,7 +122,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
   const int er = lane / C4, ec = (lane % C4) * 4;
   const int ncol = n0 + wn * 32 * TN + ec;
   f32x4 res[2][NIT];
-  if (p.residual) {
+  if (!DIRECT && p.residual) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -171,6 +174,34 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are retired before the next barrier
       st = st == 2 ? 0 : st + 1;
     }
+  }
+  if constexpr (DIRECT) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * 32 * TN + b * 32 + l31;
+        const float scv = p.scale ? p.scale[col] : 1.f, biv = p.bias ? p.bias[col] : 0.f;
+        const float csv = col < p.colscale_n ? p.colscale : 1.f;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          rv[r] = 0.f;
+          if (p.residual && m < p.M) rv[r] = p.residual[(size_t)(p.res_row_mod > 0 ? fastmod(m, p.fd_resrow) : m) * p.ldr + col];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          float x = acc[a][b][r];
+          x = p.scale ? fmaf(x, scv, biv) : x + biv;
+          x *= csv;
+          if (p.residual) x += rv[r];
+          if (p.relu) x = (x < 0.f) ? 0.f : x;
+          if (m < p.M) p.C[(size_t)m * p.ldc + col] = x;
+        }
+      }
+    return;
   }
   __syncthreads();                                      // every wavefront is done reading the operand stages
 
@@ -451,9 +482,9 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int TN, int MODE, int NST>
+template <int TN, int MODE, int NST, bool DIRECT = false>
 __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
-  gemm_big_body<TN, MODE, NST>(p, blockIdx.x);
+  gemm_big_body<TN, MODE, NST, DIRECT>(p, blockIdx.x);
 }
 
 // two independent problems in one grid (common.h: launch_gemm_dual_cfg)
@@ -493,7 +524,7 @@ int launch_gemm_big_dual(int mode, int variant, const GemmParams& p0, const Gemm
   return variant == 0 ? launch_big_dual_t<2>(p0, p1, s) : variant == 1 ? launch_big_dual_t<1>(p0, p1, s) : -1;
 }
 
-template <int TN, int MODE, int NST>
+template <int TN, int MODE, int NST, bool DIRECT = false>
 static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr size_t smem = (size_t)NST * (BM + BN) * BK * sizeof(float);
@@ -506,14 +537,14 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   if (p.zeros == nullptr) return -2;
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST, DIRECT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set.set();
   }
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
   const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST>), dim3(tiles), dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST, DIRECT>), dim3(tiles), dim3(256), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -529,6 +560,8 @@ int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s) {
 #ifdef COTR_EXPERIMENTAL   // configurations 28 / 29 (three LDS stages: within +-5 % of the two-stage kernel, never in the tuned table)
     case 2: return d ? launch_big_t<2, GEMM_DENSE, 3>(p, s) : launch_big_t<2, GEMM_CONV, 3>(p, s);
     case 3: return d ? launch_big_t<1, GEMM_DENSE, 3>(p, s) : launch_big_t<1, GEMM_CONV, 3>(p, s);
+    case 6: return d ? launch_big_t<2, GEMM_DENSE, 2, true>(p, s) : launch_big_t<2, GEMM_CONV, 2, true>(p, s);   // direct epilogue
+    case 7: return d ? launch_big_t<1, GEMM_DENSE, 2, true>(p, s) : launch_big_t<1, GEMM_CONV, 2, true>(p, s);
 #endif
     case 4: return d ? launch_ws_t<2, GEMM_DENSE>(p, s) : launch_ws_t<2, GEMM_CONV>(p, s);   // wave-specialised 128 x 128
     case 5: return d ? launch_ws_t<1, GEMM_DENSE>(p, s) : launch_ws_t<1, GEMM_CONV>(p, s);   // wave-specialised 128 x 64

@@ -340,3 +340,22 @@ def test_persistent_large_tile_is_bit_identical(M, N, K):
                 assert lib.cotr_op_conv_cfg(G.P(xs), G.P(ws), G.P(sc), G.P(bi), G.P(rs), 1, G.P(y), B, H, H, cin, cout, k, stride, cfg, G.sptr()) == 0
                 outs.append(y)
             assert torch.equal(outs[0], outs[1]), (base, pp, k, stride)
+
+
+@pytest.mark.parametrize('M,N,K', [(16384, 1024, 256), (4133, 512, 64), (65536, 128, 1024)])
+def test_large_tile_with_lds_free_epilogue_is_bit_identical(M, N, K):
+    """configurations 44 / 45 = 26 / 27 with the epilogue storing straight from the accumulators (no LDS staging): same bits, with
+    bias + residual + ReLU and without, ragged last row tile."""
+    lib = _lib.load_library()
+    d = G.dev()
+    g = _g(M + N + K + 1)
+    x, w = torch.randn(M, K, generator=g).to(d), (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d)
+    b, r = torch.randn(N, generator=g).to(d), torch.randn(M, N, generator=g).to(d)
+    for res, relu in ((r, 1), (None, 0)):
+        for base, direct in ((26, 44), (27, 45)):
+            outs = []
+            for cfg in (base, direct):
+                y = torch.full((M + 1, N), 7.0, device=d)
+                assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(res) if res is not None else None, relu, G.P(y), M, N, K, cfg, G.sptr()) == 0
+                outs.append(y)
+            assert torch.equal(outs[0], outs[1]), (base, direct)

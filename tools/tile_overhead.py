@@ -10,7 +10,7 @@ from cotr_amd import _lib
 lib = _lib.load_library()
 dev = torch.device('cuda:0')
 P = lambda t: t.data_ptr()
-PP = (42, 43) if _lib.experimental_selected() else ()      # experimental/gemm_pp.hip: COTR_HIP_EXPERIMENTAL=1
+PP = (44, 45) if _lib.experimental_selected() else ()      # experimental: 26 / 27 with the LDS-free epilogue (42 / 43: gemm_pp.hip)
 SHAPES = (('16384 x 1024', 16384, 1024, (26, 27, 40) + PP), ('16384 x 256', 16384, 256, (26, 27, 40, 41) + PP), ('32000 x 256', 32000, 256, (26, 27) + PP),
           ('65536 x 512', 65536, 512, (26, 27)), ('262144 x 256', 262144, 256, (26, 27) + PP))
 if len(sys.argv) > 2:
@@ -34,7 +34,7 @@ for tag, M, N, cfgs in SHAPES:
             del x, w, y
         if len(ks) < 3:
             continue
-        bn = 128 if cfg in (26, 40) else 64
+        bn = 128 if cfg in (26, 40, 44) else 64
         tiles = (M // 128) * (N // bn)
         per_cu = tiles / 256.0
         kt = np.array(ks) / 32.0
