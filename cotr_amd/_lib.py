@@ -75,6 +75,7 @@ _PROTOS = {
     'cotr_train_gemm_tn': (ctypes.c_int, [c_float_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_train_gemm_tn_parts': (ctypes.c_int, [c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     'cotr_train_reduce_jobs': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_train_perm_jobs': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_train_adam': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.POINTER(ctypes.c_float), ctypes.c_int,
                                        ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p,
                                        ctypes.c_void_p]),

@@ -1556,6 +1556,11 @@ int cotr_train_adam(const cotr_adam_job* jobs, const unsigned* chunk_job, int nc
   return op_ret(train_adam(reinterpret_cast<const TrainAdamJob*>(jobs), chunk_job, nchunks, g, m, v, lr, ngroups, beta1, beta2, eps,
                            bias_correction1, bias_correction2_sqrt, step, TS));
 }
+static_assert(sizeof(cotr_perm_job) == sizeof(TrainPermJob), "include/cotr_hip.h and train.h disagree on cotr_perm_job");
+int cotr_train_perm_jobs(const cotr_perm_job* jobs, const unsigned* tile_job, int njobs, int ntiles, cotr_stream stream) {
+  if (njobs < 0 || ntiles < 0 || (njobs > 0 && (jobs == nullptr || tile_job == nullptr))) return COTR_ERR_ARG;
+  return op_ret(train_perm_jobs(reinterpret_cast<const TrainPermJob*>(jobs), tile_job, njobs, ntiles, TS));
+}
 int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream) {
   return op_ret(launch_head2(x, w, b, y, nb, nq, nq, TS));
 }

@@ -51,6 +51,18 @@ struct TrainReduceJob {
 };
 int train_reduce_jobs(const TrainReduceJob* jobs, const TrainReduceSrc* srcs, const unsigned* chunk_job, int njobs, int nchunks,
                       hipStream_t s);
+// One launch that re-derives EVERY weight-shaped operand a training step needs from the parameters (after the optimiser step): the W^T
+// slices of the dX GEMMs, the packed [Cout][k][k][Cin] convolution weights, the FrozenBN-scaled transposed convolution weights.  A job is
+// a batched strided transpose with an optional per-source-row factor: dst[z * dz + c * dc + r] = src[z * sz + r * sr + c * sc] * scale[r]
+struct TrainPermJob {
+  const float* src;
+  float* dst;
+  const float* scale;          // [R] or nullptr
+  unsigned Z, R, C;            // batches, rows, columns of the source view
+  unsigned sz, sr, sc, dz, dc; // element strides (the destination's row stride is 1)
+  unsigned tile0, tiles_r, tiles_c, pad;
+};
+int train_perm_jobs(const TrainPermJob* jobs, const unsigned* tile_job, int njobs, int ntiles, hipStream_t s);
 struct TrainAdamJob {
   float* p;                      // the parameter
   unsigned long long off;        // its offset (floats) in the flat gradient / m / v buffers

@@ -770,6 +770,42 @@ int train_reduce_jobs(const TrainReduceJob* jobs, const TrainReduceSrc* srcs, co
   return LAUNCH_OK();
 }
 
+__global__ __launch_bounds__(256) void perm_jobs_kernel(const TrainPermJob* __restrict__ jobs, const unsigned* __restrict__ tile_job) {
+  __shared__ float tile[32][33];
+  const TrainPermJob j = jobs[tile_job[blockIdx.x]];
+  unsigned t = blockIdx.x - j.tile0;
+  const unsigned per_z = j.tiles_r * j.tiles_c;
+  const unsigned z = t / per_z;
+  t -= z * per_z;
+  const unsigned tr = t / j.tiles_c, tc = t - tr * j.tiles_c;
+  const unsigned r0 = tr * 32, c0 = tc * 32;
+  const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = j.src + (size_t)z * j.sz;
+  float* dst = j.dst + (size_t)z * j.dz;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned r = r0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (r < j.R && c < j.C) {
+      v = src[(size_t)r * j.sr + (size_t)c * j.sc];
+      if (j.scale != nullptr) v = __fmul_rn(v, j.scale[r]);      // (one rounding, as scale_rows makes)
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < j.C && r < j.R) dst[(size_t)c * j.dc + r] = tile[tx][ty + 8 * i];
+  }
+}
+
+int train_perm_jobs(const TrainPermJob* jobs, const unsigned* tile_job, int njobs, int ntiles, hipStream_t s) {
+  if (njobs <= 0 || ntiles <= 0) return 0;
+  hipLaunchKernelGGL(perm_jobs_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, jobs, tile_job);
+  return LAUNCH_OK();
+}
+
 int train_adam(const TrainAdamJob* jobs, const unsigned* chunk_job, int nchunks, const float* g, float* m, float* v, const float* lr,
                int ngroups, double b1, double b2, double eps, double bc1, double bc2_sqrt, const float* step_ptr, hipStream_t s) {
   if (nchunks <= 0) return 0;

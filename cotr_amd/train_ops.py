@@ -386,38 +386,168 @@ def colsum(x, out):
     return out
 
 
-_wt_cache = {}   # id(base tensor) -> (weakref to it, {(storage offset, shape): (version, W^T)})
+# ---- weight-shaped operands DERIVED from the parameters ---------------------------------------------------------------------
+# A training step needs, besides the parameters themselves, ~130 re-laid-out copies of them: the W^T slices of the dX GEMMs (the
+# GEMM kernels take their weight operand as [N][K]), the convolution weights packed [Cout][k][k][Cin] (forward, implicit GEMM) and
+# their FrozenBN-scaled transposes [k*k*Cin][Cout] (dgrad).  They change exactly when the optimiser steps.  This registry keeps each
+# in a PERSISTENT buffer, knows how it is derived (a batched strided transpose with an optional row factor: cotr_perm_job) and
+# re-derives ALL of them in one launch after the optimiser step (refresh_derived) - instead of ~130 transposes / row scalings of a
+# few microseconds each spread over the next backward pass (0.6 ms of a 22 ms stage-2 step).  A miss (first use, a new slice, a
+# parameter that moved) is served by the same kernel with a one-job table.
+_PERM_DT = None
+
+
+def _perm_dtype():
+    global _PERM_DT
+    if _PERM_DT is None:
+        import numpy as np
+        _PERM_DT = np.dtype([('src', '<u8'), ('dst', '<u8'), ('scale', '<u8'), ('Z', '<u4'), ('R', '<u4'), ('C', '<u4'), ('sz', '<u4'),
+                             ('sr', '<u4'), ('sc', '<u4'), ('dz', '<u4'), ('dc', '<u4'), ('tile0', '<u4'), ('tiles_r', '<u4'),
+                             ('tiles_c', '<u4'), ('pad', '<u4')])
+        assert _PERM_DT.itemsize == 72
+    return _PERM_DT
+
+
+class _Derived:
+    def __init__(self):
+        self.entries = {}      # key -> entry dict
+        self.table = None      # (signature, device table tensor, njobs, ntiles) of the last full refresh
+
+    def get(self, base, view, kind, scale, spec, shape):
+        """The derived operand of ``view`` (a view of parameter ``base``), current with respect to the parameter."""
+        import weakref
+        key = (id(base), view.storage_offset(), tuple(view.shape), kind, 0 if scale is None else id(scale))
+        e = self.entries.get(key)
+        if e is not None and (e['ref']() is not base or e['src'] != view.data_ptr() or (scale is not None and e['scale_ref']() is not scale)):
+            e = None                                                       # a dead parameter's address, or the parameter moved
+        if e is None:
+            for k in [k for k, v in self.entries.items() if v['ref']() is None]:
+                del self.entries[k]
+            e = {'ref': weakref.ref(base), 'src': view.data_ptr(), 'dst': _empty(shape, view), 'spec': spec, 'version': None,
+                 'scale_ref': None if scale is None else weakref.ref(scale), 'scale': 0 if scale is None else scale.data_ptr(),
+                 'fresh': False, 'device': view.device}
+            self.entries[key] = e
+            self.table = None
+        if not e['fresh'] or e['version'] != base._version:
+            self._run([e], cache=False)
+            e['fresh'], e['version'] = True, base._version
+        return e['dst']
+
+    def _build(self, entries):
+        import numpy as np
+        jobs = np.zeros(len(entries), dtype=_perm_dtype())
+        tile = 0
+        owners = []
+        for i, e in enumerate(entries):
+            Z, R, C, sz, sr, sc, dz, dc = e['spec']
+            tr, tc = (R + 31) // 32, (C + 31) // 32
+            jobs[i] = (e['src'], e['dst'].data_ptr(), e['scale'], Z, R, C, sz, sr, sc, dz, dc, tile, tr, tc, 0)
+            owners.append(np.full(Z * tr * tc, i, dtype=np.uint32))
+            tile += Z * tr * tc
+        cmap = np.concatenate(owners) if owners else np.zeros(0, np.uint32)
+        raw = np.concatenate([jobs.view(np.uint8), cmap.view(np.uint8)])
+        return raw, jobs.nbytes, len(entries), tile
+
+    def _run(self, entries, cache):
+        if not entries:
+            return
+        dev = entries[0]['device']
+        sig = tuple((e['src'], e['dst'].data_ptr(), e['scale']) for e in entries)
+        if cache and self.table is not None and self.table[0] == sig:
+            _, table, off, njobs, ntiles = self.table
+        else:
+            raw, off, njobs, ntiles = self._build(entries)
+            host = torch.from_numpy(raw)
+            if dev.type == 'cuda':
+                host = host.pin_memory()
+            table = torch.empty(raw.nbytes, dtype=torch.uint8, device=dev)
+            table.copy_(host, non_blocking=True)
+            if dev.type == 'cuda':
+                host_keep = (host, torch.cuda.Event())                    # the pinned staging buffer outlives the copy
+                host_keep[1].record()
+                self._staging = getattr(self, '_staging', [])[-8:] + [host_keep]
+            if cache:
+                self.table = (sig, table, off, njobs, ntiles)
+        lib = _lib.load_library()
+        with _on(dev):
+            base = table.data_ptr()
+            _chk(lib.cotr_train_perm_jobs(ctypes.c_void_p(base), ctypes.c_void_p(base + off), njobs, ntiles, _sp()), 'cotr_train_perm_jobs')
+        self._last_table = table                                           # (stream-ordered allocator: alive until the launch ran)
+
+    def refresh(self):
+        """Every registered operand re-derived from its parameter in ONE launch (call after the optimiser step)."""
+        live = [e for e in self.entries.values() if e['ref']() is not None]
+        live = [e for e in live if e['scale_ref'] is None or e['scale_ref']() is not None]
+        if len(live) != len(self.entries):
+            self.entries = {k: v for k, v in self.entries.items() if any(v is e for e in live)}
+            self.table = None
+        by_dev = {}
+        for e in live:
+            by_dev.setdefault(e['device'], []).append(e)
+        for dev_entries in by_dev.values():
+            self._run(dev_entries, cache=len(by_dev) == 1)
+        for e in live:
+            e['fresh'], e['version'] = True, e['ref']()._version
+        return len(live)
+
+    def mark_stale(self, keep=()):
+        keep = set(keep)
+        for k, e in self.entries.items():
+            if k not in keep:
+                e['fresh'] = False
+
+    def clear(self):
+        self.entries, self.table = {}, None
+
+
+_derived = _Derived()
 
 
 def clear_weight_cache():
-    """Drop the cached W^T tensors (GraphedTrainStep: a replayed graph updates the weights without bumping their Python-side
-    version counters, so entries made before / during capture would look current to a later eager step)."""
-    _wt_cache.clear()
+    """Forget every derived operand (their buffers are re-made at the next use)."""
+    _derived.clear()
+
+
+def refresh_derived():
+    """Re-derive every registered weight-shaped operand (W^T slices, packed / BN-scaled convolution weights) in one launch: call
+    after the optimiser step.  -> number of operands."""
+    return _derived.refresh()
+
+
+def derived_keys():
+    return tuple(_derived.entries)
+
+
+def mark_derived_stale(keep=()):
+    """The parameters changed behind the registry's back (a replayed graph that does not refresh these operands itself)."""
+    _derived.mark_stale(keep)
+
+
+def _base_of(w):
+    return w._base if w._base is not None else w
 
 
 def weight_t(w):
-    """w[N,K] -> contiguous w^T [K,N] by the HIP transpose kernel, cached until the parameter changes (optimiser step).
-    The cache hangs on the identity of the parameter object (weak reference), not on its address: torch's allocator hands
-    the address of a freed model's weights to the next model."""
-    import weakref
-    base = w._base if w._base is not None else w
-    entry = _wt_cache.get(id(base))
-    if entry is None or entry[0]() is not base:
-        for k in [k for k, e in _wt_cache.items() if e[0]() is None]:      # drop entries of dead parameters
-            del _wt_cache[k]
-        entry = (weakref.ref(base), {})
-        _wt_cache[id(base)] = entry
-    key = (w.storage_offset(), tuple(w.shape))
-    hit = entry[1].get(key)
-    if hit is not None and hit[0] == base._version:
-        return hit[1]
-    lib = _lib.load_library()
+    """w [N,K] (a parameter, or a contiguous row slice of one) -> contiguous w^T [K,N], kept current by the registry above."""
     n, k = w.shape
-    wt = _empty((k, n), w)
-    with _on(w.device):
-        _chk(lib.cotr_train_transpose(_P(w.detach()), _P(wt), n, k, _sp()), 'cotr_train_transpose')
-    entry[1][key] = (base._version, wt)
-    return wt
+    assert w.is_contiguous()
+    return _derived.get(_base_of(w), w.detach(), 'T', None, (1, n, k, 0, k, 1, 0, n), (k, n))
+
+
+def conv_packed(w):
+    """torch's [Cout, Cin, k, k] -> the kernels' [Cout][k*k*Cin] (tap-major, channel fastest)."""
+    cout, cin, k, _ = w.shape
+    if k == 1:
+        return w.detach().reshape(cout, cin)
+    kk = k * k
+    return _derived.get(_base_of(w), w.detach(), 'P', None, (cout, cin, kk, cin * kk, kk, 1, kk * cin, cin), (cout, kk * cin))
+
+
+def conv_scaled_t(w, scale):
+    """(packed weight * FrozenBN scale per output channel)^T -> [k*k*Cin][Cout]: the weight operand of the dgrad GEMM."""
+    cout, cin, k, _ = w.shape
+    kk = k * k
+    return _derived.get(_base_of(w), w.detach(), 'S', scale, (kk, cout, cin, 1, cin * kk, kk, cin * cout, cout), (kk * cin, cout))
 
 
 class Proj(torch.autograd.Function):
@@ -763,18 +893,6 @@ class Attention(torch.autograd.Function):
         return None, dq, dk, dv, None, None, None, None
 
 
-def _pack_conv_weight(w):
-    """torch's [Cout, Cin, k, k] -> the kernels' [Cout][k][k][Cin] (batched transpose on the device)."""
-    lib = _lib.load_library()
-    cout, cin, k, _ = w.shape
-    if k == 1:
-        return w.detach().reshape(cout, cin)
-    out = _empty((cout, k * k * cin), w)
-    with _on(w.device):
-        _chk(lib.cotr_train_transpose_batched(_P(w.detach().contiguous()), _P(out), cout, cin, k * k, _sp()), 'cotr_train_transpose_batched')
-    return out
-
-
 class ConvBN(torch.autograd.Function):
     """One convolution of a trainable bottleneck (layer2 / layer3: COTR/models/backbone.py:66-69 trains only these) with its
     FrozenBatchNorm2d affine (backbone.py:46-56), optional residual and ReLU, on the NHWC side-by-side layout of the inference
@@ -791,21 +909,21 @@ class ConvBN(torch.autograd.Function):
         cout, _, k, _ = w.shape
         pad = k // 2
         ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
-        wp = _pack_conv_weight(w)
+        wp = conv_packed(w)
         y = _empty((b, ho, 2 * wo, cout), x)
         with _on(x.device):
             _chk(lib.cotr_op_conv(_P(x), _P(wp), _P(scale), _P(bias), _P(None if res is None else res.contiguous()), int(relu), _P(y),
                                   b, h, wd, cin, cout, k, stride, _sp()), 'cotr_op_conv')
         ctx.meta = (b, h, wd, cin, cout, k, stride, ho, wo, bool(relu), res is not None)
         ctx.weight = w
-        ctx.save_for_backward(x, wp, scale, y)
+        ctx.save_for_backward(x, scale, y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load_library()
         b, h, wd, cin, cout, k, stride, ho, wo, relu, has_res = ctx.meta
-        x, wp, scale, y = ctx.saved_tensors
+        x, scale, y = ctx.saved_tensors
         m, kk = b * ho * 2 * wo, k * k * cin
         dy = dy.contiguous()
         dz = dy
@@ -835,10 +953,7 @@ class ConvBN(torch.autograd.Function):
                     _chk(lib.cotr_train_transpose_batched(_P(dwp), _P(dw), cout, k * k, cin, _sp()), 'cotr_train_transpose_batched')
             dx = None
             if ctx.needs_input_grad[0]:
-                ws = torch.empty_like(wp)
-                _chk(lib.cotr_train_scale_rows(_P(wp), _P(scale), _P(ws), cout, kk, _sp()), 'cotr_train_scale_rows')
-                wst = _empty((kk, cout), x)
-                _chk(lib.cotr_train_transpose(_P(ws), _P(wst), cout, kk, _sp()), 'cotr_train_transpose')
+                wst = conv_scaled_t(ctx.weight, scale)                        # (W * scale)^T, derived once per optimiser step
                 dcol = gemm(dz2, wst)                                         # [m, k*k*cin]
                 if direct:
                     dx = dcol.view(b, h, 2 * wd, cin)

@@ -474,7 +474,8 @@ class GraphedTrainStep:
                 self._body()
         torch.cuda.current_stream(img.device).wait_stream(side)
         torch.cuda.synchronize(img.device)
-        T.clear_weight_cache()                             # transposes made during capture must live in the graph's pool
+        # (the derived weight operands - train_ops._derived - were made by the warm-up steps and are persistent: the captured step
+        #  reads them and, with a FusedAdam, re-derives them itself behind its optimiser step; any other optimiser: see __call__)
         self.graph = torch.cuda.CUDAGraph()
         if self.sink is None:
             optim.zero_grad(set_to_none=True)
@@ -482,7 +483,7 @@ class GraphedTrainStep:
             self.loss, self.pred = self._body()
         if self.sink is not None:
             self.sink.frozen = True                        # the graph replays its table upload from the sink's pinned buffer
-        T.clear_weight_cache()                             # (their Python handles may go: the pool keeps the memory for the graph)
+        self._derived_keys = T.derived_keys()              # what a replay keeps current by itself (it re-derives them behind its update)
 
     def _body(self):
         self.salt.add_(0x3C6EF35F)                         # a new mask family per step (int32 wrap-around is fine)
@@ -504,6 +505,9 @@ class GraphedTrainStep:
         elif self.group is not None or (dist.is_available() and dist.is_initialized()):
             sync_gradients([p for g in self.optim.param_groups for p in g['params']], self.group)
         self.optim.step()
+        if not isinstance(self.optim, FusedAdam):           # (a FusedAdam re-derives the weight operands behind its own update)
+            from . import train_ops as T
+            T.refresh_derived()
         return loss.detach(), pred.detach()
 
     def __call__(self, img, query, target, check=False):
@@ -512,10 +516,10 @@ class GraphedTrainStep:
         self.query.copy_(query)
         self.target.copy_(target)
         self.graph.replay()
-        # a replay updates the weights without bumping their Python version counters: a W^T cached by an eager step in between
-        # would be stale for the next eager backward
+        # a replay updates the weights without bumping their Python version counters: derived operands the captured step does not
+        # refresh itself (made by an eager step in between, or all of them with an optimiser other than FusedAdam) are stale now
         from . import train_ops as T
-        T.clear_weight_cache()
+        T.mark_derived_stale(keep=self._derived_keys)
         if check and not bool(torch.isfinite(self.loss)):
             raise FloatingPointError('loss is not finite in a captured training step (train_batch would have skipped it)')
         return self.loss, self.pred
@@ -645,8 +649,9 @@ class FusedAdam(torch.optim.Adam):
                                        ctypes.c_void_p(self.sink.flat.data_ptr()), ctypes.c_void_p(self._m.data_ptr()),
                                        ctypes.c_void_p(self._v.data_ptr()), lrs, len(self.param_groups), float(b1), float(b2),
                                        float(g0['eps']), bc1, bc2s, step_ptr, T._sp()), 'cotr_train_adam')
-        # the kernel wrote the weights through raw pointers: their Python version counters did not move, so drop what is keyed by them
-        T.clear_weight_cache()
+        # the kernel wrote the weights through raw pointers (their Python version counters did not move): every weight-shaped operand
+        # derived from them - W^T slices, packed / BN-scaled convolution weights - is re-derived now, in one launch
+        T.refresh_derived()
         return None
 
 
@@ -729,6 +734,9 @@ def train_batch(model, optim, img, query, target, cycle_consis=True, bidirection
     elif distributed:
         sync_gradients([p for g in optim.param_groups for p in g['params']], group)
     optim.step()
+    if not isinstance(optim, FusedAdam):                 # (a FusedAdam re-derives the weight operands itself, behind its update)
+        from . import train_ops as T
+        T.refresh_derived()
     return value, pred.detach()
 
 

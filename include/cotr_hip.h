@@ -254,6 +254,20 @@ typedef struct cotr_adam_job {
 int cotr_train_adam(const cotr_adam_job* jobs, const unsigned* chunk_job, int nchunks, const float* g, float* m, float* v, const float* lr,
                     int ngroups, double beta1, double beta2, double eps, double bias_correction1, double bias_correction2_sqrt,
                     const float* step, cotr_stream stream);
+/* Every weight-shaped operand of a training step re-derived from the parameters in ONE launch (after the optimiser step): the W^T
+ * slices of the dX GEMMs, the packed [Cout][k][k][Cin] convolution weights, the FrozenBN-scaled transposed convolution weights (one
+ * fp32 multiply per element, as cotr_train_scale_rows makes).  A job is a batched strided transpose of 32 x 32 tiles:
+ * dst[z*dz + c*dc + r] = src[z*sz + r*sr + c*sc] * (scale ? scale[r] : 1); tile_job[workgroup] = its job (device memory, like
+ * cotr_train_reduce_jobs); tile0 = the job's first workgroup, tiles_r / tiles_c = ceil(R / 32) / ceil(C / 32). */
+typedef struct cotr_perm_job {
+  const float* src;
+  float* dst;
+  const float* scale;
+  unsigned Z, R, C;
+  unsigned sz, sr, sc, dz, dc;
+  unsigned tile0, tiles_r, tiles_c, pad;
+} cotr_perm_job;
+int cotr_train_perm_jobs(const cotr_perm_job* jobs, const unsigned* tile_job, int njobs, int ntiles, cotr_stream stream);
 /* last corr_embed layer 256 -> 2 (position_encoding.py:23-26): y [nb][nq][2]; backward: dh [rows][256], dwb [514] = dW2 | db2 */
 int cotr_train_head_fwd(const float* x, const float* w, const float* b, float* y, int nb, int nq, cotr_stream stream);
 int cotr_train_head_bwd_parts(int rows);

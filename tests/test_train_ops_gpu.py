@@ -354,3 +354,47 @@ def test_reduce_jobs_kernel():
     assert torch.equal(sink.flat[mask], untouched[mask])
     sink.flush()                                                                    # nothing registered: no launch, no change
     assert sink.last == (0, 0)
+
+
+def test_derived_weight_operands_one_launch_refresh():
+    """train_ops._derived: the W^T slices of the dX GEMMs, the packed [Cout][k][k][Cin] convolution weights and the FrozenBN-scaled
+    transposed ones are kept in persistent buffers and re-derived from the parameters by ONE launch (cotr_train_perm_jobs) after the
+    optimiser step.  Values = what the single-purpose kernels / torch produce, bit for bit (a transpose is a copy; the scaling is
+    one fp32 multiply); an in-place parameter update is picked up by refresh_derived() and the buffers stay where they are."""
+    g = _g(123)
+    T.clear_weight_cache()
+    w = torch.nn.Parameter(torch.randn(768, 256, generator=g).cuda())
+    wc3 = torch.nn.Parameter(torch.randn(128, 64, 3, 3, generator=g).cuda())
+    wc1 = torch.nn.Parameter(torch.randn(96, 160, 1, 1, generator=g).cuda())
+    sc3, sc1 = (torch.rand(128, generator=g) + 0.5).cuda(), (torch.rand(96, generator=g) + 0.5).cuda()
+
+    def want():
+        out = {'t_all': w.detach().t().contiguous(), 't_qk': w.detach()[0:512].t().contiguous(), 't_v': w.detach()[512:768].t().contiguous()}
+        out['p3'] = wc3.detach().permute(0, 2, 3, 1).reshape(128, 576).contiguous()
+        out['s3'] = (out['p3'] * sc3[:, None]).t().contiguous()
+        out['s1'] = (wc1.detach().reshape(96, 160) * sc1[:, None]).t().contiguous()
+        return out
+
+    def got():
+        return {'t_all': T.weight_t(w), 't_qk': T.weight_t(w[0:512]), 't_v': T.weight_t(w[512:768]), 'p3': T.conv_packed(wc3),
+                's3': T.conv_scaled_t(wc3, sc3), 's1': T.conv_scaled_t(wc1, sc1)}
+    a, b = got(), want()
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+    assert T.conv_packed(wc1).data_ptr() == wc1.data_ptr()              # 1x1: the parameter is its own packed form
+    ptrs = {k: v.data_ptr() for k, v in a.items()}
+    with torch.no_grad():                                                # what FusedAdam does: the weights change through raw pointers
+        w.data.add_(1.0)
+        wc3.data.mul_(0.5)
+        wc1.data.sub_(0.25)
+    w._version, wc3._version                                             # (versions moved here; a captured step would not move them)
+    assert T.refresh_derived() == 6
+    a, b = got(), want()
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+        assert a[k].data_ptr() == ptrs[k], k                             # persistent buffers: a captured graph can keep reading them
+    T.mark_derived_stale()
+    with torch.no_grad():
+        w.data.add_(1.0)
+    assert torch.equal(T.weight_t(w[0:512]), w.detach()[0:512].t().contiguous())      # a stale entry is re-derived at its next use
+    T.clear_weight_cache()
