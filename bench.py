@@ -705,7 +705,12 @@ def main():
                          'launch': 'one cotr_forward (all kernels of a step)', 'launch_ms_hip_events': kernel_ms,
                          'algorithmic_gflop_per_launch': my_flop / 1e9,
                          'min_hbm_gbs': min_hbm_bytes(pairs, my_queries) / (kernel_ms * 1e-3) / 1e9,
-                         'hbm_peak_gbs': HBM_PEAK_GBS},
+                         'hbm_peak_gbs': HBM_PEAK_GBS,
+                         'peak_at_measured_clock': 155.9,
+                         'clock_note': ('shader clock under this workload measured by an un-instrumented probe wavefront (s_memtime vs the 100 MHz '
+                                        'wall clock, tools/clock_settle.py): 2.38-2.39 GHz for the 1-pair and the 32-pair forward and for back-to-back large-tile '
+                                        'GEMMs, amd-smi reads 2.38-2.40 GHz per XCD (profiles/r4_shader_clock_probe_and_smi.txt) - the chip does not throttle here, '
+                                        'so the nominal 157.3 TFLOP/s (2.4 GHz) is the peak to measure against; 155.9 = 65536 FLOP/clock x 2.379 GHz')},
         }
         extras = world == 1 and not args.no_extras and not batch256 and not dense
         line.update(ident)

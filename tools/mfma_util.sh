@@ -50,18 +50,21 @@ for pos, d in enumerate(ids):
     e['n'] += 1; e['ns'] += t0[d]; e['mfma'] += val[d].get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0); e['gui'] += val[d].get('GRBM_GUI_ACTIVE', 0.0)
     if pos < len(fetch): e['fetch'] += fetch[pos] * 1024 * 2
     if pos < len(write): e['write'] += write[pos] * 1024
-print(f'# one forward at B={B}, Q={Q}: per kernel family - launches, time, MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs),')
-print('# sustained clock = GRBM_GUI_ACTIVE / 8 / time, L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE, separate passes) and their rate.  rocprofv3 adds ~2.5 us to short kernels.')
-print(f'{"kernel":46s} {"n":>3s} {"us":>9s} {"MFMA util":>9s} {"GHz":>5s} {"MB":>8s} {"GB/s":>7s}')
+CLOCK_GHZ = 2.38   # shader clock under this load, measured by the un-instrumented probe (tools/clock_settle.py, profiles/r4_shader_clock_probe_and_smi.txt)
+print(f'# one forward at B={B}, Q={Q}: per kernel family - launches, time, MFMA pipe utilisation two ways: "util/GUI" = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x')
+print('# GRBM_GUI_ACTIVE / 8 XCDs) and "util/time" = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel time x 2.38 GHz, the probe-measured shader clock) - GRBM_GUI_ACTIVE')
+print('# also counts cycles outside the kernel timestamps (it read 4 "GHz" for LayerNorm in round 3: NOT a clock, that column is gone); L2<->fabric bytes')
+print('# (FETCH_SIZE x2 + WRITE_SIZE, separate passes) and their rate.  rocprofv3 adds ~2.5 us to short kernels.')
+print(f'{"kernel":46s} {"n":>3s} {"us":>9s} {"util/GUI":>9s} {"util/time":>9s} {"MB":>8s} {"GB/s":>7s}')
 tot = dict(ns=0.0, mfma=0.0, gui=0.0, b=0.0)
 for name, e in sorted(fam.items(), key=lambda kv: -kv[1]['ns']):
     cyc = e['gui'] / 8.0
     util = e['mfma'] / (1024.0 * cyc) if cyc else 0.0
-    ghz = cyc / e['ns'] if e['ns'] else 0.0
+    ghz = e['mfma'] / (1024.0 * e['ns'] * CLOCK_GHZ) if e['ns'] else 0.0
     mb = (e['fetch'] + e['write']) / 1e6
-    print(f'{name:46s} {e["n"]:3d} {e["ns"] / 1e3:9.1f} {util:9.3f} {ghz:5.2f} {mb:8.1f} {mb * 1e6 / e["ns"]:7.0f}')
+    print(f'{name:46s} {e["n"]:3d} {e["ns"] / 1e3:9.1f} {util:9.3f} {ghz:9.3f} {mb:8.1f} {mb * 1e6 / e["ns"]:7.0f}')
     tot['ns'] += e['ns']; tot['mfma'] += e['mfma']; tot['gui'] += e['gui']; tot['b'] += e['fetch'] + e['write']
 cyc = tot['gui'] / 8.0
-print(f'{"all kernels":46s} {"":3s} {tot["ns"] / 1e3:9.1f} {tot["mfma"] / (1024.0 * cyc):9.3f} {cyc / tot["ns"]:5.2f} {tot["b"] / 1e6:8.1f} {tot["b"] / tot["ns"]:7.0f}')
+print(f'{"all kernels":46s} {"":3s} {tot["ns"] / 1e3:9.1f} {tot["mfma"] / (1024.0 * cyc):9.3f} {tot["mfma"] / (1024.0 * tot["ns"] * CLOCK_GHZ):9.3f} {tot["b"] / 1e6:8.1f} {tot["b"] / tot["ns"]:7.0f}')
 PY
 cat $out
