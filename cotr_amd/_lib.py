@@ -128,6 +128,7 @@ _PROTOS = {
 _EXP_PROTOS = {
     'cotr_op_dec_head': (ctypes.c_int, [c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_linear_ln': (ctypes.c_int, [c_float_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_split_h2': (ctypes.c_int, [c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -19,12 +19,13 @@ LIB = os.path.join(CSRC, 'libcotr_hip.so')
 LIB_EXP = os.path.join(CSRC, 'libcotr_hip_exp.so')
 SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip',
            'dense_post.hip', 'ffn.hip', 'train.hip', 'attention_train.hip', 'api.hip']
-EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip'), os.path.join('experimental', 'gemm_pp.hip')]
+EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip'), os.path.join('experimental', 'gemm_pp.hip'),
+               os.path.join('experimental', 'gemm_h2.hip')]
 # Pillow-exact resamples and the torch-CPU-exact cycle map (8-bit, float and double code whose products must not be contracted into
 # FMAs behind the source's back; the FMAs that belong there are explicit)
 EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ffp-contract=off']}
 HEADERS = ['common.h', 'train.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
-EXP_HEADERS = [os.path.join('experimental', f) for f in ('coop_tail.h', 'experimental.h', 'api_exp.inc')]
+EXP_HEADERS = [os.path.join('experimental', f) for f in ('coop_tail.h', 'experimental.h', 'api_exp.inc', 'gemm_h2.h')]
 # code-object v5: loadable by the ROCm 7.0 runtime torch bundles as well as by ROCm 7.2's
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-mcode-object-version=5',
          '-Wall', '-Wno-unused-function']

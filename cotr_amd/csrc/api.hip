@@ -1316,6 +1316,10 @@ int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const f
                       float* y, int M, int K, cotr_stream stream) {
   return op_ret(launch_gemm_ln(x, K, w, bias, residual, 256, ln_w, ln_b, y, M, K, static_cast<hipStream_t>(stream)));
 }
+int cotr_op_split_h2(const float* x, void* y, size_t n, cotr_stream stream) {
+  if (!x || !y) return COTR_ERR_ARG;
+  return op_ret(launch_split_h2(x, y, n, static_cast<hipStream_t>(stream)));
+}
 #endif
 // one layer1 bottleneck from UNPACKED weights (tests): w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wd [256][64] or NULL (device
 // pointers); packs the fragment images on the host and launches bottleneck.hip

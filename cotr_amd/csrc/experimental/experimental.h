@@ -8,6 +8,8 @@
 //   GEMM configs 28 / 29  three LDS stages in the large-tile kernel                                  within +-5 %
 //   gemm_pp.hip      persistent ping-pong large tiles (configs 42 / 43): loaders run ahead across tiles,   383 vs 306 us (K = 256):
 //                    a tile's write-out beside the next tile's MFMAs                                     the write-out is not hidden
+//   gemm_h2.h/.hip   RESEARCH, not a dead end: fp32 products from three f16 MFMAs on packed split-f16 operands (configs 46 / 47);
+//                    not bit-identical to the fp32 path and range-limited (|x| < 65504) - see the header of gemm_h2.h
 #pragma once
 #include "coop_tail.h"
 
@@ -35,4 +37,7 @@ int launch_dec_head(const float* x, const float* nw, const float* nb, const floa
 void set_ln_reduce_warm(const float* p0, size_t bytes0, const float* p1, size_t bytes1);
 // gemm_pp.hip: persistent ping-pong large tiles (1 = 128 x 64 staged write-out, 3 = 128 x 64 LDS-free write-out)
 int launch_gemm_pp(int mode, int variant, const GemmParams& p, hipStream_t s);
-int gemm_pp_workgroups();   // persistent workgroups per launch on the current device
+int gemm_pp_workgroups();
+// gemm_h2.hip / gemm_h2.h (research): fp32 -> packed split-f16 dwords, the operand format of GEMM configurations 46 / 47
+int launch_split_h2(const float* x, void* y, size_t n, hipStream_t s);
+//   // persistent workgroups per launch on the current device

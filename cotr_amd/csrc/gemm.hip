@@ -749,6 +749,8 @@ static const GemmCfg kCfgs[] = {
     {9, 0, 2, 1},   // 43 persistent ping-pong 128x64, LDS-free write-out
     {5, 0, 2, 2},   // 44 large tile 128x128 (26) with the LDS-free epilogue: dword stores straight from the accumulators
     {5, 0, 2, 1},   // 45 large tile 128x64 (27) with the LDS-free epilogue
+    {5, 0, 2, 2},   // 46 large tile 128x128 on PACKED SPLIT-f16 operands (experimental/gemm_h2.h): 3 f16 MFMAs per fp32 product
+    {5, 0, 2, 1},   // 47 the same, 128x64
 #endif
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -870,6 +872,8 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 43: return launch_gemm_pp(MODE, 3, p, s);
     case 44: return launch_gemm_big(MODE, 6, p, s);
     case 45: return launch_gemm_big(MODE, 7, p, s);
+    case 46: return launch_gemm_big(MODE, 8, p, s);
+    case 47: return launch_gemm_big(MODE, 9, p, s);
 #endif
     case 40: return launch_gemm_big(MODE, 4, p, s);
     case 41: return launch_gemm_big(MODE, 5, p, s);
@@ -998,7 +1002,7 @@ static int gemm_pick_config_table(int mode, const GemmParams& p) {
   if (near != nullptr && near_d < 1.0) return cfg_fits(near->cfg, p) ? near->cfg : near->cfg_reg;
   int best = -1;
   double best_cost = 0;
-  for (int i = 0; i < kNumCfgs; ++i) {
+  for (int i = 0; i < kNumCfgs && i < 42; ++i) {   // 42 and up: experimental configurations, only ever run when forced
     if (!cfg_fits(i, p)) continue;
     const double c = model_cost(kCfgs[i], p);
     if (best < 0 || c < best_cost) {

@@ -20,6 +20,9 @@
 #include "common.h"
 
 #define BK 32
+#ifdef COTR_EXPERIMENTAL
+#include "experimental/gemm_h2.h"
+#endif
 
 // NST = LDS stages: 2 = every barrier drains the LDS-DMA queue (vmcnt(0)); 3 = ring with TWO tiles in flight: the wait before
 // the barrier of step t is a counted vmcnt that covers tile t only, tile t+1 stays in flight across the barrier (raw s_barrier,
@@ -27,8 +30,13 @@
 // DIRECT (experiment, configurations 44 / 45): the epilogue stores straight from the accumulators - a wave store = rows r and r + 4 of a
 // 32-column block = two full 128-B lines - instead of staging 32 rows at a time through LDS for float4 row stores: no LDS round trip, no
 // barrier between the K loop and the epilogue, 4x the store instructions.  Same arithmetic per element: bit-identical.
-template <int TN, int MODE, int NST, bool DIRECT = false>
+// X selects an experimental form (libcotr_hip_exp.so only): 0 = the product kernel, 1 = DIRECT, 2 = H2 (configurations 46 / 47,
+// experimental/gemm_h2.h): both operands arrive as PACKED SPLIT-f16 dwords (cotr_op_split_h2) and every fp32 product becomes three
+// v_mfma_f32_32x32x16_f16 - research, NOT bit-identical to the fp32 path.
+template <int TN, int MODE, int NST, int X = 0>
 __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid) {
+  constexpr bool DIRECT = X == 1;
+  constexpr bool H2 = X == 2;
   constexpr int BM = 128, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage
   constexpr int QW = BN / 32;             // W-tile DMA instructions per wavefront
@@ -111,6 +119,17 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#ifdef COTR_EXPERIMENTAL
+  f32x16 accx[H2 ? 2 : 1][H2 ? TN : 1];                 // H2: the cross terms (hi x lo + lo x hi), scaled by 2^11
+  if constexpr (H2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[a][b][r] = 0.f;
+  }
+#endif
 
   // both stages are requested up front; the residual tile (epilogue layout: row it*RPI + er, 4 columns at ec) follows
   // them so that its HBM latency is paid under the first barrier / the MFMAs instead of after them
@@ -154,6 +173,11 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
     }
     const float* As = smem + st * STAGE + (wm * 64 + l31) * BK;
     const float* Ws = smem + st * STAGE + BM * BK + (wn * 32 * TN + l31) * BK;
+#ifdef COTR_EXPERIMENTAL
+    if constexpr (H2) {
+      h2_kstep<TN>(As, Ws, hh, sw, acc, accx);
+    } else
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ch = ((j * 2 + hh) ^ sw) * 4;
@@ -175,6 +199,16 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
       st = st == 2 ? 0 : st + 1;
     }
   }
+#ifdef COTR_EXPERIMENTAL
+  if constexpr (H2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = fmaf(accx[a][b][r], 0x1p-11f, acc[a][b][r]);
+  }
+#endif
   if constexpr (DIRECT) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -482,9 +516,9 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int TN, int MODE, int NST, bool DIRECT = false>
+template <int TN, int MODE, int NST, int X = 0>
 __global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
-  gemm_big_body<TN, MODE, NST, DIRECT>(p, blockIdx.x);
+  gemm_big_body<TN, MODE, NST, X>(p, blockIdx.x);
 }
 
 // two independent problems in one grid (common.h: launch_gemm_dual_cfg)
@@ -524,7 +558,7 @@ int launch_gemm_big_dual(int mode, int variant, const GemmParams& p0, const Gemm
   return variant == 0 ? launch_big_dual_t<2>(p0, p1, s) : variant == 1 ? launch_big_dual_t<1>(p0, p1, s) : -1;
 }
 
-template <int TN, int MODE, int NST, bool DIRECT = false>
+template <int TN, int MODE, int NST, int X = 0>
 static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr size_t smem = (size_t)NST * (BM + BN) * BK * sizeof(float);
@@ -537,14 +571,14 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   if (p.zeros == nullptr) return -2;
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST, DIRECT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST, X>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set.set();
   }
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
   const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST, DIRECT>), dim3(tiles), dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST, X>), dim3(tiles), dim3(256), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -560,8 +594,10 @@ int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s) {
 #ifdef COTR_EXPERIMENTAL   // configurations 28 / 29 (three LDS stages: within +-5 % of the two-stage kernel, never in the tuned table)
     case 2: return d ? launch_big_t<2, GEMM_DENSE, 3>(p, s) : launch_big_t<2, GEMM_CONV, 3>(p, s);
     case 3: return d ? launch_big_t<1, GEMM_DENSE, 3>(p, s) : launch_big_t<1, GEMM_CONV, 3>(p, s);
-    case 6: return d ? launch_big_t<2, GEMM_DENSE, 2, true>(p, s) : launch_big_t<2, GEMM_CONV, 2, true>(p, s);   // direct epilogue
-    case 7: return d ? launch_big_t<1, GEMM_DENSE, 2, true>(p, s) : launch_big_t<1, GEMM_CONV, 2, true>(p, s);
+    case 6: return d ? launch_big_t<2, GEMM_DENSE, 2, 1>(p, s) : launch_big_t<2, GEMM_CONV, 2, 1>(p, s);   // direct epilogue
+    case 7: return d ? launch_big_t<1, GEMM_DENSE, 2, 1>(p, s) : launch_big_t<1, GEMM_CONV, 2, 1>(p, s);
+    case 8: return d ? launch_big_t<2, GEMM_DENSE, 2, 2>(p, s) : launch_big_t<2, GEMM_CONV, 2, 2>(p, s);   // packed split-f16 operands
+    case 9: return d ? launch_big_t<1, GEMM_DENSE, 2, 2>(p, s) : launch_big_t<1, GEMM_CONV, 2, 2>(p, s);
 #endif
     case 4: return d ? launch_ws_t<2, GEMM_DENSE>(p, s) : launch_ws_t<2, GEMM_CONV>(p, s);   // wave-specialised 128 x 128
     case 5: return d ? launch_ws_t<1, GEMM_DENSE>(p, s) : launch_ws_t<1, GEMM_CONV>(p, s);   // wave-specialised 128 x 64

@@ -407,6 +407,10 @@ int cotr_op_dec_head(const float* x, const float* nw, const float* nb, const flo
 /* y [M][256] = LayerNorm(x [M][K] . w [256][K]^T + bias + residual [M][256]) * ln_w + ln_b in one launch (op-level entry for the tests) */
 int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const float* residual, const float* ln_w, const float* ln_b,
                       float* y, int M, int K, cotr_stream stream);
+/* RESEARCH (csrc/experimental/gemm_h2.h): y[i] = packed split-f16 form of x[i] (f16(x) | f16((x - f16(x)) * 2^11) << 16), n a multiple of 4,
+ * 16-byte aligned, in place allowed.  cotr_op_linear / cotr_op_conv with the forced configurations 46 / 47 take BOTH operands (activations
+ * and weights) in this form and return fp32; |x| must stay below 65504.  Not bit-identical to the fp32-MFMA path. */
+int cotr_op_split_h2(const float* x, void* y, size_t n, cotr_stream stream);
 #endif
 
 #ifdef __cplusplus

@@ -359,3 +359,58 @@ def test_large_tile_with_lds_free_epilogue_is_bit_identical(M, N, K):
                 assert lib.cotr_op_linear_cfg(G.P(x), G.P(w), G.P(b), G.P(res) if res is not None else None, relu, G.P(y), M, N, K, cfg, G.sptr()) == 0
                 outs.append(y)
             assert torch.equal(outs[0], outs[1]), (base, direct)
+
+
+def _split_h2_host(x):
+    """the packing of experimental/gemm_h2.h restated with torch: (f16 hi | f16((x - hi) * 2^11) << 16) as int32"""
+    hi = x.to(torch.float16)
+    lo = ((x - hi.float()) * 2048.0).to(torch.float16)
+    return (hi.view(torch.int16).to(torch.int32) & 0xFFFF) | (lo.view(torch.int16).to(torch.int32) << 16)
+
+
+@pytest.mark.parametrize('M,N,K', [(4133, 512, 256), (16384, 256, 1024), (1000, 128, 2304)])
+def test_split_f16_large_tile_is_as_close_to_fp64_as_the_fp32_path(M, N, K):
+    """RESEARCH (experimental/gemm_h2.h, configurations 46 / 47): both operands as packed split-f16 dwords, three f16 MFMAs per
+    fp32 product.  Pinned here: the packing kernel bit for bit against its torch restatement; the GEMM (bias + residual + ReLU,
+    ragged last row tile) against the fp64 truth - no further from it than 1.5x the fp32-MFMA configurations 26 / 27, measured
+    against sum |a||b| (tools/split_mfma_numerics.py predicts 1.0-1.2x); a convolution gathers packed pixels like fp32 ones."""
+    lib = _lib.load_library()
+    d = G.dev()
+    g = _g(M + N + K + 2)
+    x = torch.relu(torch.randn(M, K, generator=g)).to(d)                     # post-ReLU activations
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(d)
+    b, r = torch.randn(N, generator=g).to(d), torch.randn(M, N, generator=g).to(d)
+    xp, wp = torch.empty_like(x), torch.empty_like(w)
+    assert lib.cotr_op_split_h2(G.P(x), G.P(xp), x.numel(), G.sptr()) == 0
+    assert lib.cotr_op_split_h2(G.P(w), G.P(wp), w.numel(), G.sptr()) == 0
+    assert torch.equal(xp.view(torch.int32), _split_h2_host(x)) and torch.equal(wp.view(torch.int32), _split_h2_host(w))
+    truth = x.double() @ w.double().t() + b.double() + r.double()
+    scale = x.double().abs() @ w.double().abs().t() + b.double().abs() + r.double().abs()
+    err = {}
+    for cfg, a_, w_ in ((26, x, w), (27, x, w), (46, xp, wp), (47, xp, wp)):
+        y = torch.full((M + 1, N), 7.0, device=d)
+        assert lib.cotr_op_linear_cfg(G.P(a_), G.P(w_), G.P(b), G.P(r), 0, G.P(y), M, N, K, cfg, G.sptr()) == 0
+        assert bool((y[M] == 7.0).all())
+        e = (y[:M].double() - truth).abs() / scale
+        err[cfg] = (float(e.pow(2).mean().sqrt()), float(e.max()))
+        yr = torch.empty(M, N, device=d)
+        assert lib.cotr_op_linear_cfg(G.P(a_), G.P(w_), G.P(b), G.P(r), 1, G.P(yr), M, N, K, cfg, G.sptr()) == 0
+        assert torch.equal(yr, torch.relu(y[:M]))
+    print(M, N, K, {k: (f'{v[0]:.3g}', f'{v[1]:.3g}') for k, v in err.items()})
+    assert err[46][0] <= 1.5 * err[26][0] and err[47][0] <= 1.5 * err[27][0], err
+    assert err[46][1] <= 4e-7 and err[47][1] <= 4e-7, err
+    # 3x3 convolution + FrozenBN + residual + ReLU on packed pixels / packed weights
+    B, H, cin, cout = 3, 32, 64, 128
+    xs = torch.relu(torch.randn(B, H, 2 * H, cin, generator=g)).to(d)
+    ws = (torch.randn(cout, 9 * cin, generator=g) / math.sqrt(9 * cin)).to(d)
+    sc, bi = (torch.rand(cout, generator=g) + 0.5).to(d), torch.randn(cout, generator=g).to(d)
+    rs = torch.randn(B, H, 2 * H, cout, generator=g).to(d)
+    xsp, wsp = torch.empty_like(xs), torch.empty_like(ws)
+    assert lib.cotr_op_split_h2(G.P(xs), G.P(xsp), xs.numel(), G.sptr()) == 0
+    assert lib.cotr_op_split_h2(G.P(ws), G.P(wsp), ws.numel(), G.sptr()) == 0
+    want = torch.empty(B, H, 2 * H, cout, device=d)
+    assert lib.cotr_op_conv_cfg(G.P(xs), G.P(ws), G.P(sc), G.P(bi), G.P(rs), 1, G.P(want), B, H, H, cin, cout, 3, 1, 27, G.sptr()) == 0
+    for cfg in (46, 47):
+        got = torch.empty_like(want)
+        assert lib.cotr_op_conv_cfg(G.P(xsp), G.P(wsp), G.P(sc), G.P(bi), G.P(rs), 1, G.P(got), B, H, H, cin, cout, 3, 1, cfg, G.sptr()) == 0
+        assert float((got - want).abs().max()) < 2e-5, (cfg, float((got - want).abs().max()))

@@ -1,0 +1,38 @@
+"""RESEARCH (round-3 verdict item 8): the large-tile GEMM on packed split-f16 operands (configurations 46 / 47 of libcotr_hip_exp.so,
+csrc/experimental/gemm_h2.h: three v_mfma_f32_32x32x16_f16 per fp32 product) next to the fp32-MFMA configurations 26 / 27 on the
+shapes of the batched forward and on plain squares; the cost of packing an operand (cotr_op_split_h2) is timed on its own.
+"TFLOP/s" counts the fp32 work (2 M N K) whatever the kernel does inside.   GPU box:  COTR_HIP_EXPERIMENTAL=1 python tools/bench_split_f16.py"""
+import ctypes, os, sys
+os.environ.setdefault('COTR_HIP_EXPERIMENTAL', '1')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cotr_amd import _lib
+lib = _lib.load_library()
+dev = torch.device('cuda:0')
+P = lambda t: t.data_ptr()
+shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (16384, 1024, 256), (16384, 256, 1024), (32000, 1024, 256), (32000, 256, 1024),
+          (16384, 256, 2304), (65536, 128, 1152), (262144, 64, 576), (262144, 256, 64), (262144, 64, 256), (16384, 768, 256)]
+for M, N, K in shapes:
+    x = torch.relu(torch.randn(M, K, device=dev))
+    w = torch.randn(N, K, device=dev) / K ** 0.5
+    y = torch.empty(M, N, device=dev)
+    xp, wp = torch.empty_like(x), torch.empty_like(w)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.cotr_op_split_h2(P(x), P(xp), x.numel(), s) == 0 and lib.cotr_op_split_h2(P(w), P(wp), w.numel(), s) == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        lib.cotr_op_split_h2(P(x), P(xp), x.numel(), s)
+    e1.record()
+    torch.cuda.synchronize()
+    pack_us = e0.elapsed_time(e1) * 100
+    line = f'{M:7d} x {N:5d} x {K:5d}:'
+    t = {}
+    for cfg, a_, w_ in ((26, x, w), (27, x, w), (46, xp, wp), (47, xp, wp)):
+        us = ctypes.c_float(0)
+        r = lib.cotr_bench_linear(P(a_), P(w_), None, P(y), M, N, K, cfg, 10, ctypes.byref(us))
+        t[cfg] = us.value if r == 0 else float('nan')
+        line += f'  cfg {cfg} {t[cfg]:8.1f} us {2.0 * M * N * K / t[cfg] / 1e6:6.1f} TF'
+    best32, best16 = min(t[26], t[27]), min(t[46], t[47])
+    print(line + f'   packing x: {pack_us:6.1f} us   split-f16 / fp32 = {best32 / best16:.2f}x ({best32 / (best16 + pack_us):.2f}x with the packing pass)', flush=True)
