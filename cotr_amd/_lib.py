@@ -129,6 +129,8 @@ _EXP_PROTOS = {
     'cotr_op_dec_head': (ctypes.c_int, [c_float_p] * 11 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_linear_ln': (ctypes.c_int, [c_float_p] * 7 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_split_h2': (ctypes.c_int, [c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'cotr_op_unsplit_h2': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_void_p]),
+    'cotr_op_set_h2_flags': (ctypes.c_int, [ctypes.c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -98,6 +98,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"coop_tail_spin", 4000, 0, INT_MAX},
     {"gemm_ln_min_rows", 1 << 30, 0, INT_MAX},
     {"l2_warm", 0, 0, 3},
+    {"split_f16", 0, 0, 2},
 #endif
 };
 bool knob_value_ok(int id, int v) {
@@ -130,6 +131,12 @@ struct cotr_ctx {
   // cooperative tails (experimental/coop_tail.h): generation-tagged arrival / claim words per row tile, and the launch counter that tags them
   unsigned long long* tail_state = nullptr;
   unsigned long long tail_gen = 0;
+  // RESEARCH, knob split_f16 (experimental/gemm_h2.h): the packed split-f16 image of wbuf (same offsets), built on first use; h2_pass is
+  // set while encode / decode walk a section whose activations are packed dwords instead of fp32
+  float* wbuf_h2 = nullptr;
+  size_t wbuf_h2_floats = 0;
+  bool wbuf_h2_valid = false;
+  bool h2_pass = false;
 #endif
   // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
   struct FusedBlock { const float *w2p = nullptr, *w3p = nullptr, *wdp = nullptr; };
@@ -281,6 +288,11 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
   Arena& a = h->tap_store[name];
   int r = ensure(h, a, n);
   if (r) return r;
+#ifdef COTR_EXPERIMENTAL
+  if (h->h2_pass) {
+    KCHK(h, launch_unsplit_h2(src, a.ptr, n, s), "unsplit_h2 (tap)");
+  } else
+#endif
   HIPCHK(h, hipMemcpyAsync(a.ptr, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   h->taps[name] = {a.ptr, n};
   return COTR_OK;
@@ -294,6 +306,26 @@ GemmParams base_params() {
   return p;
 }
 
+#ifdef COTR_EXPERIMENTAL
+// RESEARCH, knob split_f16: the packed image of a weight tensor of wbuf; the large-tile configuration for packed operands
+const float* h2_weight(const cotr_ctx* h, const float* w) { return h->wbuf_h2 + (w - h->wbuf); }
+int h2_config(const GemmParams& p) { return (p.N % 128 == 0 && (long)p.M * p.N >= (long)256 * 128 * 128) ? 46 : 47; }
+int h2_prepare_weights(cotr_ctx* h, hipStream_t s) {
+  if (h->wbuf_h2 && h->wbuf_h2_valid) return COTR_OK;
+  if (h->wbuf_h2 && h->wbuf_h2_floats < h->wfloats) {
+    HIPCHK(h, hipFree(h->wbuf_h2));
+    h->wbuf_h2 = nullptr;
+  }
+  if (!h->wbuf_h2) {
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->wbuf_h2), (h->wfloats + 4) * sizeof(float)));
+    h->wbuf_h2_floats = h->wfloats;
+  }
+  KCHK(h, launch_split_h2(h->wbuf, h->wbuf_h2, h->wfloats & ~(size_t)3, s), "split_h2 (weights)");
+  h->wbuf_h2_valid = true;
+  return COTR_OK;
+}
+#endif
+
 // y[M,N] = epi( (x (+x2)) . w^T )
 int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_period, int a2_width,
            const float* w, const float* bias, const float* residual, int relu, float colscale, int colscale_n,
@@ -305,6 +337,16 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
   p.W = w; p.C = y; p.ldc = ldc ? ldc : N;
   p.bias = bias; p.residual = residual; p.ldr = N; p.res_row_mod = res_row_mod; p.relu = relu;
   p.colscale = colscale; p.colscale_n = colscale_n;
+#ifdef COTR_EXPERIMENTAL
+  if (h->h2_pass) {   // x is packed; y is fp32 (the consumers of a projection - LayerNorm, attention, the residual stream - read fp32)
+    if (x2 != nullptr) { h->err = "split_f16: the x + pos prologue is not available on packed operands"; return COTR_ERR_ARG; }
+    p.W = h2_weight(h, w);
+    const int cfg = h2_config(p);
+    KCHK(h, launch_gemm_cfg(GEMM_DENSE, cfg, p, s), "linear (split f16)");
+    if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, cfg); prof_mark(h, nm, s, 2); }
+    return COTR_OK;
+  }
+#endif
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, gemm_pick_config(GEMM_DENSE, p)); prof_mark(h, nm, s, 2); }
   return COTR_OK;
@@ -364,6 +406,9 @@ GemmParams conv_params(const ConvW& c, const float* x, const float* residual, in
 int conv_pair(cotr_ctx* h, const ConvW& cd, const ConvW& c1, const float* x, float* yd, float* y1, int B, int Hin, int Win,
               hipStream_t s) {
   if (!knob(KN_DUAL_CONV)) return 0;
+#ifdef COTR_EXPERIMENTAL
+  if (h->h2_pass) return 0;
+#endif
   const GemmParams pd = conv_params(cd, x, nullptr, 0, yd, B, Hin, Win), p1 = conv_params(c1, x, nullptr, 1, y1, B, Hin, Win);
   if (p1.M > 16384) return 0;   // batched: throughput-bound, each problem keeps its own best configuration
   const int cfd = gemm_pick_config(GEMM_CONV, pd), cf1 = gemm_pick_config(GEMM_CONV, p1);
@@ -386,6 +431,17 @@ int conv_pair(cotr_ctx* h, const ConvW& cd, const ConvW& c1, const float* x, flo
 
 int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int relu, float* y, int B,
          int Hin, int Win, hipStream_t s) {
+#ifdef COTR_EXPERIMENTAL
+  if (h->h2_pass) {   // x, the residual and y are packed split-f16 tensors
+    GemmParams q = conv_params(c, x, residual, relu, y, B, Hin, Win);
+    q.W = h2_weight(h, c.w);
+    q.h2_flags = 1 | (residual ? 2 : 0);
+    const int cfg = h2_config(q);
+    KCHK(h, launch_gemm_cfg(GEMM_CONV, cfg, q, s), "conv (split f16)");
+    if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "conv%dx%d/%d %dx%dx%d cfg%d", c.k, c.k, c.stride, q.M, q.N, q.K, cfg); prof_mark(h, nm, s, 2); }
+    return COTR_OK;
+  }
+#endif
   const GemmParams p = conv_params(c, x, residual, relu, y, B, Hin, Win);
   KCHK(h, launch_gemm(GEMM_CONV, p, s), "conv");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "conv%dx%d/%d %dx%dx%d cfg%d", c.k, c.k, c.stride, p.M, p.N, p.K, gemm_pick_config(GEMM_CONV, p)); prof_mark(h, nm, s, 2); }
@@ -467,6 +523,7 @@ void cotr_destroy(cotr_handle h) {
   if (h->pos) (void)hipFree(h->pos);
 #ifdef COTR_EXPERIMENTAL
   if (h->tail_state) (void)hipFree(h->tail_state);
+  if (h->wbuf_h2) (void)hipFree(h->wbuf_h2);
 #endif
   for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr})
     if (a->ptr && !a->external) (void)hipFree(a->ptr);
@@ -651,6 +708,9 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
     h->wfloats = host.size();
   }
   HIPCHK(h, hipMemcpy(h->wbuf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+#ifdef COTR_EXPERIMENTAL
+  h->wbuf_h2_valid = false;
+#endif
   const float* base = h->wbuf;
   h->convs.clear();
   for (const auto& c : convs) h->convs.push_back({base + c.w, base + c.scale, base + c.bias, c.cin, c.cout, c.k, c.stride});
@@ -756,6 +816,15 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     prof_mark(h, "stem+pool", s);
     if (int r = tap_save(h, "stem", b_stem, n_stem * Bc, s)) return r;
     if (int r = tap_save(h, "pool", b_pool, n_pool * Bc, s)) return r;
+#ifdef COTR_EXPERIMENTAL
+    if (knob(KN_SPLIT_F16)) {   // RESEARCH: from here to input_proj every activation is a packed split-f16 tensor (gemm_h2.h)
+      if (int r = h2_prepare_weights(h, s)) return r;
+      KCHK(h, launch_split_h2(b_pool, b_pool, n_pool * Bc, s), "split_h2 (pool)");
+      prof_mark(h, "split_h2 pool", s, 2);
+      h->h2_pass = true;
+    }
+    struct H2PassEnd { cotr_ctx* h; ~H2PassEnd() { h->h2_pass = false; } } h2_pass_end{h};
+#endif
     const float* x = b_pool;
     float* outbuf[2] = {b_x, b_y};
     int flip = 0, H = 64, W = 64;
@@ -769,7 +838,11 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
         float* y = outbuf[flip];
         flip ^= 1;
         int r;
-        if (st == 0 && Bc <= knob(KN_BOTTLENECK_MAX_PAIRS) && H == 64 && W == 64) {
+        bool one_launch = st == 0 && Bc <= knob(KN_BOTTLENECK_MAX_PAIRS) && H == 64 && W == 64;
+#ifdef COTR_EXPERIMENTAL
+        one_launch = one_launch && !h->h2_pass;
+#endif
+        if (one_launch) {
           // the whole bottleneck - conv1, conv2, conv3, (downsample,) FrozenBN, identity, ReLU - in one launch (bottleneck.hip)
           const ConvW* cd = (b == 0) ? &h->convs[ci++] : nullptr;
           KCHK(h, launch_bottleneck(x, y, Bc, c1.cin, c1.w, h->l1_fused[b].w2p, h->l1_fused[b].w3p, h->l1_fused[b].wdp, c1.scale,
@@ -800,6 +873,11 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       prof_mark(h, names[st], s);
       if (feat_out && st + 1 == upto) {  // cotr_backbone: [Bc, H, 2W, 4*planes] of this stage, NHWC over the pair
         const size_t per_pair = (size_t)H * 2 * W * kStages[st].planes * 4;
+#ifdef COTR_EXPERIMENTAL
+        if (h->h2_pass) {
+          KCHK(h, launch_unsplit_h2(x, feat_out + (size_t)b0 * per_pair, (size_t)Bc * per_pair, s), "unsplit_h2 (features)");
+        } else
+#endif
         HIPCHK(h, hipMemcpyAsync(feat_out + (size_t)b0 * per_pair, x, (size_t)Bc * per_pair * sizeof(float),
                                  hipMemcpyDeviceToDevice, s));
         break;
@@ -810,6 +888,9 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     const int M = Bc * TOK;
     int r;
     if ((r = linear(h, x, nullptr, 0, 1, 0, h->ip_w, h->ip_b, nullptr, 0, 1.f, 0, t_src, M, D, CFEAT, s))) return r;
+#ifdef COTR_EXPERIMENTAL
+    h->h2_pass = false;   // the transformer reads fp32
+#endif
     if ((r = tap_save(h, "src", t_src, (size_t)M * D, s))) return r;
     prof_mark(h, "input_proj", s);
     // ---- encoder (transformer.py:143-159, post-norm) ----------------------------------------
@@ -1413,11 +1494,26 @@ int cotr_bench_conv(const float* x, const float* w, const float* scale, const fl
 }
 
 // explicit-config variants of the op entry points (tests check every config against torch)
+#ifdef COTR_EXPERIMENTAL
+static thread_local int g_op_h2_flags = 0;   // GemmParams::h2_flags of the cotr_op_*_cfg calls of this thread (configurations 46 / 47)
+int cotr_op_set_h2_flags(int flags) {
+  if (flags < 0 || flags > 3) return COTR_ERR_ARG;
+  g_op_h2_flags = flags;
+  return COTR_OK;
+}
+int cotr_op_unsplit_h2(const void* x, float* y, size_t n, cotr_stream stream) {
+  if (!x || !y) return COTR_ERR_ARG;
+  return op_ret(launch_unsplit_h2(x, y, n, static_cast<hipStream_t>(stream)));
+}
+#endif
 int cotr_op_linear_cfg(const float* x, const float* w, const float* bias, const float* residual, int relu, float* y,
                        int M, int N, int K, int cfg, cotr_stream stream) {
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K; p.W = w; p.C = y; p.ldc = N;
   p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
+#ifdef COTR_EXPERIMENTAL
+  p.h2_flags = g_op_h2_flags;
+#endif
   return op_ret(launch_gemm_cfg(GEMM_DENSE, cfg, p, static_cast<hipStream_t>(stream)));
 }
 
@@ -1433,6 +1529,9 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
   p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
   p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout;
   p.scale = scale; p.bias = bias; p.residual = residual; p.ldr = Cout; p.relu = relu;
+#ifdef COTR_EXPERIMENTAL
+  p.h2_flags = g_op_h2_flags;
+#endif
   return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
 }
 

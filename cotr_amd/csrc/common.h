@@ -76,6 +76,7 @@ enum KnobId {
   KN_COOP_TAIL_SPIN,             // polls before a member leaves its share to the last arriver
   KN_GEMM_LN_MIN_ROWS,           // 256-wide projection + LayerNorm as one launch from this many rows (measured neutral; off)
   KN_L2_WARM,                    // ln_reduce launches also touch the next launch's weights (weights-ahead L2 warmer; bit 0 FFN weights, bit 1 attention weights; measured slower)
+  KN_SPLIT_F16,                  // RESEARCH (experimental/gemm_h2.h): 1 = the backbone + input_proj of a pass run on packed split-f16 activations / weights (three f16 MFMAs per fp32 product), 2 = also the transformer's projections and FFN GEMMs of the unfused (many-row) path
 #endif
   KN_COUNT
 };
@@ -154,6 +155,9 @@ struct GemmParams {
   const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
   int xcd_msplit;      // workgroup -> tile mapping, see gemm_tile_coords
   int ws_flags;        // wave-specialised large tiles (gemm_big.hip): priorities, see gemm_set_ws_flags
+#ifdef COTR_EXPERIMENTAL
+  int h2_flags;        // configurations 46 / 47 (packed split-f16 operands): bit 0 = C is written packed, bit 1 = the residual is packed
+#endif
   // launch-time divisors (gemm_fill_divs, called by every launch helper): column tiles of the launch's tile shape; the
   // convolution's pixel decomposition (Hout * 2*Wout, 2*Wout, Wout), channel tiles per tap (Cin / 32), ksize; the x + pos
   // prologue's row period and column period; the row period of a table residual

@@ -20,6 +20,10 @@ __device__ __forceinline__ unsigned int h2_pack(const float a) {
   return (unsigned int)__half_as_ushort(h) | ((unsigned int)__half_as_ushort(l) << 16);
 }
 
+__device__ __forceinline__ float h2_unpack(const unsigned int d) {
+  return fmaf(__half2float(__ushort_as_half((unsigned short)(d >> 16))), 0x1p-11f, __half2float(__ushort_as_half((unsigned short)(d & 0xFFFFu))));
+}
+
 // 8 packed dwords (k = 0..7 of one row) -> the 8 hi halves / the 8 lo halves, each as an MFMA operand
 __device__ __forceinline__ void h2_unzip(const u32x4 d0, const u32x4 d1, f16x8& hi, f16x8& lo) {
   u32x4 h, l;

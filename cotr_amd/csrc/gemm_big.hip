@@ -36,7 +36,7 @@
 template <int TN, int MODE, int NST, int X = 0>
 __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid) {
   constexpr bool DIRECT = X == 1;
-  constexpr bool H2 = X == 2;
+  [[maybe_unused]] constexpr bool H2 = X == 2;
   constexpr int BM = 128, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage
   constexpr int QW = BN / 32;             // W-tile DMA instructions per wavefront
@@ -266,9 +266,18 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
           float x = v[e];
           x = p.scale ? fmaf(x, sc[e], bi[e]) : x + bi[e];
           x *= cs[e];
+#ifdef COTR_EXPERIMENTAL
+          if constexpr (H2) {
+            const float rv = res[a][it][e];   // (a scalar copy: __builtin_bit_cast on the vector element reads element 0 with this hipcc)
+            if (p.residual) x += (p.h2_flags & 2) ? h2_unpack(__float_as_uint(rv)) : rv;
+          } else
+#endif
           if (p.residual) x += res[a][it][e];
           if (p.relu) x = (x < 0.f) ? 0.f : x;
           v[e] = x;
+#ifdef COTR_EXPERIMENTAL
+          if constexpr (H2) if (p.h2_flags & 1) v[e] = __uint_as_float(h2_pack(x));
+#endif
         }
         *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + ncol) = v;
       }

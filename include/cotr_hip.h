@@ -411,6 +411,10 @@ int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const f
  * 16-byte aligned, in place allowed.  cotr_op_linear / cotr_op_conv with the forced configurations 46 / 47 take BOTH operands (activations
  * and weights) in this form and return fp32; |x| must stay below 65504.  Not bit-identical to the fp32-MFMA path. */
 int cotr_op_split_h2(const float* x, void* y, size_t n, cotr_stream stream);
+int cotr_op_unsplit_h2(const void* x, float* y, size_t n, cotr_stream stream);   /* the inverse: exact */
+/* flags of the following cotr_op_linear_cfg / cotr_op_conv_cfg calls of this thread on configurations 46 / 47: bit 0 = y is written packed,
+ * bit 1 = the residual is packed (what a chain of such launches passes from one to the next); 0 restores fp32 residual / output */
+int cotr_op_set_h2_flags(int flags);
 #endif
 
 #ifdef __cplusplus

@@ -414,3 +414,60 @@ def test_split_f16_large_tile_is_as_close_to_fp64_as_the_fp32_path(M, N, K):
         got = torch.empty_like(want)
         assert lib.cotr_op_conv_cfg(G.P(xsp), G.P(wsp), G.P(sc), G.P(bi), G.P(rs), 1, G.P(got), B, H, H, cin, cout, 3, 1, cfg, G.sptr()) == 0
         assert float((got - want).abs().max()) < 2e-5, (cfg, float((got - want).abs().max()))
+
+
+@pytest.mark.parametrize('level', [1, 2])
+@pytest.mark.parametrize('name', list(make_golden.CASES))
+def test_split_f16_pass_on_the_goldens_of_the_reference(name, level, golden_dir):
+    """RESEARCH knob split_f16 (1: backbone + input_proj on packed split-f16 tensors, 2: also the transformer's large GEMMs) against ALL model goldens of the
+    reference, the ill-conditioned ones included: the same bars as the fp32-MFMA path (1e-3 px; 3x the reference's own fp32-vs-fp64
+    gap on the peaky cases), AND no further from the fp64 truth than 1.5x the fp32-MFMA path of this library on the same inputs
+    (+ 2e-5 px of slack for errors that are both tiny).  The error each path makes is printed."""
+    wseed, gain = make_golden.CASES[name][:2]
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    sd, img, qs = make_golden.case_inputs(name)
+    m = hip_model(wseed, gain)
+    f64 = torch.from_numpy(g['pred_f64'])
+    base = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    with G.model_knobs(m, split_f16=level):
+        out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    assert not torch.isnan(out).any() and not torch.equal(out, base), 'the knob did not change the path'
+    ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), f64)
+    e_base, e_h2 = cotr_oracle.px_err(base, f64), cotr_oracle.px_err(out, f64)
+    print(f'{name} level {level}: px error vs fp64  fp32-MFMA path {e_base:.3g}   split-f16 {e_h2:.3g}   (reference fp32 vs fp64 {ref_gap:.3g})')
+    assert e_h2 < max(PX_BAR, 3 * ref_gap), (e_h2, ref_gap)
+    assert e_h2 <= 1.5 * e_base + 2e-5, (e_h2, e_base)
+
+
+def test_split_f16_stage_taps_against_oracle():
+    """the stage taps of a split-f16 pass (unpacked on the way out) against the CPU oracle, with the bars of test_stage_taps_against_oracle"""
+    sd, img, qs = make_golden.case_inputs('ragged_b2_q257')
+    taps = {}
+    ref = cotr_oracle.cotr_forward(sd, img, qs, taps=taps)
+    m = build_model(cotr_amd.default_args()).cuda().eval()      # a model of its own: the tap stores size its workspace
+    m.load_state_dict(synth_state_dict(0))
+    m.set_debug_taps(True)
+    checks = {
+        'pool': G.nchw_to_sbs(taps['pool']),
+        'layer1': G.nchw_to_sbs(taps['layer1.2']), 'layer2': G.nchw_to_sbs(taps['layer2.3']),
+        'layer3': G.nchw_to_sbs(taps['layer3.5']), 'src': G.seq_to_rows(taps['src']), 'memory': G.seq_to_rows(taps['enc.5']),
+    }
+    errs = {}
+    for level in (0, 1, 2):
+        with G.model_knobs(m, split_f16=level):
+            out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+            errs[level] = {k: G.rel_err(m.debug_tap(k).cpu().view(v.shape), v) for k, v in checks.items()}
+        errs[level]['px'] = cotr_oracle.px_err(out, ref)
+        print(level, {k: f'{v:.3g}' for k, v in errs[level].items()})
+        assert all(e < 5e-5 for k, e in errs[level].items() if k != 'px'), errs[level]
+        assert errs[level]['px'] < PX_BAR
+    m.set_debug_taps(False)
+    # the backbone features through cotr_backbone_upto (unpacked copy-out)
+    lib = _lib.load_library()
+    img_d = img.cuda().contiguous()
+    with G.model_knobs(m, split_f16=1):
+        for stage, name in ((1, 'layer1'), (3, 'layer3')):
+            out = torch.empty(checks[name].shape, device='cuda')
+            _lib.check(lib.cotr_backbone_upto(m._handle, img_d.data_ptr(), img_d.shape[0], stage, out.data_ptr(), _lib.current_stream_ptr()),
+                       m._handle, 'cotr_backbone_upto')
+            assert G.rel_err(out.cpu(), checks[name]) < 5e-5, name
