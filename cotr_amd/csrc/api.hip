@@ -137,6 +137,10 @@ struct cotr_ctx {
   size_t wbuf_h2_floats = 0;
   bool wbuf_h2_valid = false;
   bool h2_pass = false;
+  // level 2: linear() packs its fp32 input into h2_scr first; one-shot requests of the caller for the NEXT linear(): its input is packed
+  // already / its output is wanted packed (the hidden activations of an FFN block never exist in fp32)
+  Arena h2_scr;
+  bool h2_in_packed = false, h2_out_packed = false;
 #endif
   // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
   struct FusedBlock { const float *w2p = nullptr, *w3p = nullptr, *wdp = nullptr; };
@@ -309,6 +313,7 @@ GemmParams base_params() {
 #ifdef COTR_EXPERIMENTAL
 // RESEARCH, knob split_f16: the packed image of a weight tensor of wbuf; the large-tile configuration for packed operands
 const float* h2_weight(const cotr_ctx* h, const float* w) { return h->wbuf_h2 + (w - h->wbuf); }
+constexpr int H2_MIN_ROWS = 8192;   // level 2 takes a projection from this many rows (the regime where the large tiles are the tuned pick anyway)
 int h2_config(const GemmParams& p) { return (p.N % 128 == 0 && (long)p.M * p.N >= (long)256 * 128 * 128) ? 46 : 47; }
 int h2_prepare_weights(cotr_ctx* h, hipStream_t s) {
   if (h->wbuf_h2 && h->wbuf_h2_valid) return COTR_OK;
@@ -338,13 +343,29 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
   p.bias = bias; p.residual = residual; p.ldr = N; p.res_row_mod = res_row_mod; p.relu = relu;
   p.colscale = colscale; p.colscale_n = colscale_n;
 #ifdef COTR_EXPERIMENTAL
-  if (h->h2_pass) {   // x is packed; y is fp32 (the consumers of a projection - LayerNorm, attention, the residual stream - read fp32)
-    if (x2 != nullptr) { h->err = "split_f16: the x + pos prologue is not available on packed operands"; return COTR_ERR_ARG; }
-    p.W = h2_weight(h, w);
-    const int cfg = h2_config(p);
-    KCHK(h, launch_gemm_cfg(GEMM_DENSE, cfg, p, s), "linear (split f16)");
-    if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, cfg); prof_mark(h, nm, s, 2); }
-    return COTR_OK;
+  {  // RESEARCH, knob split_f16 (experimental/gemm_h2.h)
+    const bool in_packed = h->h2_pass || h->h2_in_packed, out_packed = h->h2_out_packed;
+    h->h2_in_packed = h->h2_out_packed = false;
+    const bool simple_x2 = x2 == nullptr || (x2_row_mod == 0 && a2_period == 1 && a2_width == 1);
+    const bool level2 = knob(KN_SPLIT_F16) >= 2 && M >= H2_MIN_ROWS && N % 64 == 0 && K % 32 == 0 && simple_x2;
+    if (in_packed || level2) {
+      if (in_packed && x2 != nullptr) { h->err = "split_f16: the x + pos prologue is not available on packed operands"; return COTR_ERR_ARG; }
+      if (int r = h2_prepare_weights(h, s)) return r;
+      if (!in_packed) {   // x (+ x2) -> packed split-f16 copy
+        if (int r = ensure(h, h->h2_scr, (size_t)M * K)) return r;
+        KCHK(h, launch_split_h2(x, h->h2_scr.ptr, (size_t)M * K, s, x2), "split_h2");
+        prof_mark(h, "split_h2", s, 2);
+        p.A = h->h2_scr.ptr;
+        p.A2 = nullptr;
+      }
+      p.W = h2_weight(h, w);
+      p.h2_flags = out_packed ? 1 : 0;
+      const int cfg = h2_config(p);
+      KCHK(h, launch_gemm_cfg(GEMM_DENSE, cfg, p, s), "linear (split f16)");
+      if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, cfg); prof_mark(h, nm, s, 2); }
+      return COTR_OK;
+    }
+    if (out_packed) { h->err = "split_f16: packed output requested from an fp32 launch"; return COTR_ERR_ARG; }
   }
 #endif
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
@@ -524,6 +545,7 @@ void cotr_destroy(cotr_handle h) {
 #ifdef COTR_EXPERIMENTAL
   if (h->tail_state) (void)hipFree(h->tail_state);
   if (h->wbuf_h2) (void)hipFree(h->wbuf_h2);
+  if (h->h2_scr.ptr && !h->h2_scr.external) (void)hipFree(h->h2_scr.ptr);
 #endif
   for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr})
     if (a->ptr && !a->external) (void)hipFree(a->ptr);

@@ -39,6 +39,6 @@ void set_ln_reduce_warm(const float* p0, size_t bytes0, const float* p1, size_t 
 int launch_gemm_pp(int mode, int variant, const GemmParams& p, hipStream_t s);
 int gemm_pp_workgroups();
 // gemm_h2.hip / gemm_h2.h (research): fp32 -> packed split-f16 dwords, the operand format of GEMM configurations 46 / 47
-int launch_split_h2(const float* x, void* y, size_t n, hipStream_t s);
+int launch_split_h2(const float* x, void* y, size_t n, hipStream_t s, const float* x2 = nullptr);   // y = pack(x [+ x2])
 int launch_unsplit_h2(const void* x, float* y, size_t n, hipStream_t s);
 //   // persistent workgroups per launch on the current device

@@ -3,9 +3,10 @@
 #include "gemm_h2.h"
 
 namespace {
-__global__ __launch_bounds__(256) void split_h2_kernel(const float* __restrict__ x, unsigned int* __restrict__ y, const size_t n4) {
+__global__ __launch_bounds__(256) void split_h2_kernel(const float* x, const float* __restrict__ x2, unsigned int* y, const size_t n4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    if (x2 != nullptr) v += reinterpret_cast<const f32x4*>(x2)[i];
     u32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = h2_pack(v[e]);
@@ -34,11 +35,11 @@ int launch_unsplit_h2(const void* x, float* y, size_t n, hipStream_t s) {
 }
 
 // n floats (a multiple of 4, 16-byte aligned pointers; x == y allowed)
-int launch_split_h2(const float* x, void* y, size_t n, hipStream_t s) {
+int launch_split_h2(const float* x, void* y, size_t n, hipStream_t s, const float* x2) {
   if (n == 0) return 0;
-  if (n % 4 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return -1;
+  if (n % 4 != 0 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)x2 & 15)) return -1;
   const size_t n4 = n / 4;
   const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-  hipLaunchKernelGGL(split_h2_kernel, dim3(blocks), dim3(256), 0, s, x, static_cast<unsigned int*>(y), n4);
+  hipLaunchKernelGGL(split_h2_kernel, dim3(blocks), dim3(256), 0, s, x, x2, static_cast<unsigned int*>(y), n4);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -1,5 +1,5 @@
 """In-situ per-launch HIP-event timing of one forward (no rocprof overhead). GPU box.
-    python tools/kernel_times.py [B] [Q]"""
+    python tools/kernel_times.py [B] [Q] [KNOB=INT ...]"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 m = build_model(cotr_amd.default_args()).cuda().eval()
 m.load_state_dict(synth_state_dict(0))
+for kv in sys.argv[3:]:
+    m.set_knob(kv.split('=')[0], int(kv.split('=')[1]))
 img, qs = synth_inputs(B, Q, seed=1)
 img, qs = img.cuda(), qs.cuda()
 for _ in range(30):

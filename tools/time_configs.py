@@ -1,5 +1,5 @@
 """Forward time at the shapes BASELINE.json's configs name (and the engine's), HIP events around n calls. GPU box.
-    python tools/time_configs.py"""
+    python tools/time_configs.py [KNOB=INT ...]      (knobs of the model's handle, e.g. split_f16=1 with COTR_HIP_EXPERIMENTAL=1)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,10 @@ from cotr_amd.utils.synth import synth_state_dict, synth_inputs
 
 m = build_model(cotr_amd.default_args()).cuda().eval()
 m.load_state_dict(synth_state_dict(0))
+for kv in sys.argv[1:]:
+    m.set_knob(kv.split('=')[0], int(kv.split('=')[1]))
+if sys.argv[1:]:
+    print('knobs:', ' '.join(sys.argv[1:]))
 for tag, B, Q, n in (('configs[1] primary', 1, 1000, 200), ('engine batch (sparse_engine.py:47-56)', 32, 1, 30),
                      ('dense pass, one pair (inference_helper.py:116-127)', 1, 131072, 10),
                      ('dense pass, 2x2 patch pairs', 4, 131072, 5), ('32 pairs x 1000', 32, 1000, 10),
