@@ -250,6 +250,53 @@ def other_regimes(sd, dev):
     return out
 
 
+# ---- research: split-f16 MFMAs (never the headline) ------------------------------------------------------------------
+def research_split_f16_child():
+    """Child process (COTR_HIP_EXPERIMENTAL=1: libcotr_hip_exp.so): the batched shapes with the RESEARCH knob split_f16=2 (fp32 products
+    from three f16 MFMAs on packed split-f16 tensors, csrc/experimental/gemm_h2.h) next to the same library's fp32-MFMA path, and how far
+    apart the two results are.  One JSON object on stdout."""
+    import cotr_amd
+    from cotr_amd.models import build_model
+    from cotr_amd.utils.synth import synth_state_dict, synth_inputs
+    dev = torch.device('cuda', 0)
+    m = build_model(cotr_amd.default_args()).to(dev).eval()
+    m.load_state_dict(synth_state_dict(0))
+    out = {}
+    for tag, b, q, n in (('batch_32_pairs_x_1000_queries', 32, 1000, 5), ('engine_batch_32_pairs_x_1_query', 32, 1, 10)):
+        img, qs = synth_inputs(b, q, seed=2)
+        img, qs = img.to(dev), qs.to(dev)
+        res = {}
+        for level in (0, 2):
+            m.set_knob('split_f16', level)
+            res[level] = m(img, qs)['pred_corrs'].clone()
+            dt = time_calls(lambda: m(img, qs), n)
+            key = 'fp32_mfma' if level == 0 else 'split_f16'
+            out.setdefault(tag, {})[key] = {'ms_per_call': dt * 1e3, 'query_corr_per_s': b * q / dt, 'pairs_per_s': b / dt,
+                                            'fp32_equivalent_tflops': flop(b, q) / dt / 1e12}
+        d = (res[0] - res[2]).abs() * torch.tensor([512.0, 256.0], device=dev)
+        out[tag]['max_px_between_the_two_paths'] = float(d.max())
+        out[tag]['speedup'] = out[tag]['fp32_mfma']['ms_per_call'] / out[tag]['split_f16']['ms_per_call']
+    print(json.dumps(out), flush=True)
+
+
+def research_split_f16():
+    """also_measured['RESEARCH_split_f16_opt_in_not_the_product_path']: measured by a child on the experimental library; the headline, the
+    roofline object and batched_frac stay on v_mfma_f32_32x32x2_f32 (dtype f32)."""
+    note = ('RESEARCH, opt-in (knob split_f16 of libcotr_hip_exp.so, off by default, never on the product path): every fp32 product of the '
+            'large GEMMs / convolutions as three v_mfma_f32_32x32x16_f16 on packed split-f16 tensors (hi = f16(a), lo = f16((a - hi) * 2^11)); '
+            'as close to the fp64 truth as the fp32-MFMA path on all 9 goldens of the reference (tests/test_experimental_gpu.py), not '
+            'bit-identical to it, range-limited to |x| < 65504; "fp32_equivalent_tflops" counts the fp32 work and is NOT a fraction of any roofline')
+    try:
+        env = dict(os.environ, COTR_HIP_EXPERIMENTAL='1')
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), '--research-child'], env=env, capture_output=True, text=True, timeout=240)
+        lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+        if p.returncode != 0 or not lines:
+            return {'note': note, 'error': (p.stderr or p.stdout)[-300:]}
+        return dict(json.loads(lines[-1]), note=note)
+    except Exception as e:   # the research leg must never take the bench line down
+        return {'note': note, 'error': repr(e)[:300]}
+
+
 # ---- L2 <-> fabric traffic ------------------------------------------------------------------------------------------
 def traffic_child(n_forward):
     """Child process of measure_traffic (runs under rocprofv3 --pmc): a few warm-up forwards, then n_forward forwards."""
@@ -546,6 +593,7 @@ def main():
                     help='roofline.traffic: measured by a rocprofv3 --pmc child of this run (auto: when available, N == 1, extras '
                          'on), or the committed profile')
     ap.add_argument('--traffic-child', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--research-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl', help='torch.distributed backend (nccl = RCCL; gloo with --dry-run)')
     ap.add_argument('--dry-run', action='store_true',
                     help='CPU plumbing check (tests): stand-in model, same launch / barrier / timing / gather / JSON code; never a measurement')
@@ -556,6 +604,8 @@ def main():
     args = ap.parse_args()
     if args.traffic_child:
         return traffic_child(args.traffic_child)
+    if args.research_child:
+        return research_split_f16_child()
     if args.steps is None:
         args.steps = {'headline': 200, 'batch256': 5, 'dense': 10, 'train': 10}[args.workload]
     if args.warmup is None:
@@ -740,6 +790,7 @@ def main():
             line['also_measured'] = other_regimes(synth_state_dict(0), dev)
             roof['batched_frac'] = line['also_measured']['batch_32_pairs_x_1000_queries']['frac_of_fp32_mfma_peak']
             roof['batched_frac_note'] = 'same path at 32 pairs x 1000 queries per call (throughput regime)'
+            line['also_measured']['RESEARCH_split_f16_opt_in_not_the_product_path'] = research_split_f16()
         if world == 1 and not args.no_cpu_baseline and not batch256 and not dense:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

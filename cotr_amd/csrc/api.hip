@@ -99,6 +99,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"gemm_ln_min_rows", 1 << 30, 0, INT_MAX},
     {"l2_warm", 0, 0, 3},
     {"split_f16", 0, 0, 2},
+    {"split_f16_min_pairs", 8, 1, INT_MAX},
 #endif
 };
 bool knob_value_ok(int id, int v) {
@@ -839,7 +840,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     if (int r = tap_save(h, "stem", b_stem, n_stem * Bc, s)) return r;
     if (int r = tap_save(h, "pool", b_pool, n_pool * Bc, s)) return r;
 #ifdef COTR_EXPERIMENTAL
-    if (knob(KN_SPLIT_F16)) {   // RESEARCH: from here to input_proj every activation is a packed split-f16 tensor (gemm_h2.h)
+    if (knob(KN_SPLIT_F16) && Bc >= knob(KN_SPLIT_F16_MIN_PAIRS)) {   // RESEARCH: from here to input_proj every activation is a packed split-f16 tensor (gemm_h2.h)
       if (int r = h2_prepare_weights(h, s)) return r;
       KCHK(h, launch_split_h2(b_pool, b_pool, n_pool * Bc, s), "split_h2 (pool)");
       prof_mark(h, "split_h2 pool", s, 2);

@@ -77,6 +77,7 @@ enum KnobId {
   KN_GEMM_LN_MIN_ROWS,           // 256-wide projection + LayerNorm as one launch from this many rows (measured neutral; off)
   KN_L2_WARM,                    // ln_reduce launches also touch the next launch's weights (weights-ahead L2 warmer; bit 0 FFN weights, bit 1 attention weights; measured slower)
   KN_SPLIT_F16,                  // RESEARCH (experimental/gemm_h2.h): 1 = the backbone + input_proj of a pass run on packed split-f16 activations / weights (three f16 MFMAs per fp32 product), 2 = also the transformer's projections and FFN GEMMs of the unfused (many-row) path
+  KN_SPLIT_F16_MIN_PAIRS,        // ... the backbone pass only from this many pairs per pass (below, the tuned small-tile fp32 kernels win: 8)
 #endif
   KN_COUNT
 };

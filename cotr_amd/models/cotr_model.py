@@ -220,7 +220,8 @@ class COTR(nn.Module):
         workspace only grows; a cached encode is carried over into the new one (stream-ordered device copy; the old tensor
         goes back to torch's pool, which is stream-ordered too)."""
         b, q = max(b, self._ws_shape[0]), max(q, self._ws_shape[1])
-        if (b, q) == self._ws_shape:
+        stale = self.__dict__.get('_ws_stale', False)      # a knob changed: the library's carving of the workspace is re-done
+        if (b, q) == self._ws_shape and not stale:
             return
         need = ctypes.c_size_t()
         _lib.check(lib.cotr_scratch_bytes(self._handle, b, max(q, 1), ctypes.byref(need)), self._handle, 'cotr_scratch_bytes')
@@ -242,6 +243,14 @@ class COTR(nn.Module):
             self._ws = ws
             if not keep:
                 self._encoded_batch = 0
+        elif stale and not self.__dict__.get('_ws_pins'):
+            # same buffer, new knobs: the three regions grow in place and never shrink, so regions carved under the old knobs plus one
+            # that is larger under the new ones can exceed what cotr_scratch_bytes promises for either - start the carving afresh
+            off = (-self._ws.data_ptr()) % 256
+            _lib.check(lib.cotr_set_workspace(self._handle, ctypes.c_void_p(self._ws.data_ptr() + off), self._ws.numel() - 256, 0,
+                                              _lib.current_stream_ptr()), self._handle, 'cotr_set_workspace')
+            self._encoded_batch = 0
+        self._ws_stale = False
         self._ws_shape = (b, q)
 
     def _release(self):
@@ -377,7 +386,7 @@ class COTR(nn.Module):
         else:
             _lib.load_library()
         self._knobs[name] = int(value)
-        self._ws_shape = (0, 0)
+        self._ws_stale = True
 
     def knobs(self):
         """{name: (current, default)} of this model's handle (the shipped defaults + set_knob calls before the handle exists)."""
@@ -389,7 +398,7 @@ class COTR(nn.Module):
         if self._handle is not None:
             _lib.reset_knobs(self._handle)
         self._knobs = {}
-        self._ws_shape = (0, 0)
+        self._ws_stale = True
 
     # ------------------------------------------------------------------ test / profiling hooks
     def debug_tap(self, name):

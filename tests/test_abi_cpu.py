@@ -116,7 +116,7 @@ def test_knob_registry_round_trip_without_a_gpu():
     k0 = _lib.knobs()
     assert len(k0) == 18 and all(cur == dflt for cur, dflt in k0.values())
     assert k0['attention_fusion_max_rows'] == (1024, 1024) and k0['encode_chunk'] == (64, 64)
-    for exp_only in ('head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail', 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm'):
+    for exp_only in ('head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail', 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs'):
         assert exp_only not in k0
     try:
         _lib.set_knob('conv1x1_dense', 0)
@@ -151,9 +151,9 @@ def test_experimental_library_has_the_dead_ends_and_their_knobs():
     lib.cotr_knob_name.restype = ctypes.c_char_p
     names = [lib.cotr_knob_name(i).decode() for i in range(lib.cotr_knob_count())]
     assert names[:18] == list(_lib.knobs()) and names[18:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
-                                                                 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm']
+                                                                 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs']
     for n, want in (('head_fusion_max_rows', 0), ('ffn_preln', 0), ('ffn_tail', 0), ('coop_tail', 0), ('gemm_ln_min_rows', 1 << 30),
-                    ('l2_warm', 0)):
+                    ('l2_warm', 0), ('split_f16', 0), ('split_f16_min_pairs', 8)):
         cur, dflt = ctypes.c_int(), ctypes.c_int()
         assert lib.cotr_get_knob(None, n.encode(), ctypes.byref(cur), ctypes.byref(dflt)) == 0 and cur.value == dflt.value == want
 

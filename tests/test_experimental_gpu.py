@@ -429,7 +429,7 @@ def test_split_f16_pass_on_the_goldens_of_the_reference(name, level, golden_dir)
     m = hip_model(wseed, gain)
     f64 = torch.from_numpy(g['pred_f64'])
     base = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
-    with G.model_knobs(m, split_f16=level):
+    with G.model_knobs(m, split_f16=level, split_f16_min_pairs=1):
         out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
     assert not torch.isnan(out).any() and not torch.equal(out, base), 'the knob did not change the path'
     ref_gap = cotr_oracle.px_err(torch.from_numpy(g['pred_f32']), f64)
@@ -454,7 +454,7 @@ def test_split_f16_stage_taps_against_oracle():
     }
     errs = {}
     for level in (0, 1, 2):
-        with G.model_knobs(m, split_f16=level):
+        with G.model_knobs(m, split_f16=level, split_f16_min_pairs=1):
             out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
             errs[level] = {k: G.rel_err(m.debug_tap(k).cpu().view(v.shape), v) for k, v in checks.items()}
         errs[level]['px'] = cotr_oracle.px_err(out, ref)
@@ -465,7 +465,7 @@ def test_split_f16_stage_taps_against_oracle():
     # the backbone features through cotr_backbone_upto (unpacked copy-out)
     lib = _lib.load_library()
     img_d = img.cuda().contiguous()
-    with G.model_knobs(m, split_f16=1):
+    with G.model_knobs(m, split_f16=1, split_f16_min_pairs=1):
         for stage, name in ((1, 'layer1'), (3, 'layer3')):
             out = torch.empty(checks[name].shape, device='cuda')
             _lib.check(lib.cotr_backbone_upto(m._handle, img_d.data_ptr(), img_d.shape[0], stage, out.data_ptr(), _lib.current_stream_ptr()),

@@ -121,6 +121,11 @@ def main():
     q = (g.standard_normal((a.rows, 32)) * 6).astype(np.float32)
     k = (g.standard_normal((a.cols, 32)) * 6).astype(np.float32)
     report('attention logits (peaky: gain 32^2)', q, k)
+    # a tensor whose WHOLE scale is tiny: below f16's normal range (6.1e-5) the hi term loses bits that the lo term cannot give back
+    A = np.maximum(g.standard_normal((a.rows, 256)), 0).astype(np.float32)
+    for sc in (1e-3, 1e-5, 1e-6):
+        B = (g.standard_normal((a.cols, 256)) / 16 * sc).astype(np.float32)
+        report(f'weights of scale {sc:g} (f16 subnormals below 6.1e-5)', A, B)
     # large activations: f16 overflows above 65504
     A = (np.maximum(g.standard_normal((a.rows, 256)), 0) * 1e5).astype(np.float32)
     B = (g.standard_normal((a.cols, 256)) / 16).astype(np.float32)
