@@ -315,7 +315,16 @@ GemmParams base_params() {
 // RESEARCH, knob split_f16: the packed image of a weight tensor of wbuf; the large-tile configuration for packed operands
 const float* h2_weight(const cotr_ctx* h, const float* w) { return h->wbuf_h2 + (w - h->wbuf); }
 constexpr int H2_MIN_ROWS = 8192;   // level 2 takes a projection from this many rows (the regime where the large tiles are the tuned pick anyway)
-int h2_config(const GemmParams& p) { return (p.N % 128 == 0 && (long)p.M * p.N >= (long)256 * 128 * 128) ? 46 : 47; }
+// (tools/bench_split_f16.py, profiles/r4_split_f16_gemm_configs.txt: the wave-specialised form wins where a CU gets ONE deep tile, the
+// 128 x 64 tile where K is short and N wide, the plain 128 x 128 tile elsewhere)
+int h2_config(const GemmParams& p) {
+  if (p.N % 128 != 0) return 47;
+  const long tiles = (long)((p.M + 127) / 128) * (p.N / 128);
+  if (tiles < 256) return 47;
+  if (p.K >= 1024 && tiles <= 320) return 48;
+  if (p.K <= 256 && p.N >= 768) return 47;
+  return 46;
+}
 int h2_prepare_weights(cotr_ctx* h, hipStream_t s) {
   if (h->wbuf_h2 && h->wbuf_h2_valid) return COTR_OK;
   if (h->wbuf_h2 && h->wbuf_h2_floats < h->wfloats) {
@@ -1523,6 +1532,11 @@ int cotr_op_set_h2_flags(int flags) {
   if (flags < 0 || flags > 3) return COTR_ERR_ARG;
   g_op_h2_flags = flags;
   return COTR_OK;
+}
+int cotr_op_attention_h2(const float* q, int ldq, int q_packed, const float* k, const float* v, int ldkv, float* o, int ldo, int out_packed,
+                         int nb, int nq, cotr_stream stream) {
+  if (!q || !k || !v || !o) return COTR_ERR_ARG;
+  return op_ret(launch_attention_h2(q, ldq, q_packed, k, v, ldkv, o, ldo, out_packed, nb, nq, static_cast<hipStream_t>(stream)));
 }
 int cotr_op_unsplit_h2(const void* x, float* y, size_t n, cotr_stream stream) {
   if (!x || !y) return COTR_ERR_ARG;

@@ -751,6 +751,8 @@ static const GemmCfg kCfgs[] = {
     {5, 0, 2, 1},   // 45 large tile 128x64 (27) with the LDS-free epilogue
     {5, 0, 2, 2},   // 46 large tile 128x128 on PACKED SPLIT-f16 operands (experimental/gemm_h2.h): 3 f16 MFMAs per fp32 product
     {5, 0, 2, 1},   // 47 the same, 128x64
+    {5, 0, 2, 2},   // 48 packed split-f16 operands on the wave-specialised 128x128 tile (4 loader + 4 MFMA wavefronts)
+    {5, 0, 2, 1},   // 49 the same, 128x64
 #endif
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -874,6 +876,8 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 45: return launch_gemm_big(MODE, 7, p, s);
     case 46: return launch_gemm_big(MODE, 8, p, s);
     case 47: return launch_gemm_big(MODE, 9, p, s);
+    case 48: return launch_gemm_big(MODE, 10, p, s);
+    case 49: return launch_gemm_big(MODE, 11, p, s);
 #endif
     case 40: return launch_gemm_big(MODE, 4, p, s);
     case 41: return launch_gemm_big(MODE, 5, p, s);

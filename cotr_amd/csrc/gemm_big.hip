@@ -296,7 +296,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
 // Three LDS stages, ONE barrier per K step: the loaders wait (counted vmcnt) until tile kt has landed, everybody meets at the
 // barrier, the loaders request tile kt+2 into the stage whose readers passed this very barrier after finishing tile kt-1, the MFMA
 // wavefronts consume tile kt.  Same tile decomposition, same k order, same epilogue as gemm_big_body: bit-identical results.
-template <int TN, int MODE>
+template <int TN, int MODE, bool H2 = false>   // H2 (experimental, configurations 48 / 49): packed split-f16 operands, experimental/gemm_h2.h
 __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage (one 32-deep K tile)
@@ -402,6 +402,17 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#ifdef COTR_EXPERIMENTAL
+  f32x16 accx[H2 ? 2 : 1][H2 ? TN : 1];                 // H2: the cross terms, scaled by 2^11
+  if constexpr (H2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[a][b][r] = 0.f;
+  }
+#endif
   constexpr int C4 = 8 * TN;
   constexpr int RPI = 64 / C4;
   constexpr int NIT = 32 / RPI;
@@ -436,6 +447,13 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
       for (int b = 0; b < TN; ++b) r.b[b] = *reinterpret_cast<const f32x4*>(Ws + b * 32 * BK + ch);
       return r;
     };
+#ifdef COTR_EXPERIMENTAL
+    if constexpr (H2) {
+      h2_kstep<TN>(As, Ws, hh, sw, acc, accx);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      continue;
+    }
+#endif
     // the reads of slice j+1 are issued before the 8 TN MFMAs of slice j (hipcc on its own leaves a read two MFMAs of cover)
     Frag cur = load_frag(0);
 #pragma unroll
@@ -456,6 +474,16 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
   if (p.ws_flags & 1) __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_s_barrier();                         // every MFMA wavefront is done reading the operand stages
   asm volatile("" ::: "memory");
+#ifdef COTR_EXPERIMENTAL
+  if constexpr (H2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = fmaf(accx[a][b][r], 0x1p-11f, acc[a][b][r]);
+  }
+#endif
 
   float* Es = smem + wave * 32 * EP;
   f32x4 sc, bi, cs;
@@ -483,9 +511,18 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
           float x = v[e];
           x = p.scale ? fmaf(x, sc[e], bi[e]) : x + bi[e];
           x *= cs[e];
+#ifdef COTR_EXPERIMENTAL
+          if constexpr (H2) {
+            const float rv = res[a][it][e];
+            if (p.residual) x += (p.h2_flags & 2) ? h2_unpack(__float_as_uint(rv)) : rv;
+          } else
+#endif
           if (p.residual) x += res[a][it][e];
           if (p.relu) x = (x < 0.f) ? 0.f : x;
           v[e] = x;
+#ifdef COTR_EXPERIMENTAL
+          if constexpr (H2) if (p.h2_flags & 1) v[e] = __uint_as_float(h2_pack(x));
+#endif
         }
         *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + ncol) = v;
       }
@@ -493,14 +530,14 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
   }
 }
 
-template <int TN, int MODE>
+template <int TN, int MODE, bool H2 = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
-  gemm_ws_body<TN, MODE>(p, blockIdx.x);
+  gemm_ws_body<TN, MODE, H2>(p, blockIdx.x);
 }
 
 // knob KN_WS_FLAGS: bit 0 = s_setprio(1) around the MFMA wavefronts' loop, bit 1 = s_setprio(3) for the loaders
 
-template <int TN, int MODE>
+template <int TN, int MODE, bool H2 = false>
 static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr size_t smem = (size_t)4 * (BM + BN) * BK * sizeof(float);
@@ -513,7 +550,7 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   if (p.zeros == nullptr) return -2;
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<TN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<TN, MODE, H2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
       return -2;
     attr_set.set();
@@ -521,7 +558,7 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
   p.ws_flags = knob(KN_WS_FLAGS);
   const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_ws_kernel<TN, MODE>), dim3(tiles), dim3(512), smem, s, p);
+  hipLaunchKernelGGL((gemm_ws_kernel<TN, MODE, H2>), dim3(tiles), dim3(512), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -607,6 +644,8 @@ int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s) {
     case 7: return d ? launch_big_t<1, GEMM_DENSE, 2, 1>(p, s) : launch_big_t<1, GEMM_CONV, 2, 1>(p, s);
     case 8: return d ? launch_big_t<2, GEMM_DENSE, 2, 2>(p, s) : launch_big_t<2, GEMM_CONV, 2, 2>(p, s);   // packed split-f16 operands
     case 9: return d ? launch_big_t<1, GEMM_DENSE, 2, 2>(p, s) : launch_big_t<1, GEMM_CONV, 2, 2>(p, s);
+    case 10: return d ? launch_ws_t<2, GEMM_DENSE, true>(p, s) : launch_ws_t<2, GEMM_CONV, true>(p, s);   // packed split-f16, wave-specialised
+    case 11: return d ? launch_ws_t<1, GEMM_DENSE, true>(p, s) : launch_ws_t<1, GEMM_CONV, true>(p, s);
 #endif
     case 4: return d ? launch_ws_t<2, GEMM_DENSE>(p, s) : launch_ws_t<2, GEMM_CONV>(p, s);   // wave-specialised 128 x 128
     case 5: return d ? launch_ws_t<1, GEMM_DENSE>(p, s) : launch_ws_t<1, GEMM_CONV>(p, s);   // wave-specialised 128 x 64

@@ -387,7 +387,7 @@ def test_split_f16_large_tile_is_as_close_to_fp64_as_the_fp32_path(M, N, K):
     truth = x.double() @ w.double().t() + b.double() + r.double()
     scale = x.double().abs() @ w.double().abs().t() + b.double().abs() + r.double().abs()
     err = {}
-    for cfg, a_, w_ in ((26, x, w), (27, x, w), (46, xp, wp), (47, xp, wp)):
+    for cfg, a_, w_ in ((26, x, w), (27, x, w), (46, xp, wp), (47, xp, wp), (48, xp, wp), (49, xp, wp)):
         y = torch.full((M + 1, N), 7.0, device=d)
         assert lib.cotr_op_linear_cfg(G.P(a_), G.P(w_), G.P(b), G.P(r), 0, G.P(y), M, N, K, cfg, G.sptr()) == 0
         assert bool((y[M] == 7.0).all())
@@ -397,8 +397,7 @@ def test_split_f16_large_tile_is_as_close_to_fp64_as_the_fp32_path(M, N, K):
         assert lib.cotr_op_linear_cfg(G.P(a_), G.P(w_), G.P(b), G.P(r), 1, G.P(yr), M, N, K, cfg, G.sptr()) == 0
         assert torch.equal(yr, torch.relu(y[:M]))
     print(M, N, K, {k: (f'{v[0]:.3g}', f'{v[1]:.3g}') for k, v in err.items()})
-    assert err[46][0] <= 1.5 * err[26][0] and err[47][0] <= 1.5 * err[27][0], err
-    assert err[46][1] <= 4e-7 and err[47][1] <= 4e-7, err
+    assert all(err[c][0] <= 1.5 * err[26][0] and err[c][1] <= 4e-7 for c in (46, 47, 48, 49)), err
     # 3x3 convolution + FrozenBN + residual + ReLU on packed pixels / packed weights
     B, H, cin, cout = 3, 32, 64, 128
     xs = torch.relu(torch.randn(B, H, 2 * H, cin, generator=g)).to(d)
@@ -410,7 +409,7 @@ def test_split_f16_large_tile_is_as_close_to_fp64_as_the_fp32_path(M, N, K):
     assert lib.cotr_op_split_h2(G.P(ws), G.P(wsp), ws.numel(), G.sptr()) == 0
     want = torch.empty(B, H, 2 * H, cout, device=d)
     assert lib.cotr_op_conv_cfg(G.P(xs), G.P(ws), G.P(sc), G.P(bi), G.P(rs), 1, G.P(want), B, H, H, cin, cout, 3, 1, 27, G.sptr()) == 0
-    for cfg in (46, 47):
+    for cfg in (46, 47, 48, 49):
         got = torch.empty_like(want)
         assert lib.cotr_op_conv_cfg(G.P(xsp), G.P(wsp), G.P(sc), G.P(bi), G.P(rs), 1, G.P(got), B, H, H, cin, cout, 3, 1, cfg, G.sptr()) == 0
         assert float((got - want).abs().max()) < 2e-5, (cfg, float((got - want).abs().max()))
@@ -490,3 +489,60 @@ def test_split_f16_level2_at_many_rows_against_the_fp64_oracle():
     assert not torch.equal(outs[1], outs[0]) and not torch.equal(outs[2], outs[1]), 'the knob did not change the path'
     for level in (1, 2):
         assert err[level] < PX_BAR and err[level] <= 1.5 * err[0] + 2e-5, err
+
+
+@pytest.mark.parametrize('case', ['plain', 'gain6', 'gain64', 'gain256', 'constant', 'spike_late', 'spike_every_block', 'huge_negative'])
+def test_split_f16_attention_against_fp64(case):
+    """RESEARCH (experimental/attention_h2.hip): the resident-K/V attention kernel with both products on split-f16 MFMAs (P split in
+    registers), on the inputs of test_attention / test_attention_softmax_extremes (forced rescales, one-hot rows, equal scores, underflow):
+    against the fp64 softmax attention - no further from it than 1.5x the fp32 kernel (+ 2e-6 relative) - with fp32 and packed q, fp32
+    and packed output, ragged query tiles."""
+    lib = _lib.load_library()
+    nb, nq = 3, 333
+    g = _g(sum(map(ord, case)))
+    q = torch.randn(nb * nq, 256, generator=g) / math.sqrt(32)
+    k = torch.randn(nb * 512, 256, generator=g)
+    v = torch.randn(nb * 512, 256, generator=g)
+    if case == 'gain6':
+        q *= 6.0
+    elif case == 'gain64':
+        q *= 64.0
+    elif case == 'gain256':
+        q *= 256.0
+    elif case == 'constant':
+        k[:] = k[:1]
+    elif case == 'spike_late':
+        k[500::512] = 40.0 * q[:nb] / q[:nb].norm(dim=1, keepdim=True)
+    elif case == 'spike_every_block':
+        for blk in range(16):
+            k[blk * 32 + 5::512] *= (1.0 + blk)
+        q *= 8.0
+    elif case == 'huge_negative':
+        q *= 32.0
+        k[:, :] = -k.abs()
+    qh = q.double().view(nb, nq, 8, 32).permute(0, 2, 1, 3)
+    kh = k.double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    vh = v.double().reshape(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).permute(0, 2, 1, 3).reshape(nb * nq, 256)
+    d = G.dev()
+    qd, kv = q.to(d), torch.cat([k, v], 1).to(d)
+    qp, kvp = torch.empty_like(qd), torch.empty_like(kv)
+    assert lib.cotr_op_split_h2(G.P(qd), G.P(qp), qd.numel(), G.sptr()) == 0
+    assert lib.cotr_op_split_h2(G.P(kv), G.P(kvp), kv.numel(), G.sptr()) == 0
+    o32 = torch.full((nb * nq, 256), float('nan'), device=d)
+    assert lib.cotr_op_attention(G.P(qd), 256, G.P(kv), G.P(kv[:, 256:]), 512, G.P(o32), 256, nb, nq, G.sptr()) == 0
+    e32 = G.rel_err(o32, ref)
+    errs = {}
+    for q_packed in (0, 1):
+        for out_packed in (0, 1):
+            o = torch.full((nb * nq, 256), float('nan'), device=d)
+            assert lib.cotr_op_attention_h2(G.P(qp if q_packed else qd), 256, q_packed, G.P(kvp), G.P(kvp[:, 256:]), 512, G.P(o), 256,
+                                            out_packed, nb, nq, G.sptr()) == 0
+            if out_packed:
+                u = torch.empty_like(o)
+                assert lib.cotr_op_unsplit_h2(G.P(o), G.P(u), o.numel(), G.sptr()) == 0
+                o = u
+            assert torch.isfinite(o).all(), (case, q_packed, out_packed)
+            errs[(q_packed, out_packed)] = G.rel_err(o, ref)
+    print(case, f'fp32 kernel {e32:.3g}', {k_: f'{v_:.3g}' for k_, v_ in errs.items()})
+    assert all(e <= 1.5 * e32 + 2e-6 for e in errs.values()), (case, e32, errs)
