@@ -266,14 +266,14 @@ def research_split_f16_child():
         img, qs = synth_inputs(b, q, seed=2)
         img, qs = img.to(dev), qs.to(dev)
         res = {}
-        for level in (0, 2):
+        for level in (0, 3):
             m.set_knob('split_f16', level)
             res[level] = m(img, qs)['pred_corrs'].clone()
             dt = time_calls(lambda: m(img, qs), n)
             key = 'fp32_mfma' if level == 0 else 'split_f16'
             out.setdefault(tag, {})[key] = {'ms_per_call': dt * 1e3, 'query_corr_per_s': b * q / dt, 'pairs_per_s': b / dt,
                                             'fp32_equivalent_tflops': flop(b, q) / dt / 1e12}
-        d = (res[0] - res[2]).abs() * torch.tensor([512.0, 256.0], device=dev)
+        d = (res[0] - res[3]).abs() * torch.tensor([512.0, 256.0], device=dev)
         out[tag]['max_px_between_the_two_paths'] = float(d.max())
         out[tag]['speedup'] = out[tag]['fp32_mfma']['ms_per_call'] / out[tag]['split_f16']['ms_per_call']
     print(json.dumps(out), flush=True)

@@ -98,7 +98,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"coop_tail_spin", 4000, 0, INT_MAX},
     {"gemm_ln_min_rows", 1 << 30, 0, INT_MAX},
     {"l2_warm", 0, 0, 3},
-    {"split_f16", 0, 0, 2},
+    {"split_f16", 0, 0, 3},
     {"split_f16_min_pairs", 8, 1, INT_MAX},
 #endif
 };
@@ -142,6 +142,9 @@ struct cotr_ctx {
   // already / its output is wanted packed (the hidden activations of an FFN block never exist in fp32)
   Arena h2_scr;
   bool h2_in_packed = false, h2_out_packed = false;
+  // level 3 (split-f16 attention): a packed copy of the cached decoder K / V of the current encode, made by the first decode that wants it
+  Arena kv_h2;
+  unsigned long long enc_serial = 0, kv_h2_serial = 0;
 #endif
   // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
   struct FusedBlock { const float *w2p = nullptr, *w3p = nullptr, *wdp = nullptr; };
@@ -556,6 +559,7 @@ void cotr_destroy(cotr_handle h) {
   if (h->tail_state) (void)hipFree(h->tail_state);
   if (h->wbuf_h2) (void)hipFree(h->wbuf_h2);
   if (h->h2_scr.ptr && !h->h2_scr.external) (void)hipFree(h->h2_scr.ptr);
+  if (h->kv_h2.ptr && !h->kv_h2.external) (void)hipFree(h->kv_h2.ptr);
 #endif
   for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr})
     if (a->ptr && !a->external) (void)hipFree(a->ptr);
@@ -791,6 +795,9 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   const size_t KVLD = (size_t)L * 2 * D;
   h->enc_B = 0;
   h->taps.clear();
+#ifdef COTR_EXPERIMENTAL
+  ++h->enc_serial;
+#endif
   if (!feat_out) {
     int r = ensure(h, h->memkv, (size_t)B * TOK * (D + KVLD));
     if (r) return r;
@@ -932,6 +939,9 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       const EncW& e = h->enc[li];
       // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
       if (M >= knob(KN_POS_TABLE_MIN_ROWS)) {
+#ifdef COTR_EXPERIMENTAL
+        h->h2_out_packed = exp_h2_attention(M, n_part != 0 && M <= knob(KN_ATTENTION_FUSION_MAX_ROWS) && M <= knob(KN_FFN_FUSION_MAX_ROWS));   // level 3: q | k | v go to the split-f16 attention kernel as packed tensors
+#endif
         if ((r = linear(h, xin, nullptr, 0, 1, 0, e.in_w, e.in_b, h->tab_qkv + li * TOK * 3 * D, 0, QSCALE, D, t_qkv, M, 3 * D, D, s, 0, TOK)))
           return r;
       } else if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;

@@ -473,7 +473,7 @@ def test_split_f16_stage_taps_against_oracle():
 
 
 def test_split_f16_level2_at_many_rows_against_the_fp64_oracle():
-    """Level 2 only engages from 8192 rows (20 pairs x 512 tokens in the encoder, 20 x 450 query rows in the decoder): the transformer's
+    """(level 3 = level 2 + the split-f16 attention kernel in both stacks.)  Level 2 only engages from 8192 rows (20 pairs x 512 tokens in the encoder, 20 x 450 query rows in the decoder): the transformer's
     projections, FFN blocks (hidden activations only ever packed), the hoisted K/V projection and corr_embed on split-f16 GEMMs.  Against the
     CPU oracle in fp64 on the same inputs: inside the 1e-3 px bar and no further from the truth than 1.5x the fp32-MFMA path (+ 2e-5 px)."""
     sd = synth_state_dict(0)
@@ -481,13 +481,18 @@ def test_split_f16_level2_at_many_rows_against_the_fp64_oracle():
     truth = cotr_oracle.cotr_forward(sd, img, qs, dtype=torch.float64).float()
     m = hip_model()
     outs = {}
-    for level in (0, 1, 2):
+    for level in (0, 1, 2, 3):
         with G.model_knobs(m, split_f16=level):
             outs[level] = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
     err = {k: cotr_oracle.px_err(v, truth) for k, v in outs.items()}
     print('px error vs the fp64 oracle:', {k: f'{v:.3g}' for k, v in err.items()})
-    assert not torch.equal(outs[1], outs[0]) and not torch.equal(outs[2], outs[1]), 'the knob did not change the path'
-    for level in (1, 2):
+    assert all(not torch.equal(outs[i + 1], outs[i]) for i in range(3)), 'the knob did not change the path'
+    # encode once / decode in two calls (the cached K / V get their packed copy once per encode) = one forward
+    with G.model_knobs(m, split_f16=3):
+        m.encode(img.cuda())
+        first, second = m.decode(qs.cuda()).cpu(), m.decode(qs.flip(1).cuda()).flip(1).cpu()
+    assert torch.equal(first, outs[3]) and cotr_oracle.px_err(second, outs[3]) < SHAPE_NOISE_PX
+    for level in (1, 2, 3):
         assert err[level] < PX_BAR and err[level] <= 1.5 * err[0] + 2e-5, err
 
 
