@@ -252,7 +252,7 @@ def other_regimes(sd, dev):
 
 # ---- research: split-f16 MFMAs (never the headline) ------------------------------------------------------------------
 def research_split_f16_child():
-    """Child process (COTR_HIP_EXPERIMENTAL=1: libcotr_hip_exp.so): the batched shapes with the RESEARCH knob split_f16=2 (fp32 products
+    """Child process (COTR_HIP_EXPERIMENTAL=1: libcotr_hip_exp.so): the batched shapes with the RESEARCH knob split_f16=3 (fp32 products
     from three f16 MFMAs on packed split-f16 tensors, csrc/experimental/gemm_h2.h) next to the same library's fp32-MFMA path, and how far
     apart the two results are.  One JSON object on stdout."""
     import cotr_amd
@@ -283,7 +283,7 @@ def research_split_f16():
     """also_measured['RESEARCH_split_f16_opt_in_not_the_product_path']: measured by a child on the experimental library; the headline, the
     roofline object and batched_frac stay on v_mfma_f32_32x32x2_f32 (dtype f32)."""
     note = ('RESEARCH, opt-in (knob split_f16 of libcotr_hip_exp.so, off by default, never on the product path): every fp32 product of the '
-            'large GEMMs / convolutions as three v_mfma_f32_32x32x16_f16 on packed split-f16 tensors (hi = f16(a), lo = f16((a - hi) * 2^11)); '
+            'large GEMMs / convolutions / attention products (level 3) as three v_mfma_f32_32x32x16_f16 on packed split-f16 tensors (hi = f16(a), lo = f16((a - hi) * 2^11)); '
             'as close to the fp64 truth as the fp32-MFMA path on all 9 goldens of the reference (tests/test_experimental_gpu.py), not '
             'bit-identical to it, range-limited to |x| < 65504; "fp32_equivalent_tflops" counts the fp32 work and is NOT a fraction of any roofline')
     try:
