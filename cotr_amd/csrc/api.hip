@@ -145,6 +145,11 @@ struct cotr_ctx {
   // level 3 (split-f16 attention): a packed copy of the cached decoder K / V of the current encode, made by the first decode that wants it
   Arena kv_h2;
   unsigned long long enc_serial = 0, kv_h2_serial = 0;
+  // the LayerNorm in front of a projection leaves the packed form of its output (+ h2_ln_add, one-shot: the decoder's query_pos) in
+  // h2_scr: linear() then finds its input packed (h2_prepacked_src / _add say of what) and skips its packing launch
+  const float* h2_prepacked_src = nullptr;
+  const float* h2_prepacked_add = nullptr;
+  const float* h2_ln_add = nullptr;
 #endif
   // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
   struct FusedBlock { const float *w2p = nullptr, *w3p = nullptr, *wdp = nullptr; };
@@ -364,10 +369,14 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
     if (in_packed || level2) {
       if (in_packed && x2 != nullptr) { h->err = "split_f16: the x + pos prologue is not available on packed operands"; return COTR_ERR_ARG; }
       if (int r = h2_prepare_weights(h, s)) return r;
-      if (!in_packed) {   // x (+ x2) -> packed split-f16 copy
-        if (int r = ensure(h, h->h2_scr, (size_t)M * K)) return r;
-        KCHK(h, launch_split_h2(x, h->h2_scr.ptr, (size_t)M * K, s, x2), "split_h2");
-        prof_mark(h, "split_h2", s, 2);
+      if (!in_packed) {   // x (+ x2) -> packed split-f16 copy, unless the LayerNorm that produced x left it already
+        const bool prepacked = K == D && x == h->h2_prepacked_src && x2 == h->h2_prepacked_add && h->h2_scr.cap >= (size_t)M * K;
+        h->h2_prepacked_src = nullptr;
+        if (!prepacked) {
+          if (int r = ensure(h, h->h2_scr, (size_t)M * K)) return r;
+          KCHK(h, launch_split_h2(x, h->h2_scr.ptr, (size_t)M * K, s, x2), "split_h2");
+          prof_mark(h, "split_h2", s, 2);
+        }
         p.A = h->h2_scr.ptr;
         p.A2 = nullptr;
       }
@@ -387,6 +396,20 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
 }
 
 int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float* y, int M, hipStream_t s) {
+#ifdef COTR_EXPERIMENTAL
+  {
+    const float* add = h->h2_ln_add;
+    h->h2_ln_add = nullptr;
+    if (knob(KN_SPLIT_F16) >= 2 && M >= H2_MIN_ROWS) {   // RESEARCH: its consumer is a split-f16 projection - leave the packed form too
+      if (int r = ensure(h, h->h2_scr, (size_t)M * D)) return r;
+      KCHK(h, launch_layernorm_h2(x, w, b, y, h->h2_scr.ptr, add, M, s), "layernorm (+ packed copy)");
+      prof_mark(h, "layernorm+pack", s, 2);
+      h->h2_prepacked_src = y;
+      h->h2_prepacked_add = add;
+      return COTR_OK;
+    }
+  }
+#endif
   KCHK(h, launch_layernorm(x, w, b, y, M, s), "layernorm");
   prof_mark(h, "layernorm", s, 2);
   return COTR_OK;

@@ -41,6 +41,8 @@ int gemm_pp_workgroups();
 // gemm_h2.hip / gemm_h2.h (research): fp32 -> packed split-f16 dwords, the operand format of GEMM configurations 46 / 47
 int launch_split_h2(const float* x, void* y, size_t n, hipStream_t s, const float* x2 = nullptr);   // y = pack(x [+ x2])
 int launch_unsplit_h2(const void* x, float* y, size_t n, hipStream_t s);
+// y = LayerNorm(x) (bits of launch_layernorm) and yp = pack(y [+ add]) in one launch
+int launch_layernorm_h2(const float* x, const float* w, const float* b, float* y, void* yp, const float* add, int rows, hipStream_t s);
 // attention_h2.hip: the resident-K/V attention kernel on packed k / v (q fp32 or packed, o fp32 or packed)
 int launch_attention_h2(const float* q, int ldq, int q_packed, const float* k, const float* v, int ldkv, float* o, int ldo, int out_packed,
                         int nb, int nq, hipStream_t s);
