@@ -42,6 +42,8 @@ int gemm_pp_workgroups();
 int launch_split_h2(const float* x, void* y, size_t n, hipStream_t s, const float* x2 = nullptr);   // y = pack(x [+ x2])
 int launch_unsplit_h2(const void* x, float* y, size_t n, hipStream_t s);
 // y = LayerNorm(x) (bits of launch_layernorm) and yp = pack(y [+ add]) in one launch
+// gemm_h2r.hip: K = 256 dense GEMM on packed operands, A tile resident in registers (configuration 50)
+int launch_gemm_h2r(const GemmParams& p, hipStream_t s);
 int launch_layernorm_h2(const float* x, const float* w, const float* b, float* y, void* yp, const float* add, int rows, hipStream_t s);
 // attention_h2.hip: the resident-K/V attention kernel on packed k / v (q fp32 or packed, o fp32 or packed)
 int launch_attention_h2(const float* q, int ldq, int q_packed, const float* k, const float* v, int ldkv, float* o, int ldo, int out_packed,

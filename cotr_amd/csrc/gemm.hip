@@ -753,6 +753,7 @@ static const GemmCfg kCfgs[] = {
     {5, 0, 2, 1},   // 47 the same, 128x64
     {5, 0, 2, 2},   // 48 packed split-f16 operands on the wave-specialised 128x128 tile (4 loader + 4 MFMA wavefronts)
     {5, 0, 2, 1},   // 49 the same, 128x64
+    {10, 0, 2, 2},  // 50 packed split-f16, K = 256 dense: A tile resident in REGISTERS, W through an 8-stage ring across column tiles (experimental/gemm_h2r.hip)
 #endif
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -878,6 +879,7 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 47: return launch_gemm_big(MODE, 9, p, s);
     case 48: return launch_gemm_big(MODE, 10, p, s);
     case 49: return launch_gemm_big(MODE, 11, p, s);
+    case 50: return MODE == GEMM_DENSE ? launch_gemm_h2r(p, s) : -1;
 #endif
     case 40: return launch_gemm_big(MODE, 4, p, s);
     case 41: return launch_gemm_big(MODE, 5, p, s);
@@ -919,6 +921,7 @@ static const TunedEntry kTuned[] = {
 
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
+  if (c.kind == 10) return p.K == 256 && p.N % 128 == 0 && p.A2 == nullptr && p.lda % 4 == 0;
   if (c.kind == 4 || c.kind == 5 || c.kind == 9) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
     if (c.kind == 9 && p.K < 64) return false;
     if (p.A2 != nullptr || p.ldc % 4 != 0 || ((uintptr_t)p.C & 15)) return false;

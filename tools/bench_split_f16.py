@@ -10,7 +10,7 @@ from cotr_amd import _lib
 lib = _lib.load_library()
 dev = torch.device('cuda:0')
 P = lambda t: t.data_ptr()
-shapes = [(4096, 4096, 4096), (8192, 8192, 8192), (16384, 1024, 256), (16384, 256, 1024), (32000, 1024, 256), (32000, 256, 1024),
+shapes = [(16384, 3072, 256), (32000, 256, 256), (16384, 256, 256), (4096, 4096, 4096), (8192, 8192, 8192), (16384, 1024, 256), (16384, 256, 1024), (32000, 1024, 256), (32000, 256, 1024),
           (16384, 256, 2304), (65536, 128, 1152), (262144, 64, 576), (262144, 256, 64), (262144, 64, 256), (16384, 768, 256)]
 for M, N, K in shapes:
     x = torch.relu(torch.randn(M, K, device=dev))
@@ -29,13 +29,13 @@ for M, N, K in shapes:
     pack_us = e0.elapsed_time(e1) * 100
     line = f'{M:7d} x {N:5d} x {K:5d}:'
     t = {}
-    for cfg, a_, w_ in ((26, x, w), (27, x, w), (40, x, w), (46, xp, wp), (47, xp, wp), (48, xp, wp), (49, xp, wp)):
+    for cfg, a_, w_ in ((26, x, w), (27, x, w), (40, x, w), (46, xp, wp), (47, xp, wp), (48, xp, wp), (49, xp, wp), (50, xp, wp)):
         us = ctypes.c_float(0)
         r = lib.cotr_bench_linear(P(a_), P(w_), None, P(y), M, N, K, cfg, 10, ctypes.byref(us))
         t[cfg] = us.value if r == 0 else float('nan')
         line += f'  {cfg}: {t[cfg]:7.1f} us {2.0 * M * N * K / t[cfg] / 1e6:5.0f} TF'
     nn = lambda v: v if v == v else 1e30
-    best32, best16 = min(nn(t[26]), nn(t[27]), nn(t[40])), min(nn(t[c]) for c in (46, 47, 48, 49))
+    best32, best16 = min(nn(t[26]), nn(t[27]), nn(t[40])), min(nn(t[c]) for c in (46, 47, 48, 49, 50))
     print(line + f'   packing x: {pack_us:6.1f} us   split-f16 / fp32 = {best32 / best16:.2f}x ({best32 / (best16 + pack_us):.2f}x with the packing pass)', flush=True)
 
 # the convolutions of the batched backbone (32 pairs), implicit GEMM on packed pixels / weights
