@@ -8,6 +8,8 @@
 //   GEMM configs 28 / 29  three LDS stages in the large-tile kernel                                  within +-5 %
 //   gemm_pp.hip      persistent ping-pong large tiles (configs 42 / 43): loaders run ahead across tiles,   383 vs 306 us (K = 256):
 //                    a tile's write-out beside the next tile's MFMAs                                     the write-out is not hidden
+//   gemm_h2r.hip     split-f16 GEMM for K = 256 with the A tile resident in registers (configuration 50): 138 vs 74 us at
+//                    32000 x 1024 x 256 - one wavefront per SIMD, nothing covers its LDS reads / perms
 //   gemm_h2.h/.hip   RESEARCH, not a dead end: fp32 products from three f16 MFMAs on packed split-f16 operands (configs 46 / 47);
 //                    not bit-identical to the fp32 path and range-limited (|x| < 65504) - see the header of gemm_h2.h
 #pragma once

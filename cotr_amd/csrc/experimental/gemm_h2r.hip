@@ -9,7 +9,10 @@
 // sets spill) (the MFMA A operands of every step come from there: no LDS read, no v_perm for A), and only W streams -
 // 16 KB per step instead of 32 - through an 8-stage LDS ring of 128 KB that runs 7 steps ahead and straight across column tiles.
 // One s_barrier per step; one drained wait (vmcnt(0)) per column tile, because the epilogue's stores share the counter with the ring's loads.
-// Epilogue straight from the accumulators (bias, column scale, fp32 / packed / row-periodic residual, ReLU, fp32 or packed output).
+// Epilogue straight from the accumulators (bias, column scale, fp32 / packed residual, ReLU, fp32 or packed output).
+// MEASURED (profiles/r4_split_f16_gemm_configs.txt): correct, same bits as 46 - 49 - and 138 us against 74 (configuration 47) at 32000 x 1024 x 256:
+// one wavefront per SIMD leaves nobody to issue while it waits for its fragment reads; as hipcc schedules the loop a K step takes 2.2 us.
+// Never picked by h2_config; kept so that the measurement can be repeated.
 #include "../common.h"
 #include "gemm_h2.h"
 
@@ -104,21 +107,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int col = nt * 128 + b * 32 + l31;
-        const float scv = p.scale ? p.scale[col] : 1.f, biv = p.bias ? p.bias[col] : 0.f;
-        const float csv = col < p.colscale_n ? p.colscale : 1.f;
+        const float biv = (p.bias ? p.bias[col] : 0.f), csv = col < p.colscale_n ? p.colscale : 1.f;
+        float* crow = p.C + (size_t)(m0 + wave * 32 + 4 * hh) * p.ldc + col;
+        const float* rrow = p.residual ? p.residual + (size_t)(m0 + wave * 32 + 4 * hh) * p.ldr + col : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (m >= p.M) continue;
-          float x = fmaf(accx[b][r], 0x1p-11f, acc[b][r]);
-          x = p.scale ? fmaf(x, scv, biv) : x + biv;
-          x *= csv;
-          if (p.residual) {
-            const float rv = p.residual[(size_t)(p.res_row_mod > 0 ? fastmod(m, p.fd_resrow) : m) * p.ldr + col];
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (m0 + wave * 32 + 4 * hh + dr >= p.M) continue;
+          float x = (fmaf(accx[b][r], 0x1p-11f, acc[b][r]) + biv) * csv;
+          if (rrow) {
+            const float rv = rrow[(size_t)dr * p.ldr];
             x += (p.h2_flags & 2) ? h2_unpack(__float_as_uint(rv)) : rv;
           }
           if (p.relu) x = (x < 0.f) ? 0.f : x;
-          p.C[(size_t)m * p.ldc + col] = (p.h2_flags & 1) ? __uint_as_float(h2_pack(x)) : x;
+          crow[(size_t)dr * p.ldc] = (p.h2_flags & 1) ? __uint_as_float(h2_pack(x)) : x;
         }
       }
   }
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // dense only, K = 256, N a multiple of 128, packed A / W (16-byte aligned rows: lda % 4 == 0)
 int launch_gemm_h2r(const GemmParams& p0, hipStream_t s) {
   GemmParams p = p0;
-  if (p.K != RK || p.N % 128 != 0 || p.M <= 0 || p.A2 != nullptr || p.lda % 4 != 0) return -1;
+  if (p.K != RK || p.N % 128 != 0 || p.M <= 0 || p.A2 != nullptr || p.lda % 4 != 0 || p.scale != nullptr || p.res_row_mod > 0) return -1;
   if (!gemm_fill_divs(p, GEMM_DENSE, 128, 128)) return -1;
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
