@@ -364,6 +364,7 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
   {  // RESEARCH, knob split_f16 (experimental/gemm_h2.h)
     const bool in_packed = h->h2_pass || h->h2_in_packed, out_packed = h->h2_out_packed;
     h->h2_in_packed = h->h2_out_packed = false;
+    h->h2_pass = false;   // a projection ends a packed backbone pass (input_proj): what follows it reads fp32
     const bool simple_x2 = x2 == nullptr || (x2_row_mod == 0 && a2_period == 1 && a2_width == 1);
     const bool level2 = knob(KN_SPLIT_F16) >= 2 && M >= H2_MIN_ROWS && N % 64 == 0 && K % 32 == 0 && simple_x2;
     if (in_packed || level2) {
@@ -950,9 +951,6 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     const int M = Bc * TOK;
     int r;
     if ((r = linear(h, x, nullptr, 0, 1, 0, h->ip_w, h->ip_b, nullptr, 0, 1.f, 0, t_src, M, D, CFEAT, s))) return r;
-#ifdef COTR_EXPERIMENTAL
-    h->h2_pass = false;   // the transformer reads fp32
-#endif
     if ((r = tap_save(h, "src", t_src, (size_t)M * D, s))) return r;
     prof_mark(h, "input_proj", s);
     // ---- encoder (transformer.py:143-159, post-norm) ----------------------------------------

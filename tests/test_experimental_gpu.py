@@ -552,3 +552,50 @@ def test_split_f16_attention_against_fp64(case):
             errs[(q_packed, out_packed)] = G.rel_err(o, ref)
     print(case, f'fp32 kernel {e32:.3g}', {k_: f'{v_:.3g}' for k_, v_ in errs.items()})
     assert all(e <= 1.5 * e32 + 2e-6 for e in errs.values()), (case, e32, errs)
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,stride', [(2, 64, 64, 256, 1, 1), (2, 64, 64, 64, 3, 1), (2, 64, 256, 512, 1, 2), (2, 64, 128, 128, 3, 2),
+                                                   (2, 32, 512, 128, 1, 1)])
+def test_split_f16_packed_residual_and_packed_output(B, H, cin, cout, k, stride):
+    """What a chain of split-f16 launches passes from one to the next: the epilogue UNPACKS a packed residual (h + 2^-11 l: exact) and
+    PACKS its result (cotr_op_set_h2_flags bits 1 / 0) - every combination, on the backbone's convolution shapes (1x1, 3x3, strided),
+    FrozenBN + residual with negative values + ReLU, configurations 46 - 49, against the fp32 configuration 27."""
+    lib = _lib.load_library()
+    d = G.dev()
+    g = _g(B + H + cin + cout + k + stride)
+    x = torch.relu(torch.randn(B, H, 2 * H, cin, generator=g)).to(d)
+    w = (torch.randn(cout, k * k * cin, generator=g) / math.sqrt(k * k * cin)).to(d)
+    sc, bi = (torch.rand(cout, generator=g) + 0.5).to(d), torch.randn(cout, generator=g).to(d)
+    Ho = H // stride
+    r = torch.randn(B, Ho, 2 * Ho, cout, generator=g).to(d)
+
+    def pk(t):
+        o = torch.empty_like(t)
+        assert lib.cotr_op_split_h2(G.P(t), G.P(o), t.numel(), G.sptr()) == 0
+        return o
+
+    def up(t):
+        o = torch.empty_like(t)
+        assert lib.cotr_op_unsplit_h2(G.P(t), G.P(o), t.numel(), G.sptr()) == 0
+        return o
+    assert float(((up(pk(r)) - r).abs() / r.abs().clamp_min(1e-3)).max()) < 2.5e-7        # 22 bits, negative values included
+    want = torch.empty(B, Ho, 2 * Ho, cout, device=d)
+    assert lib.cotr_op_conv_cfg(G.P(x), G.P(w), G.P(sc), G.P(bi), G.P(r), 1, G.P(want), B, H, H, cin, cout, k, stride, 27, G.sptr()) == 0
+    xp, wp, rp = pk(x), pk(w), pk(r)
+    ran = 0
+    try:
+        for cfg in (46, 47, 48, 49):
+            for flags in (0, 1, 2, 3):
+                assert lib.cotr_op_set_h2_flags(flags) == 0
+                got = torch.full_like(want, float('nan'))
+                rc = lib.cotr_op_conv_cfg(G.P(xp), G.P(wp), G.P(sc), G.P(bi), G.P(rp if flags & 2 else r), 1, G.P(got), B, H, H, cin, cout, k,
+                                          stride, cfg, G.sptr())
+                if rc != 0:
+                    continue                                     # the tile does not divide Cout
+                if flags & 1:
+                    got = up(got)
+                assert float((got - want).abs().max()) < 2e-5, (cfg, flags, float((got - want).abs().max()))
+                ran += 1
+    finally:
+        lib.cotr_op_set_h2_flags(0)
+    assert ran >= 8
