@@ -10,6 +10,7 @@
 //                    a tile's write-out beside the next tile's MFMAs                                     the write-out is not hidden
 //   gemm_h2r.hip     split-f16 GEMM for K = 256 with the A tile resident in registers (configuration 50): 138 vs 74 us at
 //                    32000 x 1024 x 256 - one wavefront per SIMD, nothing covers its LDS reads / perms
+//   GEMM config 51   split-f16 on a 256 x 128 tile (8 wavefronts, 3 stages): 355 vs 340 TFLOP/s at 4096^3, equal or slower on the model's shapes
 //   gemm_h2.h/.hip   RESEARCH, not a dead end: fp32 products from three f16 MFMAs on packed split-f16 operands (configs 46 / 47);
 //                    not bit-identical to the fp32 path and range-limited (|x| < 65504) - see the header of gemm_h2.h
 #pragma once

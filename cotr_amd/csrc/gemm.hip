@@ -754,6 +754,7 @@ static const GemmCfg kCfgs[] = {
     {5, 0, 2, 2},   // 48 packed split-f16 operands on the wave-specialised 128x128 tile (4 loader + 4 MFMA wavefronts)
     {5, 0, 2, 1},   // 49 the same, 128x64
     {10, 0, 2, 2},  // 50 packed split-f16, K = 256 dense: A tile resident in REGISTERS, W through an 8-stage ring across column tiles (experimental/gemm_h2r.hip)
+    {11, 0, 2, 2},  // 51 packed split-f16 on a 256 x 128 tile (8 wavefronts, three LDS stages, one workgroup per CU): 25 % fewer bytes per flop
 #endif
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -880,6 +881,7 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 48: return launch_gemm_big(MODE, 10, p, s);
     case 49: return launch_gemm_big(MODE, 11, p, s);
     case 50: return MODE == GEMM_DENSE ? launch_gemm_h2r(p, s) : -1;
+    case 51: return launch_gemm_big(MODE, 12, p, s);
 #endif
     case 40: return launch_gemm_big(MODE, 4, p, s);
     case 41: return launch_gemm_big(MODE, 5, p, s);
@@ -922,7 +924,7 @@ static const TunedEntry kTuned[] = {
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
   if (c.kind == 10) return p.K == 256 && p.N % 128 == 0 && p.A2 == nullptr && p.lda % 4 == 0;
-  if (c.kind == 4 || c.kind == 5 || c.kind == 9) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
+  if (c.kind == 4 || c.kind == 5 || c.kind == 9 || c.kind == 11) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
     if (c.kind == 9 && p.K < 64) return false;
     if (p.A2 != nullptr || p.ldc % 4 != 0 || ((uintptr_t)p.C & 15)) return false;
     if (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15))) return false;
@@ -1025,7 +1027,7 @@ static int gemm_pick_config_table(int mode, const GemmParams& p) {
 // which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
 static void set_xcd_split(int mode, int cfg, GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  const int bm = (c.kind == 4 || c.kind == 5 || c.kind == 9) ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
+  const int bm = c.kind == 11 ? 256 : (c.kind == 4 || c.kind == 5 || c.kind == 9) ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
   const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
   const double w_bytes = (double)p.N * p.K * 4.0;
   const bool fits = (p.M + bm - 1) / bm >= 8;

@@ -33,13 +33,15 @@
 // X selects an experimental form (libcotr_hip_exp.so only): 0 = the product kernel, 1 = DIRECT, 2 = H2 (configurations 46 / 47,
 // experimental/gemm_h2.h): both operands arrive as PACKED SPLIT-f16 dwords (cotr_op_split_h2) and every fp32 product becomes three
 // v_mfma_f32_32x32x16_f16 - research, NOT bit-identical to the fp32 path.
-template <int TN, int MODE, int NST, int X = 0>
+// NW = wavefronts (4: the 128-row tile of every product configuration; 8: a 256-row tile, experimental configuration 51: a wavefront still
+// fetches 32 A rows, half as many W rows, and the tile moves 25 % fewer bytes per flop)
+template <int TN, int MODE, int NST, int X = 0, int NW = 4>
 __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid) {
   constexpr bool DIRECT = X == 1;
   [[maybe_unused]] constexpr bool H2 = X == 2;
-  constexpr int BM = 128, BN = 64 * TN;
+  constexpr int BM = 32 * NW, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage
-  constexpr int QW = BN / 32;             // W-tile DMA instructions per wavefront
+  constexpr int QW = BN / (8 * NW);       // W-tile DMA instructions per wavefront
   constexpr int EP = 32 * TN + 4;         // padded row of the epilogue staging tile
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -74,7 +76,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
   const float* w_ptr[QW];
 #pragma unroll
   for (int q = 0; q < QW; ++q) {
-    const int row = wave * (BN / 4) + q * 8 + drow;    // tile-local W row
+    const int row = wave * (BN / NW) + q * 8 + drow;   // tile-local W row
     const int lch = pch ^ ((row >> 1) & 7);
     w_ptr[q] = p.W + (size_t)(n0 + row) * p.K + lch * 4;
   }
@@ -105,7 +107,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
 #pragma unroll
     for (int q = 0; q < QW; ++q)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[q] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(Ws + (wave * (BN / 4) + q * 8) * BK), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(Ws + (wave * (BN / NW) + q * 8) * BK), 16, 0, 0);
   };
 
   // ---- main loop -----------------------------------------------------------------------------------------------
@@ -162,6 +164,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
       // in flight, oldest first: [tile kt] [tile kt+1]; one tile = 4 + QW DMA instructions per wavefront.  (In the first
       // steps the residual prefetch sits behind tile 1 and is waited for too - conservative, not wrong.)
       if (kt + 1 < KT) {
+        static_assert(QW == 4 || QW == 2, "counted wait: one tile = 4 + QW DMA instructions per wavefront");
         if constexpr (QW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       } else {
@@ -562,9 +565,9 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int TN, int MODE, int NST, int X = 0>
-__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
-  gemm_big_body<TN, MODE, NST, X>(p, blockIdx.x);
+template <int TN, int MODE, int NST, int X = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_big_kernel(const GemmParams p) {
+  gemm_big_body<TN, MODE, NST, X, NW>(p, blockIdx.x);
 }
 
 // two independent problems in one grid (common.h: launch_gemm_dual_cfg)
@@ -604,11 +607,11 @@ int launch_gemm_big_dual(int mode, int variant, const GemmParams& p0, const Gemm
   return variant == 0 ? launch_big_dual_t<2>(p0, p1, s) : variant == 1 ? launch_big_dual_t<1>(p0, p1, s) : -1;
 }
 
-template <int TN, int MODE, int NST, int X = 0>
+template <int TN, int MODE, int NST, int X = 0, int NW = 4>
 static int launch_big_t(const GemmParams& p0, hipStream_t s) {
-  constexpr int BM = 128, BN = 64 * TN;
+  constexpr int BM = 32 * NW, BN = 64 * TN;
   constexpr size_t smem = (size_t)NST * (BM + BN) * BK * sizeof(float);
-  static_assert(smem >= (size_t)4 * 32 * (32 * TN + 4) * sizeof(float), "epilogue staging fits in the operand stages");
+  static_assert(smem >= (size_t)NW * 32 * (32 * TN + 4) * sizeof(float), "epilogue staging fits in the operand stages");
   GemmParams p = p0;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0 || p.A2 != nullptr) return -1;
   if (p.ldc % 4 != 0 || (p.residual && p.ldr % 4 != 0)) return -1;
@@ -617,14 +620,14 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   if (p.zeros == nullptr) return -2;
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST, X>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST, X, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set.set();
   }
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
   const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST, X>), dim3(tiles), dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST, X, NW>), dim3(tiles), dim3(64 * NW), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -646,6 +649,7 @@ int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s) {
     case 9: return d ? launch_big_t<1, GEMM_DENSE, 2, 2>(p, s) : launch_big_t<1, GEMM_CONV, 2, 2>(p, s);
     case 10: return d ? launch_ws_t<2, GEMM_DENSE, true>(p, s) : launch_ws_t<2, GEMM_CONV, true>(p, s);   // packed split-f16, wave-specialised
     case 11: return d ? launch_ws_t<1, GEMM_DENSE, true>(p, s) : launch_ws_t<1, GEMM_CONV, true>(p, s);
+    case 12: return d ? launch_big_t<2, GEMM_DENSE, 3, 2, 8>(p, s) : launch_big_t<2, GEMM_CONV, 3, 2, 8>(p, s);   // packed split-f16, 256 x 128 tile, 8 wavefronts, 3 stages
 #endif
     case 4: return d ? launch_ws_t<2, GEMM_DENSE>(p, s) : launch_ws_t<2, GEMM_CONV>(p, s);   // wave-specialised 128 x 128
     case 5: return d ? launch_ws_t<1, GEMM_DENSE>(p, s) : launch_ws_t<1, GEMM_CONV>(p, s);   // wave-specialised 128 x 64

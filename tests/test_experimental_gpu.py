@@ -387,7 +387,7 @@ def test_split_f16_large_tile_is_as_close_to_fp64_as_the_fp32_path(M, N, K):
     truth = x.double() @ w.double().t() + b.double() + r.double()
     scale = x.double().abs() @ w.double().abs().t() + b.double().abs() + r.double().abs()
     err = {}
-    h2_cfgs = (46, 47, 48, 49) + ((50,) if K == 256 else ())          # 50: A resident in registers, K = 256 only
+    h2_cfgs = (46, 47, 48, 49, 51) + ((50,) if K == 256 else ())      # 50: A resident in registers, K = 256 only; 51: 256 x 128 tile
     for cfg, a_, w_ in ((26, x, w), (27, x, w)) + tuple((c, xp, wp) for c in h2_cfgs):
         y = torch.full((M + 1, N), 7.0, device=d)
         assert lib.cotr_op_linear_cfg(G.P(a_), G.P(w_), G.P(b), G.P(r), 0, G.P(y), M, N, K, cfg, G.sptr()) == 0
@@ -410,7 +410,7 @@ def test_split_f16_large_tile_is_as_close_to_fp64_as_the_fp32_path(M, N, K):
     assert lib.cotr_op_split_h2(G.P(ws), G.P(wsp), ws.numel(), G.sptr()) == 0
     want = torch.empty(B, H, 2 * H, cout, device=d)
     assert lib.cotr_op_conv_cfg(G.P(xs), G.P(ws), G.P(sc), G.P(bi), G.P(rs), 1, G.P(want), B, H, H, cin, cout, 3, 1, 27, G.sptr()) == 0
-    for cfg in (46, 47, 48, 49):
+    for cfg in (46, 47, 48, 49, 51):
         got = torch.empty_like(want)
         assert lib.cotr_op_conv_cfg(G.P(xsp), G.P(wsp), G.P(sc), G.P(bi), G.P(rs), 1, G.P(got), B, H, H, cin, cout, 3, 1, cfg, G.sptr()) == 0
         assert float((got - want).abs().max()) < 2e-5, (cfg, float((got - want).abs().max()))
@@ -584,7 +584,7 @@ def test_split_f16_packed_residual_and_packed_output(B, H, cin, cout, k, stride)
     xp, wp, rp = pk(x), pk(w), pk(r)
     ran = 0
     try:
-        for cfg in (46, 47, 48, 49):
+        for cfg in (46, 47, 48, 49, 51):
             for flags in (0, 1, 2, 3):
                 assert lib.cotr_op_set_h2_flags(flags) == 0
                 got = torch.full_like(want, float('nan'))

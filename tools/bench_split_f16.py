@@ -29,13 +29,13 @@ for M, N, K in shapes:
     pack_us = e0.elapsed_time(e1) * 100
     line = f'{M:7d} x {N:5d} x {K:5d}:'
     t = {}
-    for cfg, a_, w_ in ((26, x, w), (27, x, w), (40, x, w), (46, xp, wp), (47, xp, wp), (48, xp, wp), (49, xp, wp), (50, xp, wp)):
+    for cfg, a_, w_ in ((26, x, w), (27, x, w), (40, x, w), (46, xp, wp), (47, xp, wp), (48, xp, wp), (49, xp, wp), (50, xp, wp), (51, xp, wp)):
         us = ctypes.c_float(0)
         r = lib.cotr_bench_linear(P(a_), P(w_), None, P(y), M, N, K, cfg, 10, ctypes.byref(us))
         t[cfg] = us.value if r == 0 else float('nan')
         line += f'  {cfg}: {t[cfg]:7.1f} us {2.0 * M * N * K / t[cfg] / 1e6:5.0f} TF'
     nn = lambda v: v if v == v else 1e30
-    best32, best16 = min(nn(t[26]), nn(t[27]), nn(t[40])), min(nn(t[c]) for c in (46, 47, 48, 49, 50))
+    best32, best16 = min(nn(t[26]), nn(t[27]), nn(t[40])), min(nn(t[c]) for c in (46, 47, 48, 49, 50, 51))
     print(line + f'   packing x: {pack_us:6.1f} us   split-f16 / fp32 = {best32 / best16:.2f}x ({best32 / (best16 + pack_us):.2f}x with the packing pass)', flush=True)
 
 # the convolutions of the batched backbone (32 pairs), implicit GEMM on packed pixels / weights
@@ -51,7 +51,7 @@ for B, H, cin, cout, k, stride in ((32, 64, 64, 64, 3, 1), (32, 32, 128, 128, 3,
     s = torch.cuda.current_stream().cuda_stream
     lib.cotr_op_split_h2(P(x), P(xp), x.numel(), s); lib.cotr_op_split_h2(P(w), P(wp), w.numel(), s)
     line = f'{B} x {H}x{2 * H} {cin:4d} -> {cout:4d} k{k} /{stride}:'
-    for cfg, a_, w_ in ((26, x, w), (27, x, w), (40, x, w), (46, xp, wp), (47, xp, wp), (48, xp, wp), (49, xp, wp)):
+    for cfg, a_, w_ in ((26, x, w), (27, x, w), (40, x, w), (46, xp, wp), (47, xp, wp), (48, xp, wp), (49, xp, wp), (51, xp, wp)):
         us = ctypes.c_float(0)
         r = lib.cotr_bench_conv(P(a_), P(w_), P(sc), P(bi), P(y), B, H, H, cin, cout, k, stride, cfg, 10, ctypes.byref(us))
         line += f'  {cfg}: {us.value if r == 0 else float("nan"):7.1f}'
