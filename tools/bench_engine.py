@@ -1,6 +1,7 @@
 """End-to-end zoom-in refinement throughput on the MI355X: ZoomEngine (one crop launch + batched model calls per
 level) vs the reference's loop shape (32 tasks per call, PIL crops on the host, H2D per batch) with the same HIP model.
-    python tools/bench_engine.py [n_queries]"""
+    python tools/bench_engine.py [n_queries] [--config2] [KNOB=INT ...]     (knobs of the model's handle, e.g. split_f16=3 with
+    COTR_HIP_EXPERIMENTAL=1: the research path of DESIGN.md 3e at engine level)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,7 +12,7 @@ from cotr_amd.models import build_model
 from cotr_amd.utils.synth import synth_state_dict
 from tests.engine_fixtures import synthetic_pair, pil_cropper_factory
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1000
 img_a, img_b = synthetic_pair(3, (783, 1064), (1053, 689))     # the cathedral demo pair's sizes
 rng = np.random.default_rng(0)
 loc_from = np.stack([rng.uniform(5, img_a.shape[1] - 5, n), rng.uniform(5, img_a.shape[0] - 5, n)], 1)
@@ -19,6 +20,9 @@ loc_to = np.stack([rng.uniform(5, img_b.shape[1] - 5, n), rng.uniform(5, img_b.s
 zooms = np.linspace(0.5, 0.0625, 4)
 m = build_model(cotr_amd.default_args()).cuda().eval()
 m.load_state_dict(synth_state_dict(0))
+for kv in [a for a in sys.argv[1:] if '=' in a]:
+    m.set_knob(kv.split('=')[0], int(kv.split('=')[1]))
+    print('knob', kv)
 for max_pairs, tag in ((256, 'ZoomEngine, device crops, 256 crops per model call'),
                        (1024, 'ZoomEngine, device crops, 1024 crops per model call')):
     eng = ZoomEngine(m, max_pairs=max_pairs)
