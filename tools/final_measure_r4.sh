@@ -1,5 +1,6 @@
 #!/bin/bash
-# Everything profiles/r4_final_* is built from, in one go on the GPU box.  usage: tools/final_measure_r4.sh [part a|b|c|all]
+# Everything profiles/r4_final_* (parts a-c) and profiles/r4_split_f16_* (part d: the research path of DESIGN.md 3e, experimental library) is
+# built from, in one go on the GPU box.  usage: tools/final_measure_r4.sh [part a|b|c|d|all]
 part=${1:-all}
 o=gpurun_out/r4_final
 mkdir -p $o
@@ -34,5 +35,17 @@ if [ "$part" = all ] || [ "$part" = c ]; then
   python tools/kernel_times.py 1 1000 > $o/kernel_times_hip_events_b1_q1000.txt 2>&1
   python tools/kernel_times.py 32 1000 > $o/kernel_times_hip_events_b32_q1000.txt 2>&1
   bash tools/mfma_util.sh 32 1000 $o/mfma_util_and_traffic_b32_q1000.txt > /dev/null 2>&1
+fi
+if [ "$part" = all ] || [ "$part" = d ]; then
+  export COTR_HIP_EXPERIMENTAL=1
+  r=gpurun_out/r4_split_f16
+  mkdir -p $r
+  python tools/bench_split_f16.py > $r/gemm_configs.txt 2>&1
+  python tools/bench_attention_h2.py > $r/attention_kernel.txt 2>&1
+  for lv in 1 2 3; do python tools/time_configs.py split_f16=$lv > $r/level${lv}_time_configs_batched.txt 2>&1; done
+  python tools/kernel_times.py 32 1000 split_f16=3 > $r/level3_kernel_times_hip_events_b32_q1000.txt 2>&1
+  python tools/bench_engine.py 1000 --config2 split_f16=3 > $r/level3_bench_engine.txt 2>&1
+  unset COTR_HIP_EXPERIMENTAL
+  ls -la $r
 fi
 ls -la $o
