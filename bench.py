@@ -762,7 +762,14 @@ def main():
                                         'GEMMs, amd-smi reads 2.38-2.40 GHz per XCD (profiles/r4_shader_clock_probe_and_smi.txt) - the chip does not throttle here, '
                                         'so the nominal 157.3 TFLOP/s (2.4 GHz) is the peak to measure against; 155.9 = 65536 FLOP/clock x 2.379 GHz')},
         }
-        extras = world == 1 and not args.no_extras and not batch256 and not dense
+        research = [f'{n}={v}' for n, v in KNOBS if n.startswith('split_f16') and v]
+        if research:   # --set split_f16=N on the experimental library: the line is NOT a measurement of the fp32-MFMA product path - say so in it
+            line['dtype'] = 'f32 carried as packed split-f16 (RESEARCH: three f16 MFMAs per fp32 product, DESIGN.md 3e)'
+            line['RESEARCH_not_the_product_path'] = ('measured with --set ' + ' '.join(research) + ' on libcotr_hip_exp.so: results are as close to fp64 as the '
+                                                     'fp32-MFMA path but not bit-identical to it; "roofline" below divides fp32-EQUIVALENT work by the fp32-MFMA '
+                                                     'peak and is not a fraction of any roofline of the kernels that ran')
+            line['roofline']['bound'] = 'none (research path)'
+        extras = world == 1 and not args.no_extras and not batch256 and not dense and not research
         line.update(ident)
         roof = line['roofline']
         mode = args.traffic
