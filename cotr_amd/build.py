@@ -18,7 +18,7 @@ LIB = os.path.join(CSRC, 'libcotr_hip.so')
 # product path; tests/test_experimental_gpu.py and the A/B tools select it with COTR_HIP_EXPERIMENTAL=1.
 LIB_EXP = os.path.join(CSRC, 'libcotr_hip_exp.so')
 SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip',
-           'dense_post.hip', 'ffn.hip', 'train.hip', 'attention_train.hip', 'api.hip']
+           'dense_post.hip', 'ffn.hip', 'ffn_rows.hip', 'train.hip', 'attention_train.hip', 'api.hip']
 EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip'), os.path.join('experimental', 'gemm_pp.hip'),
                os.path.join('experimental', 'gemm_h2.hip'), os.path.join('experimental', 'attention_h2.hip'), os.path.join('experimental', 'gemm_h2r.hip')]
 # Pillow-exact resamples and the torch-CPU-exact cycle map (8-bit, float and double code whose products must not be contracted into

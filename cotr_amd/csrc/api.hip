@@ -90,6 +90,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"bottleneck_max_pairs", 4, 0, INT_MAX},
     {"train_attention_form", 0, 0, 3},
     {"attention_resident", 1, 0, 1},
+    {"ffn_rows_min_rows", 8192, 0, INT_MAX},
 #ifdef COTR_EXPERIMENTAL
     {"head_fusion_max_rows", 0, 0, INT_MAX},
     {"ffn_preln", 0, 0, 1},
@@ -420,6 +421,15 @@ int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float
 #include "experimental/api_exp.inc"   // the measured dead ends: hooks exp_ffn_block / exp_encoder_layer / exp_decoder_layer / exp_decoder_head
 #endif
 
+// The FFN block as ONE launch (ffn_rows.hip): from knob ffn_rows_min_rows rows on, where its 64-row tiles - one workgroup per CU,
+// 256 CUs - fill their last round of the chip to at least 3/4 (500 tiles of 32 x 1000 rows: 0.98; 313 tiles of 20 000 rows: 0.61 ->
+// the three launches, whose tiles are finer)
+bool ffn_rows_applies(int M) {
+  if (M < knob(KN_FFN_ROWS_MIN_ROWS) || M <= knob(KN_FFN_FUSION_MAX_ROWS)) return false;
+  const long tiles = (M + 63) / 64, rounds = (tiles + 255) / 256;
+  return tiles * 4 >= rounds * 256 * 3;
+}
+
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
 // Up to knob ffn_fusion_max_rows rows: ONE fused launch that keeps the hidden activations on the CU and writes per-chunk
 // partial outputs + ln_reduce (sum, bias, residual, norm [, a second norm: decoder.norm after the last layer]); above: linear1,
@@ -430,6 +440,12 @@ int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, c
 #ifdef COTR_EXPERIMENTAL
   if (const int rx = exp_ffn_block(h, x, l1w, l1b, l2w, l2b, nw, nb, hid, tmp, y, M, s, post_w, post_b)) return rx < 0 ? rx : COTR_OK;
 #endif
+  if (ffn_rows_applies(M) && y != x) {
+    // many rows: the whole block - linear1, ReLU, linear2, bias, residual, norm [, decoder.norm] - in one launch (ffn_rows.hip)
+    KCHK(h, launch_ffn_rows(x, l1w, l1b, l2w, l2b, nw, nb, post_w, post_b, y, M, s), "ffn_rows");
+    if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_rows %d rows", M); prof_mark(h, nm, s, 2); }
+    return COTR_OK;
+  }
   if (post_w != nullptr || M <= knob(KN_FFN_FUSION_MAX_ROWS)) {
     const int nch = ffn_fused_chunks(M);
     KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
@@ -1123,7 +1139,11 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       prof_mark(h, "attention dec", s, 2);
       if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, tgt_in, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
       if ((r = layernorm(h, d.pre2, w.n2w, w.n2b, d.t2, R, s))) return r;
-      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, d.tgt, R, s))) return r;
+      // (many rows, last layer: decoder.norm rides in the one-launch FFN block's epilogue; pre2 = the normed 'hs')
+      const bool post = li + 1 == L && ffn_rows_applies(R);
+      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
+                         post ? h->dn_w : nullptr, post ? h->dn_b : nullptr))) return r;
+      hs_normed = post;
     }
   }
   // decoder.norm + corr_embed on the last layer only (the reference computes all 6 and keeps [-1])
@@ -1794,5 +1814,11 @@ int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const fl
 }
 
 int cotr_op_ffn_chunks(int M) { return ffn_fused_chunks(M); }
+
+// the same block in ONE launch for many rows (ffn_rows.hip); post_w / post_b: optional second LayerNorm (decoder.norm); y != x
+int cotr_op_ffn_rows(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
+                     const float* ln_b, const float* post_w, const float* post_b, float* y, int M, cotr_stream stream) {
+  return op_ret(launch_ffn_rows(x, w1, b1, w2, b2, ln_w, ln_b, post_w, post_b, y, M, static_cast<hipStream_t>(stream)));
+}
 
 }  // extern "C"

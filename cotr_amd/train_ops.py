@@ -411,7 +411,7 @@ def _perm_dtype():
 class _Derived:
     def __init__(self):
         self.entries = {}      # key -> entry dict
-        self.table = None      # (signature, device table tensor, njobs, ntiles) of the last full refresh
+        self.tables = {}       # device -> (signature, device table tensor, byte offset of the tile map, njobs, ntiles) of its last full refresh
 
     def get(self, base, view, kind, scale, spec, shape):
         """The derived operand of ``view`` (a view of parameter ``base``), current with respect to the parameter."""
@@ -427,7 +427,7 @@ class _Derived:
                  'scale_ref': None if scale is None else weakref.ref(scale), 'scale': 0 if scale is None else scale.data_ptr(),
                  'fresh': False, 'device': view.device}
             self.entries[key] = e
-            self.table = None
+            self.tables.pop(view.device, None)
         if not e['fresh'] or e['version'] != base._version:
             self._run([e], cache=False)
             e['fresh'], e['version'] = True, base._version
@@ -453,9 +453,14 @@ class _Derived:
             return
         dev = entries[0]['device']
         sig = tuple((e['src'], e['dst'].data_ptr(), e['scale']) for e in entries)
-        if cache and self.table is not None and self.table[0] == sig:
-            _, table, off, njobs, ntiles = self.table
+        cached = self.tables.get(dev) if cache else None
+        if cached is not None and cached[0] == sig:
+            _, table, off, njobs, ntiles = cached
         else:
+            # a miss allocates, pins and uploads a job table: not something a stream capture may contain (a captured step must find
+            # every operand registered and its device's table cached - GraphedTrainStep warms up eagerly for exactly that)
+            if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('a derived weight operand was registered or its job table rebuilt during stream capture')
             raw, off, njobs, ntiles = self._build(entries)
             host = torch.from_numpy(raw)
             if dev.type == 'cuda':
@@ -467,7 +472,7 @@ class _Derived:
                 host_keep[1].record()
                 self._staging = getattr(self, '_staging', [])[-8:] + [host_keep]
             if cache:
-                self.table = (sig, table, off, njobs, ntiles)
+                self.tables[dev] = (sig, table, off, njobs, ntiles)
         lib = _lib.load_library()
         with _on(dev):
             base = table.data_ptr()
@@ -480,12 +485,12 @@ class _Derived:
         live = [e for e in live if e['scale_ref'] is None or e['scale_ref']() is not None]
         if len(live) != len(self.entries):
             self.entries = {k: v for k, v in self.entries.items() if any(v is e for e in live)}
-            self.table = None
+            self.tables = {}
         by_dev = {}
         for e in live:
             by_dev.setdefault(e['device'], []).append(e)
         for dev_entries in by_dev.values():
-            self._run(dev_entries, cache=len(by_dev) == 1)
+            self._run(dev_entries, cache=True)                             # one cached table per device
         for e in live:
             e['fresh'], e['version'] = True, e['ref']()._version
         return len(live)
@@ -497,7 +502,17 @@ class _Derived:
                 e['fresh'] = False
 
     def clear(self):
-        self.entries, self.table = {}, None
+        self.entries, self.tables = {}, {}
+
+    def hold(self):
+        """Strong references to everything a captured step has baked the ADDRESS of into its graph: the destination buffers of the
+        registered operands and the cached job tables.  Whoever replays such a graph keeps this list alive (GraphedTrainStep):
+        a later miss, refresh or clear_weight_cache() then only drops the registry's own references, never the memory."""
+        keep = [e['dst'] for e in self.entries.values()]
+        keep += [t[1] for t in self.tables.values()]
+        if getattr(self, '_last_table', None) is not None:
+            keep.append(self._last_table)
+        return keep
 
 
 _derived = _Derived()
@@ -516,6 +531,11 @@ def refresh_derived():
 
 def derived_keys():
     return tuple(_derived.entries)
+
+
+def hold_derived():
+    """References that keep every registered operand buffer and job table alive (for a captured step: its graph holds their addresses)."""
+    return _derived.hold()
 
 
 def mark_derived_stale(keep=()):

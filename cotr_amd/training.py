@@ -484,6 +484,9 @@ class GraphedTrainStep:
         if self.sink is not None:
             self.sink.frozen = True                        # the graph replays its table upload from the sink's pinned buffer
         self._derived_keys = T.derived_keys()              # what a replay keeps current by itself (it re-derives them behind its update)
+        # ... and the graph holds the ADDRESSES of their buffers and of the cached job table: keep them alive for as long as it can
+        # be replayed, whatever a later miss, refresh or clear_weight_cache() does to the registry (released in close())
+        self._derived_hold = T.hold_derived()
 
     def _body(self):
         self.salt.add_(0x3C6EF35F)                         # a new mask family per step (int32 wrap-around is fine)
@@ -535,6 +538,7 @@ class GraphedTrainStep:
                 pass
             self.salt = None
             self.graph = None          # (the captured step writes the salt word: it must not be replayed after this)
+            self._derived_hold = None  # the graph is gone: the operand buffers / job table it addressed may go too
             try:
                 self.model.unpin_workspace(self)
             except Exception:

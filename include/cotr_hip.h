@@ -164,6 +164,10 @@ int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, 
 int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
                       const float* ln_b, float* scratch, float* y, int M, cotr_stream stream);
 int cotr_op_ffn_chunks(int M);
+/* the same block in ONE launch for many rows (ffn_rows.hip: transformer.py:156-158 / 199-201 [+ :110-111 with post_w / post_b, a
+ * second LayerNorm of the result]); y must not alias x */
+int cotr_op_ffn_rows(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
+                     const float* ln_b, const float* post_w, const float* post_b, float* y, int M, cotr_stream stream);
 /* lin_sine encoding of pts [n,2] -> y [n,256] (COTR/models/position_encoding.py:41-45) */
 int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
 

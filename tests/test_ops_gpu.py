@@ -346,6 +346,56 @@ def test_fused_ffn_block(M):
     assert e < 2e-5, e
 
 
+@pytest.mark.parametrize('M,post', [(64, False), (100, True), (8192, False), (20001, True)])
+def test_ffn_rows_one_launch(M, post):
+    """ffn_rows.hip: the whole block - linear1, ReLU, linear2, bias, residual, LayerNorm [, decoder.norm] - in ONE launch for many rows
+    (transformer.py:156-158 / 199-201, :110-111); ragged last tile; the same launch twice gives the same bits."""
+    from cotr_amd import _lib
+    g = _g(M + 7)
+    x = torch.randn(M, 256, generator=g)
+    w1, b1 = torch.randn(1024, 256, generator=g) / 16, torch.randn(1024, generator=g) * 0.1
+    w2, b2 = torch.randn(256, 1024, generator=g) / 32, torch.randn(256, generator=g) * 0.1
+    lw, lb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    pw, pb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    ref = F.layer_norm(x.double() + F.linear(F.relu(F.linear(x.double(), w1.double(), b1.double())), w2.double(), b2.double()), (256,),
+                       lw.double(), lb.double(), 1e-5)
+    if post:
+        ref = F.layer_norm(ref, (256,), pw.double(), pb.double(), 1e-5)
+    d = G.dev()
+    lib = _lib.load_library()
+    t = [v.to(d) for v in (x, w1, b1, w2, b2, lw, lb)]
+    pp = [pw.to(d), pb.to(d)] if post else [None, None]
+    y = torch.full((M + 1, 256), 7.0, device=d)           # one guard row behind the output
+    y2 = torch.empty(M, 256, device=d)
+    assert lib.cotr_op_ffn_rows(*[G.P(v) for v in t], G.P(pp[0]), G.P(pp[1]), G.P(y), M, G.sptr()) == 0
+    assert lib.cotr_op_ffn_rows(*[G.P(v) for v in t], G.P(pp[0]), G.P(pp[1]), G.P(y2), M, G.sptr()) == 0
+    e = G.rel_err(y[:M], ref)
+    assert e < 2e-5, e
+    assert torch.equal(y[:M], y2)
+    assert bool((y[M] == 7.0).all()), 'rows past M were written'
+    # y must not alias x
+    assert lib.cotr_op_ffn_rows(G.P(t[0]), *[G.P(v) for v in t[1:]], G.P(pp[0]), G.P(pp[1]), G.P(t[0]), M, G.sptr()) != 0
+
+
+def test_ffn_rows_passes_nan_like_the_reference():
+    """relu(NaN) = NaN in torch; a NaN row stays NaN, its neighbours are untouched (the engine raises on NaN, sparse_engine.py:54-55)."""
+    from cotr_amd import _lib
+    g = _g(3)
+    M = 130
+    x = torch.randn(M, 256, generator=g)
+    x[65, 3] = float('nan')
+    w1, b1 = torch.randn(1024, 256, generator=g) / 16, torch.randn(1024, generator=g) * 0.1
+    w2, b2 = torch.randn(256, 1024, generator=g) / 32, torch.randn(256, generator=g) * 0.1
+    lw, lb = torch.ones(256), torch.zeros(256)
+    d = G.dev()
+    t = [v.to(d) for v in (x, w1, b1, w2, b2, lw, lb)]
+    y = torch.empty(M, 256, device=d)
+    assert _lib.load_library().cotr_op_ffn_rows(*[G.P(v) for v in t], None, None, G.P(y), M, G.sptr()) == 0
+    y = y.cpu()
+    assert bool(torch.isnan(y[65]).all())
+    assert not bool(torch.isnan(y[:65]).any()) and not bool(torch.isnan(y[66:]).any())
+
+
 # ---- every launch configuration of the GEMM / implicit-GEMM kernels on the same problem -----------------------------
 def _cfgs():
     """every GEMM configuration of the loaded library that takes fp32 operands (46 - 51 of the experimental library take packed
