@@ -18,12 +18,17 @@ LIB = os.path.join(CSRC, 'libcotr_hip.so')
 # product path; tests/test_experimental_gpu.py and the A/B tools select it with COTR_HIP_EXPERIMENTAL=1.
 LIB_EXP = os.path.join(CSRC, 'libcotr_hip_exp.so')
 SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip',
-           'dense_post.hip', 'ffn.hip', 'ffn_rows.hip', 'train.hip', 'attention_train.hip', 'api.hip']
+           'dense_post.hip', 'ffn.hip', 'ffn_rows.hip', 'att_rows.hip', 'train.hip', 'attention_train.hip', 'api.hip']
 EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip'), os.path.join('experimental', 'gemm_pp.hip'),
                os.path.join('experimental', 'gemm_h2.hip'), os.path.join('experimental', 'attention_h2.hip'), os.path.join('experimental', 'gemm_h2r.hip')]
 # Pillow-exact resamples and the torch-CPU-exact cycle map (8-bit, float and double code whose products must not be contracted into
 # FMAs behind the source's back; the FMAs that belong there are explicit)
-EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ffp-contract=off']}
+EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ffp-contract=off'],
+               # att_rows.hip: matrix-instruction results in VGPRs, not AccVGPRs - its softmax VALU sits between the matrix instructions of ONE
+               # wavefront per SIMD, and any AccVGPR access (v_accvgpr_read / write) waits for the matrix instruction in flight: with the scores in
+               # AccVGPRs the softmax of a key block ran entirely BEHIND its 64 matrix instructions (K/V phase 205 k cycles against 131 k of matrix
+               # work, whatever the interleaving; profiles/r5_att_rows_probe.txt)
+               'att_rows.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 HEADERS = ['common.h', 'train.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
 EXP_HEADERS = [os.path.join('experimental', f) for f in ('coop_tail.h', 'experimental.h', 'api_exp.inc', 'gemm_h2.h')]
 # code-object v5: loadable by the ROCm 7.0 runtime torch bundles as well as by ROCm 7.2's

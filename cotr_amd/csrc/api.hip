@@ -90,6 +90,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"bottleneck_max_pairs", 4, 0, INT_MAX},
     {"train_attention_form", 0, 0, 3},
     {"attention_resident", 1, 0, 1},
+    {"att_rows_min_rows", 8192, 0, INT_MAX},
     {"ffn_rows_min_rows", 8192, 0, INT_MAX},
 #ifdef COTR_EXPERIMENTAL
     {"head_fusion_max_rows", 0, 0, INT_MAX},
@@ -428,6 +429,15 @@ bool ffn_rows_applies(int M) {
   if (M < knob(KN_FFN_ROWS_MIN_ROWS) || M <= knob(KN_FFN_FUSION_MAX_ROWS)) return false;
   const long tiles = (M + 63) / 64, rounds = (tiles + 255) / 256;
   return tiles * 4 >= rounds * 256 * 3;
+}
+
+// The attention sub-layer as ONE launch (att_rows.hip): from knob att_rows_min_rows query rows on, where its 64-query tiles (per
+// pair) fill the last round of the 256 CUs to at least 3/4 and a pair's last tile is not mostly padding
+bool att_rows_applies(int nb, int nq) {
+  const long R = (long)nb * nq;
+  if (R < knob(KN_ATT_ROWS_MIN_ROWS) || R <= knob(KN_ATTENTION_FUSION_MAX_ROWS)) return false;
+  const long tpp = (nq + 63) / 64, tiles = tpp * nb, rounds = (tiles + 255) / 256;
+  return tiles * 4 >= rounds * 256 * 3 && (long)nq * 8 >= tpp * 64 * 7;
 }
 
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
@@ -1001,6 +1011,11 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
 #endif
         KCHK(h, launch_ln_reduce(t_part, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
         prof_mark(h, "ln_reduce heads", s, 2);
+      } else if (att_rows_applies(Bc, TOK)) {
+        // many rows: attention, out_proj, residual and norm1 in one launch (att_rows.hip)
+        KCHK(h, launch_att_rows(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D, e.out_w, e.out_b,
+                                xin, e.n1w, e.n1b, t_x1, Bc, TOK, s), "att_rows");
+        prof_mark(h, "att_rows enc", s, 2);
       } else {
         KCHK(h, launch_attention(t_qkv, 3 * D, t_qkv + D, t_qkv + 2 * D, 3 * D, t_ao, D, Bc, TOK, s), "attention");
         prof_mark(h, "attention enc", s, 2);
@@ -1100,7 +1115,8 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   fused = fused && !knob(KN_FFN_PRELN);
 #endif
   bool hs_normed = false;
-  if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s, fused))) return r;
+  const bool rows = !fused && att_rows_applies(nb, nq);   // many rows: q projection, attention, out_proj, residual, norm2 in one launch
+  if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s, fused || rows))) return r;
   // transformer.py:185-201 per layer (cross-attention only, post-norm)
   for (int li = 0; li < L; ++li) {
     const DecW& w = h->dec[li];
@@ -1133,12 +1149,18 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
                          post ? h->dn_w : nullptr, post ? h->dn_b : nullptr))) return r;
       hs_normed = post;
     } else {
-      // q = Wq(tgt + query_pos) * 32^-0.5 (layer 0: computed by dec_prologue)
-      if (li > 0 && (r = linear(h, d.tgt, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s))) return r;
-      KCHK(h, launch_attention(d.q, D, kl, kl + D, KVLD, d.ao, D, nb, nq, s), "attention");
-      prof_mark(h, "attention dec", s, 2);
-      if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, tgt_in, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
-      if ((r = layernorm(h, d.pre2, w.n2w, w.n2b, d.t2, R, s))) return r;
+      if (rows) {
+        KCHK(h, launch_att_rows(nullptr, 0, tgt_in, d.qpos, w.q_w, w.q_b, QSCALE, kl, kl + D, KVLD, w.out_w, w.out_b, tgt_in, w.n2w, w.n2b,
+                                d.t2, nb, nq, s), "att_rows");
+        prof_mark(h, "att_rows dec", s, 2);
+      } else {
+        // q = Wq(tgt + query_pos) * 32^-0.5 (layer 0: computed by dec_prologue)
+        if (li > 0 && (r = linear(h, d.tgt, d.qpos, 0, 1, 1, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, R, D, D, s))) return r;
+        KCHK(h, launch_attention(d.q, D, kl, kl + D, KVLD, d.ao, D, nb, nq, s), "attention");
+        prof_mark(h, "attention dec", s, 2);
+        if ((r = linear(h, d.ao, nullptr, 0, 1, 0, w.out_w, w.out_b, tgt_in, 0, 1.f, 0, d.pre2, R, D, D, s))) return r;
+        if ((r = layernorm(h, d.pre2, w.n2w, w.n2b, d.t2, R, s))) return r;
+      }
       // (many rows, last layer: decoder.norm rides in the one-launch FFN block's epilogue; pre2 = the normed 'hs')
       const bool post = li + 1 == L && ffn_rows_applies(R);
       if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
@@ -1814,6 +1836,15 @@ int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const fl
 }
 
 int cotr_op_ffn_chunks(int M) { return ffn_fused_chunks(M); }
+
+// the attention sub-layer in ONE launch for many rows (att_rows.hip): y = LN(residual + out_proj(MHA(q, k, v)) + bo); q [rows][ldq]
+// given pre-scaled (wq == NULL) or projected here: q = ((x + x2) . wq^T + bq) * qscale (x may be NULL); residual may be NULL
+int cotr_op_att_rows(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq, float qscale,
+                     const float* k, const float* v, int ldkv, const float* wo, const float* bo, const float* residual,
+                     const float* ln_w, const float* ln_b, float* y, int nb, int nq, cotr_stream stream) {
+  return op_ret(launch_att_rows(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, wo, bo, residual, ln_w, ln_b, y, nb, nq,
+                                static_cast<hipStream_t>(stream)));
+}
 
 // the same block in ONE launch for many rows (ffn_rows.hip); post_w / post_b: optional second LayerNorm (decoder.norm); y != x
 int cotr_op_ffn_rows(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,

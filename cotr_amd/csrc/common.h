@@ -68,6 +68,7 @@ enum KnobId {
   KN_BOTTLENECK_MAX_PAIRS,       // layer1 bottlenecks as one launch each up to this many pairs per pass (-4.3 % at 1 pair, +1.4 % at 32)
   KN_TRAIN_ATTENTION_FORM,       // training attention backward: 0 = by shape, 1-3 = force a form
   KN_ATTENTION_RESIDENT,         // K_h / V_h resident in LDS (attention_res_kernel) for many rows
+  KN_ATT_ROWS_MIN_ROWS,          // attention sub-layer ([q projection,] attention, out projection, residual, LayerNorm) as ONE launch (att_rows.hip) from this many query rows
   KN_FFN_ROWS_MIN_ROWS,          // FFN block + residual + LayerNorm as ONE launch (ffn_rows.hip: 64-row tiles, hidden units dealt to the wavefronts) from this many rows
 #ifdef COTR_EXPERIMENTAL
   KN_HEAD_FUSION_MAX_ROWS,       // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower; 0)
@@ -299,6 +300,11 @@ int launch_ln_reduce(const float* parts, int np, const float* bias, const float*
 // the FFN block for many rows in one launch (ffn_rows.hip): Y = [LN_post] LN(X + W2 relu(W1 X + b1) + b2); Y != X
 int launch_ffn_rows(const float* X, const float* W1, const float* b1, const float* W2, const float* b2, const float* ln_w,
                     const float* ln_b, const float* post_w, const float* post_b, float* Y, int M, hipStream_t s);
+// the attention sub-layer for many rows in one launch (att_rows.hip): Y = LN(residual + out_proj(MHA(q, K, V)) + bo); q given
+// (wq == nullptr) or projected from x (+ x2)
+int launch_att_rows(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq, float qscale,
+                    const float* k, const float* v, int ldkv, const float* wo, const float* bo, const float* residual,
+                    const float* ln_w, const float* ln_b, float* Y, int nb, int nq, hipStream_t s);
 // one whole layer1 bottleneck in one launch (bottleneck.hip); w2p / w3p / wdp are the packed fragment arrays (bottleneck_pack_*)
 int launch_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2p, const float* w3p, const float* wdp,
                       const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,

@@ -164,6 +164,13 @@ int cotr_op_layernorm(const float* x, const float* w, const float* b, float* y, 
 int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
                       const float* ln_b, float* scratch, float* y, int M, cotr_stream stream);
 int cotr_op_ffn_chunks(int M);
+/* the attention sub-layer in ONE launch for many rows (att_rows.hip: transformer.py:149-155 encoder, :192-198 decoder):
+ * y = LayerNorm(residual + out_proj(MHA(q, k, v)) + bo), 8 heads of 32, 512 keys per pair; q [nb*nq][ldq] given pre-scaled by
+ * 32^-0.5 (wq == NULL), or projected here: q = ((x + x2) . wq^T + bq) * qscale (x may be NULL: decoder layer 0).  residual may be
+ * NULL; y must not alias residual / x / x2 / q */
+int cotr_op_att_rows(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq, float qscale,
+                     const float* k, const float* v, int ldkv, const float* wo, const float* bo, const float* residual,
+                     const float* ln_w, const float* ln_b, float* y, int nb, int nq, cotr_stream stream);
 /* the same block in ONE launch for many rows (ffn_rows.hip: transformer.py:156-158 / 199-201 [+ :110-111 with post_w / post_b, a
  * second LayerNorm of the result]); y must not alias x */
 int cotr_op_ffn_rows(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,

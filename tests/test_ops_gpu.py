@@ -396,6 +396,71 @@ def test_ffn_rows_passes_nan_like_the_reference():
     assert not bool(torch.isnan(y[:65]).any()) and not bool(torch.isnan(y[66:]).any())
 
 
+def _att_rows_ref(q, k, v, wo, bo, res, lw, lb, nb, nq):
+    """fp64 reference: q [nb*nq, 256] (pre-scaled), k / v [nb*512, 256] -> LN(res + out_proj(MHA))."""
+    qh = q.double().view(nb, nq, 8, 32).permute(0, 2, 1, 3)
+    kh = k.double().view(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    vh = v.double().view(nb, 512, 8, 32).permute(0, 2, 1, 3)
+    o = (torch.softmax(qh @ kh.transpose(-1, -2), dim=-1) @ vh).permute(0, 2, 1, 3).reshape(nb * nq, 256)
+    y = F.linear(o, wo.double(), bo.double())
+    if res is not None:
+        y = y + res.double()
+    return F.layer_norm(y, (256,), lw.double(), lb.double(), 1e-5)
+
+
+@pytest.mark.parametrize('nb,nq,qp,with_x,with_res', [(2, 64, False, False, True), (3, 100, True, True, True), (2, 512, False, False, True),
+                                                        (1, 1000, True, False, False), (5, 130, True, True, True)])
+def test_att_rows_one_launch(nb, nq, qp, with_x, with_res):
+    """att_rows.hip: [q projection,] 8-head attention over the pair's 512 keys, out projection, residual and LayerNorm in ONE launch
+    (transformer.py:149-155 / 192-198); K / V are column slices of a wider matrix as in the hoisted decoder K/V cache; ragged last
+    tile of a pair; the same launch twice gives the same bits."""
+    from cotr_amd import _lib
+    g = _g(nb * 1000 + nq)
+    R = nb * nq
+    scale = 32 ** -0.5
+    kvw = torch.randn(nb * 512, 768, generator=g)           # [.. | K | V] columns: ldkv = 768, K at 256, V at 512
+    k, v = kvw[:, 256:512], kvw[:, 512:768]
+    wo, bo = torch.randn(256, 256, generator=g) / 16, torch.randn(256, generator=g) * 0.1
+    lw, lb = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    res = torch.randn(R, 256, generator=g) if with_res else None
+    d = G.dev()
+    lib = _lib.load_library()
+    kvd = kvw.to(d)
+    if qp:
+        x2 = torch.randn(R, 256, generator=g)
+        x = torch.randn(R, 256, generator=g) if with_x else None
+        wq, bq = torch.randn(256, 256, generator=g) / 16, torch.randn(256, generator=g) * 0.1
+        xin = x2.double() + (x.double() if x is not None else 0)
+        q = (F.linear(xin, wq.double(), bq.double()) * scale).float()
+        args_q = [None, 0, G.P(x.to(d)) if x is not None else None, None, None, None]
+        keep = [x2.to(d), wq.to(d), bq.to(d)]
+        args_q[3], args_q[4], args_q[5] = G.P(keep[0]), G.P(keep[1]), G.P(keep[2])
+        if x is not None:
+            keep.append(x.to(d))
+            args_q[2] = G.P(keep[-1])
+    else:
+        qw = torch.randn(R, 768, generator=g) * 0.5           # q columns of a packed projection: ldq = 768
+        q = qw[:, :256]
+        keep = [qw.to(d)]
+        args_q = [G.P(keep[0]), 768, None, None, None, None]
+    ref = _att_rows_ref(q, k, v, wo, bo, res, lw, lb, nb, nq)
+    t = [wo.to(d), bo.to(d), lw.to(d), lb.to(d)]
+    resd = res.to(d) if res is not None else None
+    y = torch.full((R + 1, 256), 7.0, device=d)
+    y2 = torch.empty(R, 256, device=d)
+    import ctypes
+    kp = ctypes.c_void_p(kvd.data_ptr() + 256 * 4)
+    vp = ctypes.c_void_p(kvd.data_ptr() + 512 * 4)
+    for out in (y, y2):
+        rc = lib.cotr_op_att_rows(*args_q, scale, kp, vp, 768, G.P(t[0]), G.P(t[1]), G.P(resd), G.P(t[2]), G.P(t[3]), G.P(out), nb, nq,
+                                  G.sptr())
+        assert rc == 0, rc
+    e = G.rel_err(y[:R], ref)
+    assert e < 2e-5, e
+    assert torch.equal(y[:R], y2)
+    assert bool((y[R] == 7.0).all()), 'rows past the last pair were written'
+
+
 # ---- every launch configuration of the GEMM / implicit-GEMM kernels on the same problem -----------------------------
 def _cfgs():
     """every GEMM configuration of the loaded library that takes fp32 operands (46 - 51 of the experimental library take packed
