@@ -273,6 +273,10 @@ def research_split_f16_child():
             key = 'fp32_mfma' if level == 0 else 'split_f16'
             out.setdefault(tag, {})[key] = {'ms_per_call': dt * 1e3, 'query_corr_per_s': b * q / dt, 'pairs_per_s': b / dt,
                                             'fp32_equivalent_tflops': flop(b, q) / dt / 1e12}
+            if level:   # against ITS OWN roofline: 2517 TFLOP/s of dense f16 MFMA / 3 matrix instructions per fp32 product
+                eq = flop(b, q) / dt / 1e12
+                out[tag][key]['roofline'] = {'bound': 'mfma (f16, three instructions per fp32 product)', 'achieved': eq, 'peak': 839.0,
+                                             'unit': 'TFLOP/s fp32-equivalent', 'frac': eq / 839.0}
         d = (res[0] - res[3]).abs() * torch.tensor([512.0, 256.0], device=dev)
         out[tag]['max_px_between_the_two_paths'] = float(d.max())
         out[tag]['speedup'] = out[tag]['fp32_mfma']['ms_per_call'] / out[tag]['split_f16']['ms_per_call']
@@ -285,7 +289,8 @@ def research_split_f16():
     note = ('RESEARCH, opt-in (knob split_f16 of libcotr_hip_exp.so, off by default, never on the product path): every fp32 product of the '
             'large GEMMs / convolutions / attention products (level 3) as three v_mfma_f32_32x32x16_f16 on packed split-f16 tensors (hi = f16(a), lo = f16((a - hi) * 2^11)); '
             'as close to the fp64 truth as the fp32-MFMA path on all 9 goldens of the reference (tests/test_experimental_gpu.py), not '
-            'bit-identical to it, range-limited to |x| < 65504; "fp32_equivalent_tflops" counts the fp32 work and is NOT a fraction of any roofline')
+            'bit-identical to it, range-limited to |x| < 65504; "fp32_equivalent_tflops" counts the fp32 work; its own roofline is 2517 / 3 = 839 '
+            'TFLOP/s-equivalent (dense f16 MFMA peak over three matrix instructions per product): "roofline.frac" of each split_f16 entry')
     try:
         env = dict(os.environ, COTR_HIP_EXPERIMENTAL='1')
         p = subprocess.run([sys.executable, os.path.abspath(__file__), '--research-child'], env=env, capture_output=True, text=True, timeout=240)
@@ -513,10 +518,10 @@ def dry_run(args, world, rank):
     fake = lambda i, q: {'pred_corrs': q * 0.5 + i.mean(dim=(1, 2, 3)).view(-1, 1, 1)}
     finish = None
     if dense:
-        # ONE pair, a stand-in grid of 1031 queries (not a multiple of the world size), sharded by PairShardedModel exactly as the
-        # real workload's 131072: every rank holds the same inputs, decodes its slice, the all-gather is inside the step
+        # ONE pair, a stand-in grid of --dry-queries queries (default 1031: not a multiple of the world size; 131072 = the real
+        # workload's grid), sharded by PairShardedModel exactly as the real workload: every rank holds the same inputs, decodes its slice, the all-gather is inside the step
         from cotr_amd.dist import PairShardedModel
-        img, qs = torch.randn(1, 3, 16, 32, generator=g), torch.rand(1, 1031, 2, generator=g)
+        img, qs = torch.randn(1, 3, 16, 32, generator=g), torch.rand(1, args.dry_queries, 2, generator=g)
         calls = []
 
         def counted(i, q):
@@ -593,8 +598,11 @@ def main():
                     help='roofline.traffic: measured by a rocprofv3 --pmc child of this run (auto: when available, N == 1, extras '
                          'on), or the committed profile')
     ap.add_argument('--traffic-child', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--research', action='store_true',
+                    help='also time the RESEARCH path (knob split_f16 of libcotr_hip_exp.so) in a child process and report it as a named secondary entry')
     ap.add_argument('--research-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl', help='torch.distributed backend (nccl = RCCL; gloo with --dry-run)')
+    ap.add_argument('--dry-queries', type=int, default=1031, help='--dry-run --workload dense: queries of the stand-in pair (131072 = the real grid)')
     ap.add_argument('--dry-run', action='store_true',
                     help='CPU plumbing check (tests): stand-in model, same launch / barrier / timing / gather / JSON code; never a measurement')
     ap.add_argument('--stage', type=int, choices=[1, 2], default=2,
@@ -797,7 +805,8 @@ def main():
             line['also_measured'] = other_regimes(synth_state_dict(0), dev)
             roof['batched_frac'] = line['also_measured']['batch_32_pairs_x_1000_queries']['frac_of_fp32_mfma_peak']
             roof['batched_frac_note'] = 'same path at 32 pairs x 1000 queries per call (throughput regime)'
-            line['also_measured']['RESEARCH_split_f16_opt_in_not_the_product_path'] = research_split_f16()
+            if args.research:   # opt-in: the driver's run times the product only
+                line['also_measured']['RESEARCH_split_f16_opt_in_not_the_product_path'] = research_split_f16()
         if world == 1 and not args.no_cpu_baseline and not batch256 and not dense:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

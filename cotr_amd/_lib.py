@@ -224,6 +224,16 @@ def set_knob(name, value, handle=None):
     check(load_library().cotr_set_knob(_h(handle), name.encode(), int(value)), handle, f'cotr_set_knob({name}, {value})')
 
 
+def validate_knob(name, value):
+    """Raise CotrHipError unless the library's registry has the knob and accepts the value (tried on the process-wide set, which is put
+    back): what a model does with a knob set before its handle exists."""
+    lib = load_library()
+    cur, dflt = ctypes.c_int(), ctypes.c_int()
+    check(lib.cotr_get_knob(None, name.encode(), ctypes.byref(cur), ctypes.byref(dflt)), None, f'cotr_get_knob({name})')
+    check(lib.cotr_set_knob(None, name.encode(), int(value)), None, f'cotr_set_knob({name}, {value})')
+    check(lib.cotr_set_knob(None, name.encode(), cur.value), None, f'cotr_set_knob({name}, {cur.value})')
+
+
 def reset_knobs(handle=None):
     """Every knob of the set back to its shipped default (tests call this for the process-wide set after each GPU test)."""
     check(load_library().cotr_reset_knobs(_h(handle)), handle, 'cotr_reset_knobs')

@@ -13,10 +13,12 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcotr_hip.so')
-# the experimental build: the same sources with -DCOTR_EXPERIMENTAL plus csrc/experimental/*.hip - the measured dead ends (cooperative
-# tails, fused decoder head, GEMM + LayerNorm tile, FFN tail / pre-norm, three-stage large tiles) and their knobs.  Never loaded by the
-# product path; tests/test_experimental_gpu.py and the A/B tools select it with COTR_HIP_EXPERIMENTAL=1.
+# The research library (split-f16 products, the measured dead ends and their knobs): built with -DCOTR_EXPERIMENTAL from its OWN copies
+# of the translation units it changes (csrc/experimental/<name>, FORKED below) + the product's other translation units (which reach its
+# declarations through the redirect in common.h) + csrc/experimental/*.hip.  The product sources contain none of its code.  Never loaded
+# by the product path; tests/test_experimental_gpu.py and the A/B tools select it with COTR_HIP_EXPERIMENTAL=1.
 LIB_EXP = os.path.join(CSRC, 'libcotr_hip_exp.so')
+FORKED = ['gemm.hip', 'gemm_big.hip', 'attention.hip', 'pointwise.hip', 'ffn.hip', 'api.hip']
 SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip',
            'dense_post.hip', 'ffn.hip', 'ffn_rows.hip', 'att_rows.hip', 'train.hip', 'attention_train.hip', 'api.hip']
 EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip'), os.path.join('experimental', 'gemm_pp.hip'),
@@ -30,10 +32,29 @@ EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ff
                # work, whatever the interleaving; profiles/r5_att_rows_probe.txt)
                'att_rows.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 HEADERS = ['common.h', 'train.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
-EXP_HEADERS = [os.path.join('experimental', f) for f in ('coop_tail.h', 'experimental.h', 'api_exp.inc', 'gemm_h2.h')]
+EXP_HEADERS = [os.path.join('experimental', f) for f in ['coop_tail.h', 'experimental.h', 'api_exp.inc', 'gemm_h2.h', 'common_exp.h'] + FORKED]
 # code-object v5: loadable by the ROCm 7.0 runtime torch bundles as well as by ROCm 7.2's
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-mcode-object-version=5',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-mcode-object-version=5', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
+
+
+def declared_symbols(experimental=False):
+    """The C ABI: every function include/cotr_hip.h declares (the #ifdef COTR_EXPERIMENTAL block only for the experimental library)."""
+    import re
+    src = open(os.path.join(CSRC, '..', '..', 'include', 'cotr_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    if not experimental:
+        src = re.sub(r'#ifdef COTR_EXPERIMENTAL.*?#endif', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(cotr_[a-z0-9_]+)\s*\(', src)))
+
+
+def _version_script(objdir, experimental):
+    """A linker version script that exports exactly the header's names: kernel host stubs (_Z...), the thread-local knob / device
+    slots and every other internal symbol stay local - the shared object is a sealed C ABI."""
+    path = os.path.join(objdir, 'exports_exp.map' if experimental else 'exports.map')
+    with open(path, 'w') as f:
+        f.write('{\n  global:\n' + ''.join(f'    {n};\n' for n in declared_symbols(experimental)) + '  local:\n    *;\n};\n')
+    return path
 
 
 def _hipcc():
@@ -63,9 +84,10 @@ def build_library(force=False, verbose=False, experimental=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
-    for src in SOURCES + (EXP_SOURCES if experimental else []):
+    sources = [os.path.join('experimental', f) if f in FORKED else f for f in SOURCES] + EXP_SOURCES if experimental else SOURCES
+    for src in sources:
         obj = os.path.join(objdir, os.path.basename(src).replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + (['-DCOTR_EXPERIMENTAL'] if experimental else []) + EXTRA_FLAGS.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + (['-DCOTR_EXPERIMENTAL'] if experimental else []) + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -76,7 +98,7 @@ def build_library(force=False, verbose=False, experimental=False):
             raise RuntimeError(f'hipcc failed on {src}:\n{out}')
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + _version_script(objdir, experimental), '-o', lib] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}')

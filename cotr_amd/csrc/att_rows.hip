@@ -58,7 +58,7 @@ struct AttRowsParams {
 
 constexpr int AR_T = 8 * AR_BM * 32;                      // floats of the T tile
 constexpr int AR_RING = AR_NSLOT * AR_PIECE;
-constexpr int AR_MAIN = AR_T + 4 * AR_RING + 2 * AR_D;    // T, rings, bq, (spare)
+constexpr int AR_MAIN = AR_T + 4 * AR_RING + 4 * AR_D;    // T, rings, then bq, bo, ln_w, ln_b (staged once: the epilogue reads them from LDS)
 constexpr int AR_EPI = AR_BM * AR_LDT;
 constexpr size_t kAttRowsSmem = (size_t)(AR_MAIN > AR_EPI ? AR_MAIN : AR_EPI) * sizeof(float);
 static_assert(kAttRowsSmem <= 160 * 1024, "LDS");
@@ -418,6 +418,9 @@ __global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p)
       ar_dma16(p.q + (row0 + (row < nvalid ? row : 0)) * p.ldq + kt * 32 + lch * 4, T + kt * (AR_BM * 32) + rg * 256);
     }
   }
+  bqs[AR_D + t] = p.bo[t];
+  bqs[2 * AR_D + t] = p.ln_w[t];
+  bqs[3 * AR_D + t] = p.ln_b[t];
   ArIter<QP> it;
   it.init();
 #pragma unroll
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       x[c] = *reinterpret_cast<const f32x4*>(smem + row * AR_LDT + c * 32 + eseg);
-      x[c] += *reinterpret_cast<const f32x4*>(p.bo + c * 32 + eseg);
+      x[c] += *reinterpret_cast<const f32x4*>(bqs + AR_D + c * 32 + eseg);
       x[c] += xr[mb][c];
       s1 += (x[c][0] + x[c][1]) + (x[c][2] + x[c][3]);
     }
@@ -593,8 +596,8 @@ __global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p)
       float* dst = p.Y + (row0 + row) * AR_D + eseg;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const f32x4 lw = *reinterpret_cast<const f32x4*>(p.ln_w + c * 32 + eseg);
-        const f32x4 lb = *reinterpret_cast<const f32x4*>(p.ln_b + c * 32 + eseg);
+        const f32x4 lw = *reinterpret_cast<const f32x4*>(bqs + 2 * AR_D + c * 32 + eseg);
+        const f32x4 lb = *reinterpret_cast<const f32x4*>(bqs + 3 * AR_D + c * 32 + eseg);
         f32x4 out;
 #pragma unroll
         for (int e = 0; e < 4; ++e) out[e] = x[c][e] * rstd * lw[e] + lb[e];

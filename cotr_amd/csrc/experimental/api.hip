@@ -1,3 +1,5 @@
+// RESEARCH LIBRARY COPY of csrc/api.hip (libcotr_hip_exp.so only): the product file with the research / dead-end paths that used to sit
+// behind #ifdef COTR_EXPERIMENTAL in it resolved IN (tools/unifdef_exp.py -D).  The product never compiles this file.
 // libcotr_hip.so - C ABI (include/cotr_hip.h), weight packing and the launch schedule of the COTR
 // correspondence-query forward path on one MI355X.
 //
@@ -24,9 +26,9 @@
 
 #include <limits.h>
 
-#include "../../include/cotr_hip.h"
-#include "common.h"
-#include "train.h"
+#include "../../../include/cotr_hip.h"
+#include "../common.h"
+#include "../train.h"
 
 int init_attention_attributes();
 void set_ffn_debug_times(unsigned long long* p);  // ffn.hip
@@ -82,12 +84,21 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"attention_wide_min_rows", 4096, 0, INT_MAX},
     {"attention_splits", 0, 0, 16},
     {"conv1x1_dense", 1, 0, 1},
-    {"ws_flags", 2, 0, 3},
+    {"ws_flags", 2, 0, 255},   // (bits 2-5: timing experiments of experimental/gemm_pp.hip)
     {"bottleneck_max_pairs", 4, 0, INT_MAX},
     {"train_attention_form", 0, 0, 3},
     {"attention_resident", 1, 0, 1},
     {"att_rows_min_rows", 8192, 0, INT_MAX},
     {"ffn_rows_min_rows", 8192, 0, INT_MAX},
+    {"head_fusion_max_rows", 0, 0, INT_MAX},
+    {"ffn_preln", 0, 0, 1},
+    {"ffn_tail", 0, 0, 1},
+    {"coop_tail", 0, 0, 1},
+    {"coop_tail_spin", 4000, 0, INT_MAX},
+    {"gemm_ln_min_rows", 1 << 30, 0, INT_MAX},
+    {"l2_warm", 0, 0, 3},
+    {"split_f16", 0, 0, 3},
+    {"split_f16_min_pairs", 8, 1, INT_MAX},
 };
 bool knob_value_ok(int id, int v) {
   if (v < kKnobs[id].lo || v > kKnobs[id].hi) return false;
@@ -115,6 +126,27 @@ struct cotr_ctx {
   size_t wfloats = 0;
   bool loaded = false;
   std::vector<ConvW> convs;  // execution order: stem, then per block conv1, conv2, conv3, [downsample]
+  // cooperative tails (experimental/coop_tail.h): generation-tagged arrival / claim words per row tile, and the launch counter that tags them
+  unsigned long long* tail_state = nullptr;
+  unsigned long long tail_gen = 0;
+  // RESEARCH, knob split_f16 (experimental/gemm_h2.h): the packed split-f16 image of wbuf (same offsets), built on first use; h2_pass is
+  // set while encode / decode walk a section whose activations are packed dwords instead of fp32
+  float* wbuf_h2 = nullptr;
+  size_t wbuf_h2_floats = 0;
+  bool wbuf_h2_valid = false;
+  bool h2_pass = false;
+  // level 2: linear() packs its fp32 input into h2_scr first; one-shot requests of the caller for the NEXT linear(): its input is packed
+  // already / its output is wanted packed (the hidden activations of an FFN block never exist in fp32)
+  Arena h2_scr;
+  bool h2_in_packed = false, h2_out_packed = false;
+  // level 3 (split-f16 attention): a packed copy of the cached decoder K / V of the current encode, made by the first decode that wants it
+  Arena kv_h2;
+  unsigned long long enc_serial = 0, kv_h2_serial = 0;
+  // the LayerNorm in front of a projection leaves the packed form of its output (+ h2_ln_add, one-shot: the decoder's query_pos) in
+  // h2_scr: linear() then finds its input packed (h2_prepacked_src / _add say of what) and skips its packing launch
+  const float* h2_prepacked_src = nullptr;
+  const float* h2_prepacked_add = nullptr;
+  const float* h2_ln_add = nullptr;
   // packed MFMA-fragment images of layer1's conv2 / conv3 / downsample weights for the fused bottleneck kernel (bottleneck.hip)
   struct FusedBlock { const float *w2p = nullptr, *w3p = nullptr, *wdp = nullptr; };
   FusedBlock l1_fused[3];
@@ -265,6 +297,9 @@ int tap_save(cotr_ctx* h, const char* name, const float* src, size_t n, hipStrea
   Arena& a = h->tap_store[name];
   int r = ensure(h, a, n);
   if (r) return r;
+  if (h->h2_pass) {
+    KCHK(h, launch_unsplit_h2(src, a.ptr, n, s), "unsplit_h2 (tap)");
+  } else
   HIPCHK(h, hipMemcpyAsync(a.ptr, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   h->taps[name] = {a.ptr, n};
   return COTR_OK;
@@ -278,6 +313,33 @@ GemmParams base_params() {
   return p;
 }
 
+// RESEARCH, knob split_f16: the packed image of a weight tensor of wbuf; the large-tile configuration for packed operands
+const float* h2_weight(const cotr_ctx* h, const float* w) { return h->wbuf_h2 + (w - h->wbuf); }
+constexpr int H2_MIN_ROWS = 8192;   // level 2 takes a projection from this many rows (the regime where the large tiles are the tuned pick anyway)
+// (tools/bench_split_f16.py, profiles/r4_split_f16_gemm_configs.txt: the wave-specialised form wins where a CU gets ONE deep tile, the
+// 128 x 64 tile where K is short and N wide, the plain 128 x 128 tile elsewhere)
+int h2_config(const GemmParams& p) {
+  if (p.N % 128 != 0) return 47;
+  const long tiles = (long)((p.M + 127) / 128) * (p.N / 128);
+  if (tiles < 256) return 47;
+  if (p.K >= 1024 && tiles <= 320) return 48;
+  if (p.K <= 256 && p.N >= 768) return 47;
+  return 46;
+}
+int h2_prepare_weights(cotr_ctx* h, hipStream_t s) {
+  if (h->wbuf_h2 && h->wbuf_h2_valid) return COTR_OK;
+  if (h->wbuf_h2 && h->wbuf_h2_floats < h->wfloats) {
+    HIPCHK(h, hipFree(h->wbuf_h2));
+    h->wbuf_h2 = nullptr;
+  }
+  if (!h->wbuf_h2) {
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->wbuf_h2), (h->wfloats + 4) * sizeof(float)));
+    h->wbuf_h2_floats = h->wfloats;
+  }
+  KCHK(h, launch_split_h2(h->wbuf, h->wbuf_h2, h->wfloats & ~(size_t)3, s), "split_h2 (weights)");
+  h->wbuf_h2_valid = true;
+  return COTR_OK;
+}
 
 // y[M,N] = epi( (x (+x2)) . w^T )
 int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_period, int a2_width,
@@ -290,17 +352,59 @@ int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_
   p.W = w; p.C = y; p.ldc = ldc ? ldc : N;
   p.bias = bias; p.residual = residual; p.ldr = N; p.res_row_mod = res_row_mod; p.relu = relu;
   p.colscale = colscale; p.colscale_n = colscale_n;
+  {  // RESEARCH, knob split_f16 (experimental/gemm_h2.h)
+    const bool in_packed = h->h2_pass || h->h2_in_packed, out_packed = h->h2_out_packed;
+    h->h2_in_packed = h->h2_out_packed = false;
+    h->h2_pass = false;   // a projection ends a packed backbone pass (input_proj): what follows it reads fp32
+    const bool simple_x2 = x2 == nullptr || (x2_row_mod == 0 && a2_period == 1 && a2_width == 1);
+    const bool level2 = knob(KN_SPLIT_F16) >= 2 && M >= H2_MIN_ROWS && N % 64 == 0 && K % 32 == 0 && simple_x2;
+    if (in_packed || level2) {
+      if (in_packed && x2 != nullptr) { h->err = "split_f16: the x + pos prologue is not available on packed operands"; return COTR_ERR_ARG; }
+      if (int r = h2_prepare_weights(h, s)) return r;
+      if (!in_packed) {   // x (+ x2) -> packed split-f16 copy, unless the LayerNorm that produced x left it already
+        const bool prepacked = K == D && x == h->h2_prepacked_src && x2 == h->h2_prepacked_add && h->h2_scr.cap >= (size_t)M * K;
+        h->h2_prepacked_src = nullptr;
+        if (!prepacked) {
+          if (int r = ensure(h, h->h2_scr, (size_t)M * K)) return r;
+          KCHK(h, launch_split_h2(x, h->h2_scr.ptr, (size_t)M * K, s, x2), "split_h2");
+          prof_mark(h, "split_h2", s, 2);
+        }
+        p.A = h->h2_scr.ptr;
+        p.A2 = nullptr;
+      }
+      p.W = h2_weight(h, w);
+      p.h2_flags = out_packed ? 1 : 0;
+      const int cfg = h2_config(p);
+      KCHK(h, launch_gemm_cfg(GEMM_DENSE, cfg, p, s), "linear (split f16)");
+      if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, cfg); prof_mark(h, nm, s, 2); }
+      return COTR_OK;
+    }
+    if (out_packed) { h->err = "split_f16: packed output requested from an fp32 launch"; return COTR_ERR_ARG; }
+  }
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, gemm_pick_config(GEMM_DENSE, p)); prof_mark(h, nm, s, 2); }
   return COTR_OK;
 }
 
 int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float* y, int M, hipStream_t s) {
+  {
+    const float* add = h->h2_ln_add;
+    h->h2_ln_add = nullptr;
+    if (knob(KN_SPLIT_F16) >= 2 && M >= H2_MIN_ROWS) {   // RESEARCH: its consumer is a split-f16 projection - leave the packed form too
+      if (int r = ensure(h, h->h2_scr, (size_t)M * D)) return r;
+      KCHK(h, launch_layernorm_h2(x, w, b, y, h->h2_scr.ptr, add, M, s), "layernorm (+ packed copy)");
+      prof_mark(h, "layernorm+pack", s, 2);
+      h->h2_prepacked_src = y;
+      h->h2_prepacked_add = add;
+      return COTR_OK;
+    }
+  }
   KCHK(h, launch_layernorm(x, w, b, y, M, s), "layernorm");
   prof_mark(h, "layernorm", s, 2);
   return COTR_OK;
 }
 
+#include "api_exp.inc"   // the measured dead ends: hooks exp_ffn_block / exp_encoder_layer / exp_decoder_layer / exp_decoder_head
 
 // The FFN block as ONE launch (ffn_rows.hip): from knob ffn_rows_min_rows rows on, where its 64-row tiles - one workgroup per CU,
 // 256 CUs - fill their last round of the chip to at least 3/4 (500 tiles of 32 x 1000 rows: 0.98; 313 tiles of 20 000 rows: 0.61 ->
@@ -327,6 +431,7 @@ bool att_rows_applies(int nb, int nq) {
 int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, const float* l2w, const float* l2b,
               const float* nw, const float* nb, float* hid, float* tmp, float* y, int M, hipStream_t s,
               const float* post_w = nullptr, const float* post_b = nullptr) {
+  if (const int rx = exp_ffn_block(h, x, l1w, l1b, l2w, l2b, nw, nb, hid, tmp, y, M, s, post_w, post_b)) return rx < 0 ? rx : COTR_OK;
   if (ffn_rows_applies(M) && y != x) {
     // many rows: the whole block - linear1, ReLU, linear2, bias, residual, norm [, decoder.norm] - in one launch (ffn_rows.hip)
     KCHK(h, launch_ffn_rows(x, l1w, l1b, l2w, l2b, nw, nb, post_w, post_b, y, M, s), "ffn_rows");
@@ -367,6 +472,7 @@ GemmParams conv_params(const ConvW& c, const float* x, const float* residual, in
 int conv_pair(cotr_ctx* h, const ConvW& cd, const ConvW& c1, const float* x, float* yd, float* y1, int B, int Hin, int Win,
               hipStream_t s) {
   if (!knob(KN_DUAL_CONV)) return 0;
+  if (h->h2_pass) return 0;
   const GemmParams pd = conv_params(cd, x, nullptr, 0, yd, B, Hin, Win), p1 = conv_params(c1, x, nullptr, 1, y1, B, Hin, Win);
   if (p1.M > 16384) return 0;   // batched: throughput-bound, each problem keeps its own best configuration
   const int cfd = gemm_pick_config(GEMM_CONV, pd), cf1 = gemm_pick_config(GEMM_CONV, p1);
@@ -389,6 +495,15 @@ int conv_pair(cotr_ctx* h, const ConvW& cd, const ConvW& c1, const float* x, flo
 
 int conv(cotr_ctx* h, const ConvW& c, const float* x, const float* residual, int relu, float* y, int B,
          int Hin, int Win, hipStream_t s) {
+  if (h->h2_pass) {   // x, the residual and y are packed split-f16 tensors
+    GemmParams q = conv_params(c, x, residual, relu, y, B, Hin, Win);
+    q.W = h2_weight(h, c.w);
+    q.h2_flags = 1 | (residual ? 2 : 0);
+    const int cfg = h2_config(q);
+    KCHK(h, launch_gemm_cfg(GEMM_CONV, cfg, q, s), "conv (split f16)");
+    if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "conv%dx%d/%d %dx%dx%d cfg%d", c.k, c.k, c.stride, q.M, q.N, q.K, cfg); prof_mark(h, nm, s, 2); }
+    return COTR_OK;
+  }
   const GemmParams p = conv_params(c, x, residual, relu, y, B, Hin, Win);
   KCHK(h, launch_gemm(GEMM_CONV, p, s), "conv");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "conv%dx%d/%d %dx%dx%d cfg%d", c.k, c.k, c.stride, p.M, p.N, p.K, gemm_pick_config(GEMM_CONV, p)); prof_mark(h, nm, s, 2); }
@@ -443,6 +558,12 @@ int cotr_create(cotr_handle* out, int device) {
   }
   cotr_ctx* h = new cotr_ctx();
   h->device = device;
+  constexpr size_t kTailBytes = (size_t)1024 * COOP_WORDS * sizeof(unsigned long long);   // <= 1024 rows fused: <= 1024 row tiles
+  if (hipMalloc(reinterpret_cast<void**>(&h->tail_state), kTailBytes) != hipSuccess || hipMemset(h->tail_state, 0, kTailBytes) != hipSuccess) {
+    g_create_error = "allocating the cooperative-tail state failed";
+    delete h;
+    return COTR_ERR_HIP;
+  }
   if (hipMalloc(reinterpret_cast<void**>(&h->pos), (size_t)TOK * D * sizeof(float)) != hipSuccess ||
       launch_pos_table(h->pos, nullptr) != 0 || hipStreamSynchronize(nullptr) != hipSuccess) {
     g_create_error = "building the image position table failed";
@@ -460,6 +581,10 @@ void cotr_destroy(cotr_handle h) {
   prof_reset(h);
   if (h->wbuf) (void)hipFree(h->wbuf);
   if (h->pos) (void)hipFree(h->pos);
+  if (h->tail_state) (void)hipFree(h->tail_state);
+  if (h->wbuf_h2) (void)hipFree(h->wbuf_h2);
+  if (h->h2_scr.ptr && !h->h2_scr.external) (void)hipFree(h->h2_scr.ptr);
+  if (h->kv_h2.ptr && !h->kv_h2.external) (void)hipFree(h->kv_h2.ptr);
   for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr})
     if (a->ptr && !a->external) (void)hipFree(a->ptr);
   for (auto& kv : h->tap_store)
@@ -643,6 +768,7 @@ int cotr_load_weights(cotr_handle h, const char* const* names, const float* cons
     h->wfloats = host.size();
   }
   HIPCHK(h, hipMemcpy(h->wbuf, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  h->wbuf_h2_valid = false;
   const float* base = h->wbuf;
   h->convs.clear();
   for (const auto& c : convs) h->convs.push_back({base + c.w, base + c.scale, base + c.bias, c.cin, c.cout, c.k, c.stride});
@@ -691,6 +817,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   const size_t KVLD = (size_t)L * 2 * D;
   h->enc_B = 0;
   h->taps.clear();
+  ++h->enc_serial;
   if (!feat_out) {
     int r = ensure(h, h->memkv, (size_t)B * TOK * (D + KVLD));
     if (r) return r;
@@ -748,6 +875,13 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     prof_mark(h, "stem+pool", s);
     if (int r = tap_save(h, "stem", b_stem, n_stem * Bc, s)) return r;
     if (int r = tap_save(h, "pool", b_pool, n_pool * Bc, s)) return r;
+    if (knob(KN_SPLIT_F16) && Bc >= knob(KN_SPLIT_F16_MIN_PAIRS)) {   // RESEARCH: from here to input_proj every activation is a packed split-f16 tensor (gemm_h2.h)
+      if (int r = h2_prepare_weights(h, s)) return r;
+      KCHK(h, launch_split_h2(b_pool, b_pool, n_pool * Bc, s), "split_h2 (pool)");
+      prof_mark(h, "split_h2 pool", s, 2);
+      h->h2_pass = true;
+    }
+    struct H2PassEnd { cotr_ctx* h; ~H2PassEnd() { h->h2_pass = false; } } h2_pass_end{h};
     const float* x = b_pool;
     float* outbuf[2] = {b_x, b_y};
     int flip = 0, H = 64, W = 64;
@@ -762,6 +896,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
         flip ^= 1;
         int r;
         bool one_launch = st == 0 && Bc <= knob(KN_BOTTLENECK_MAX_PAIRS) && H == 64 && W == 64;
+        one_launch = one_launch && !h->h2_pass;
         if (one_launch) {
           // the whole bottleneck - conv1, conv2, conv3, (downsample,) FrozenBN, identity, ReLU - in one launch (bottleneck.hip)
           const ConvW* cd = (b == 0) ? &h->convs[ci++] : nullptr;
@@ -793,6 +928,9 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       prof_mark(h, names[st], s);
       if (feat_out && st + 1 == upto) {  // cotr_backbone: [Bc, H, 2W, 4*planes] of this stage, NHWC over the pair
         const size_t per_pair = (size_t)H * 2 * W * kStages[st].planes * 4;
+        if (h->h2_pass) {
+          KCHK(h, launch_unsplit_h2(x, feat_out + (size_t)b0 * per_pair, (size_t)Bc * per_pair, s), "unsplit_h2 (features)");
+        } else
         HIPCHK(h, hipMemcpyAsync(feat_out + (size_t)b0 * per_pair, x, (size_t)Bc * per_pair * sizeof(float),
                                  hipMemcpyDeviceToDevice, s));
         break;
@@ -812,16 +950,23 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
       const EncW& e = h->enc[li];
       // q|k use src+pos, v uses src; q scaled by 32^-0.5 (transformer.py:147-153)
       if (M >= knob(KN_POS_TABLE_MIN_ROWS)) {
+        h->h2_out_packed = exp_h2_attention(M, n_part != 0 && M <= knob(KN_ATTENTION_FUSION_MAX_ROWS) && M <= knob(KN_FFN_FUSION_MAX_ROWS));   // level 3: q | k | v go to the split-f16 attention kernel as packed tensors
         if ((r = linear(h, xin, nullptr, 0, 1, 0, e.in_w, e.in_b, h->tab_qkv + li * TOK * 3 * D, 0, QSCALE, D, t_qkv, M, 3 * D, D, s, 0, TOK)))
           return r;
       } else if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
       float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
       bool fused = n_part != 0 && M <= knob(KN_ATTENTION_FUSION_MAX_ROWS) && M <= knob(KN_FFN_FUSION_MAX_ROWS);
+      if (const int rx = exp_encoder_layer(h, e, xin, y, fused, t_qkv, t_part, t_x1, t_hid, t_tmp, t_ao, Bc, M, s)) {
+        if (rx < 0) return rx;
+        xin = y;
+        continue;
+      }
       if (fused) {
         // few rows: out_proj inside the attention kernel (8 per-head partial outputs), summed + bias + residual + norm1 by ln_reduce
         KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
                                        nullptr, 0, e.out_w, t_part, Bc, TOK, s), "attention+out_proj");
         prof_mark(h, "attention+oproj enc", s, 2);
+        if (knob(KN_L2_WARM) & 1) set_ln_reduce_warm(e.l1w, (size_t)FFN * D * 4, e.l2w, (size_t)FFN * D * 4);   // the FFN block is next
         KCHK(h, launch_ln_reduce(t_part, 8, e.out_b, xin, e.n1w, e.n1b, t_x1, M, s), "ln_reduce");
         prof_mark(h, "ln_reduce heads", s, 2);
       } else if (att_rows_applies(Bc, TOK)) {
@@ -924,6 +1069,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   const int R = nb * nq;
   int r;
   bool fused = d.part != nullptr && R <= knob(KN_ATTENTION_FUSION_MAX_ROWS) && R <= knob(KN_FFN_FUSION_MAX_ROWS);
+  fused = fused && !knob(KN_FFN_PRELN);
   bool hs_normed = false;
   const bool rows = !fused && att_rows_applies(nb, nq);   // many rows: q projection, attention, out_proj, residual, norm2 in one launch
   if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s, fused || rows))) return r;
@@ -932,6 +1078,10 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
     const DecW& w = h->dec[li];
     const float* kl = kv_c + (size_t)li * 2 * D;          // this layer's K (then V) columns of the hoisted projection
     const float* tgt_in = li == 0 ? nullptr : d.tgt;      // tgt == 0 at layer 0 (transformer.py:54)
+    if (const int rx = exp_decoder_layer(h, w, d, kl, KVLD, tgt_in, fused, li + 1 == L, hs_normed, nb, nq, R, s)) {
+      if (rx < 0) return rx;
+      continue;
+    }
     if (fused) {
       // few rows: q = Wq(tgt + query_pos) * 32^-0.5 in the attention kernel's prologue, out_proj in its epilogue (8 per-head
       // partials), then ln_reduce: sum + bias + residual + norm2; FFN block; 4 launches per layer.  Last layer: decoder.norm rides
@@ -939,9 +1089,12 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       KCHK(h, launch_attention_fused(nullptr, 0, tgt_in, d.qpos, w.q_w, w.q_b, QSCALE, kl, kl + D, KVLD, nullptr, 0, w.out_w, d.part,
                                      nb, nq, s), "q_proj+attention+out_proj");
       prof_mark(h, "qproj+attention+oproj dec", s, 2);
+      if (knob(KN_L2_WARM) & 1) set_ln_reduce_warm(w.l1w, (size_t)FFN * D * 4, w.l2w, (size_t)FFN * D * 4);     // the FFN block is next
       KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, tgt_in, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
       prof_mark(h, "ln_reduce heads", s, 2);
       const bool post = li + 1 == L;
+      if ((knob(KN_L2_WARM) & 2) && !post)   // ... and the FFN block's own ln_reduce warms the next layer's attention weights
+        set_ln_reduce_warm(h->dec[li + 1].q_w, (size_t)D * D * 4, h->dec[li + 1].out_w, (size_t)D * D * 4);
       if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
                          post ? h->dn_w : nullptr, post ? h->dn_b : nullptr))) return r;
       hs_normed = post;
@@ -966,6 +1119,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
     }
   }
   // decoder.norm + corr_embed on the last layer only (the reference computes all 6 and keeps [-1])
+  if (const int rx = exp_decoder_head(h, d, odst, nb, nq, Q, R, s)) return rx < 0 ? rx : COTR_OK;
   if (!hs_normed && (r = layernorm(h, d.tgt, h->dn_w, h->dn_b, d.pre2, R, s))) return r;
   if ((r = linear(h, d.pre2, nullptr, 0, 1, 0, h->mlp_w[0], h->mlp_b[0], nullptr, 1, 1.f, 0, d.ao, R, D, D, s))) return r;
   if ((r = linear(h, d.ao, nullptr, 0, 1, 0, h->mlp_w[1], h->mlp_b[1], nullptr, 1, 1.f, 0, d.q, R, D, D, s))) return r;
@@ -1223,6 +1377,12 @@ int cotr_op_attention_fused(const float* q, int ldq, const float* x, const float
                                        static_cast<hipStream_t>(stream)));
 }
 
+int cotr_op_dec_head(const float* x, const float* nw, const float* nb, const float* w0, const float* b0, const float* w1,
+                     const float* b1, const float* w2, const float* b2, float* hs, float* out, int nb_pairs, int nq, int q_total,
+                     cotr_stream stream) {
+  if (!x || !nw || !nb || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !out) return COTR_ERR_ARG;
+  return op_ret(launch_dec_head(x, nw, nb, w0, b0, w1, b1, w2, b2, hs, out, nb_pairs, nq, q_total, static_cast<hipStream_t>(stream)));
+}
 
 int cotr_op_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                       float* y, int rows, cotr_stream stream) {
@@ -1283,6 +1443,14 @@ static int bench_launches(int mode, int cfg, const GemmParams& p, int iters, flo
 
 int cotr_gemm_num_configs(void) { return gemm_num_configs(); }
 
+int cotr_op_linear_ln(const float* x, const float* w, const float* bias, const float* residual, const float* ln_w, const float* ln_b,
+                      float* y, int M, int K, cotr_stream stream) {
+  return op_ret(launch_gemm_ln(x, K, w, bias, residual, 256, ln_w, ln_b, y, M, K, static_cast<hipStream_t>(stream)));
+}
+int cotr_op_split_h2(const float* x, void* y, size_t n, cotr_stream stream) {
+  if (!x || !y) return COTR_ERR_ARG;
+  return op_ret(launch_split_h2(x, y, n, static_cast<hipStream_t>(stream)));
+}
 // one layer1 bottleneck from UNPACKED weights (tests): w1 [64][cin], w2 [64][3][3][64], w3 [256][64], wd [256][64] or NULL (device
 // pointers); packs the fragment images on the host and launches bottleneck.hip
 int cotr_op_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2, const float* w3, const float* wd,
@@ -1345,7 +1513,7 @@ int cotr_reset_knobs(cotr_handle h) {
   return COTR_OK;
 }
 int cotr_is_experimental(void) {
-  return 0;
+  return 1;
 }
 
 int cotr_bench_linear(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, int cfg,
@@ -1371,11 +1539,27 @@ int cotr_bench_conv(const float* x, const float* w, const float* scale, const fl
 }
 
 // explicit-config variants of the op entry points (tests check every config against torch)
+static thread_local int g_op_h2_flags = 0;   // GemmParams::h2_flags of the cotr_op_*_cfg calls of this thread (configurations 46 / 47)
+int cotr_op_set_h2_flags(int flags) {
+  if (flags < 0 || flags > 3) return COTR_ERR_ARG;
+  g_op_h2_flags = flags;
+  return COTR_OK;
+}
+int cotr_op_attention_h2(const float* q, int ldq, int q_packed, const float* k, const float* v, int ldkv, float* o, int ldo, int out_packed,
+                         int nb, int nq, cotr_stream stream) {
+  if (!q || !k || !v || !o) return COTR_ERR_ARG;
+  return op_ret(launch_attention_h2(q, ldq, q_packed, k, v, ldkv, o, ldo, out_packed, nb, nq, static_cast<hipStream_t>(stream)));
+}
+int cotr_op_unsplit_h2(const void* x, float* y, size_t n, cotr_stream stream) {
+  if (!x || !y) return COTR_ERR_ARG;
+  return op_ret(launch_unsplit_h2(x, y, n, static_cast<hipStream_t>(stream)));
+}
 int cotr_op_linear_cfg(const float* x, const float* w, const float* bias, const float* residual, int relu, float* y,
                        int M, int N, int K, int cfg, cotr_stream stream) {
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K; p.A = x; p.lda = K; p.W = w; p.C = y; p.ldc = N;
   p.bias = bias; p.residual = residual; p.ldr = N; p.relu = relu;
+  p.h2_flags = g_op_h2_flags;
   return op_ret(launch_gemm_cfg(GEMM_DENSE, cfg, p, static_cast<hipStream_t>(stream)));
 }
 
@@ -1391,6 +1575,7 @@ int cotr_op_conv_cfg(const float* x, const float* w, const float* scale, const f
   p.M = B * p.Hout * 2 * p.Wout; p.N = Cout; p.K = ksize * ksize * Cin;
   p.A = x; p.lda = Cin; p.W = w; p.C = y; p.ldc = Cout;
   p.scale = scale; p.bias = bias; p.residual = residual; p.ldr = Cout; p.relu = relu;
+  p.h2_flags = g_op_h2_flags;
   return op_ret(launch_gemm_cfg(GEMM_CONV, cfg, p, static_cast<hipStream_t>(stream)));
 }
 
@@ -1576,6 +1761,7 @@ int cotr_op_ffn_block(const float* x, const float* w1, const float* b1, const fl
                       const float* ln_b, float* scratch, float* y, int M, cotr_stream stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nch = ffn_fused_chunks(M);
+  if (knob(KN_FFN_TAIL)) return op_ret(launch_ffn_fused_ln(x, w1, b1, w2, scratch, M, nch, b2, x, ln_w, ln_b, y, s));
   int r = launch_ffn_fused(x, w1, b1, w2, scratch, M, nch, s);
   if (r == 0) r = launch_ln_reduce(scratch, nch, b2, x, ln_w, ln_b, y, M, s);
   return op_ret(r);

@@ -1,3 +1,5 @@
+// RESEARCH LIBRARY COPY of csrc/attention.hip (libcotr_hip_exp.so only): the product file with the research / dead-end paths that used to sit
+// behind #ifdef COTR_EXPERIMENTAL in it resolved IN (tools/unifdef_exp.py -D).  The product never compiles this file.
 // Multi-head softmax attention over the fixed 512-token (16x32) COTR memory, fp32 MFMA, gfx950.
 //
 // Serves both call sites of nn.MultiheadAttention in the reference:
@@ -19,7 +21,7 @@
 //   online softmax       running max / sum, exp in fp32
 //   O^T += V_blk^T . P^T 16x v_mfma_f32_32x32x2_f32   (P registers feed the B operand directly)
 // The NS partial (max, sum, O^T) triples are merged through 17 KB of LDS in a fixed order.
-#include "common.h"
+#include "../common.h"
 
 #define ATT_KEYS 512
 #define ATT_HD 32
@@ -44,6 +46,7 @@ struct AttnFuse {
   int rows_total;      // OP: rows of one partial
   int wt;              // OP: write-through (sc1) stores for the partials (read once, by every XCD)
   unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock): cotr_debug_attention_times
+  CoopTail ct;         // OP: ct.state != nullptr: the 8 head workgroups of a query tile also sum the partials + bias + residual + LayerNorm
 };
 
 template <int NS, int QP, bool OP>   // QP: 0 = q given, 1 = project x, 2 = project x + x2
@@ -275,6 +278,12 @@ __global__ __launch_bounds__(NS * 64) void attention_kernel(const float* __restr
       if (qo < nq) store_f32x4(pbase + (size_t)qo * 256 + sc, val, fz.wt != 0);
     }
     ATT_STAMP(5);
+    if (fz.ct.state != nullptr) {
+      __shared__ int coop_flags[2];
+      const int rem = nq - qtile * 32;
+      coop_tail_run(fz.ct, fz.part, (size_t)fz.rows_total * 256, pair * qtiles + qtile, pair * nq + qtile * 32, rem < 32 ? rem : 32, head, 8,
+                    coop_flags);
+    }
     if (o == nullptr) return;
   }
   for (int i = t; i < 256; i += NS * 64) {  // 32 rows x 128 B, one float4 per thread: coalesced row stores
@@ -651,12 +660,13 @@ int launch_attention(const float* q, int ldq, const float* k, const float* v, in
 
 // Attention with the q projection in the prologue (qp: x/x2/wq/bq/qscale, q unused) and / or the output projection in the
 // epilogue (op: partial outputs [8][nb*nq][256] to `part`, o may be nullptr).  4 key splits.
-#define ATT_CT_PARAM
+#define ATT_CT_PARAM , const CoopTail* ct
 static int attention_fused_impl(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
                                 float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
                                 float* part, int nb, int nq, hipStream_t s ATT_CT_PARAM) {
   if (nb <= 0 || nq <= 0) return 0;
   const bool qp = wq != nullptr, op = wo != nullptr;
+  if (ct != nullptr && !op) return -1;
   const int g_att_head_major = (knob(KN_XCD_MAPPING) >> 3) & 1;
   const int g_att_fused_splits = knob(KN_ATTENTION_FUSED_SPLITS);
   if (ldkv % 4 || (o && ldo % 4) || (!qp && (q == nullptr || ldq % 4))) return -1;
@@ -668,6 +678,7 @@ static int attention_fused_impl(const float* q, int ldq, const float* x, const f
   fz.x = x ? x : x2; fz.x2 = x ? x2 : nullptr; fz.wq = wq; fz.bq = bq; fz.qscale = qscale;
   fz.wo = wo; fz.part = part; fz.rows_total = nb * nq; fz.wt = g_att_part_wt;
   fz.dbg = g_att_dbg;
+  if (ct != nullptr) fz.ct = *ct;
   const int qmode = !qp ? 0 : (fz.x2 ? 2 : 1);
   // 8 key splits (8 wavefronts per workgroup) were tried where 4 leave CUs without a workgroup (the encoder of one pair is
   // 16 query tiles x 8 heads = 128 workgroups on 256 CUs): measured 0.978 vs 0.973 ms per forward, the merge of 8 partial
@@ -694,5 +705,11 @@ static int attention_fused_impl(const float* q, int ldq, const float* x, const f
 int launch_attention_fused(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
                            float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
                            float* part, int nb, int nq, hipStream_t s) {
-  return attention_fused_impl(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, o, ldo, wo, part, nb, nq, s);
+  return attention_fused_impl(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, o, ldo, wo, part, nb, nq, s, nullptr);
+}
+// ... with the cooperative tail (experimental/coop_tail.h): the 8 head workgroups of a query tile finish the tile themselves
+int launch_attention_fused_coop(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq,
+                                float qscale, const float* k, const float* v, int ldkv, float* o, int ldo, const float* wo,
+                                float* part, int nb, int nq, hipStream_t s, const CoopTail* ct) {
+  return attention_fused_impl(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, o, ldo, wo, part, nb, nq, s, ct);
 }

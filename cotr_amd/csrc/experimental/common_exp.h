@@ -1,12 +1,7 @@
 // Shared declarations of the gfx950 kernels behind libcotr_hip.so.
 #pragma once
-// The research library (libcotr_hip_exp.so, -DCOTR_EXPERIMENTAL: split-f16 products and the measured dead ends) is built from its OWN
-// copies of the translation units it changes (csrc/experimental/: api.hip, attention.hip, ffn.hip, gemm.hip, gemm_big.hip,
-// pointwise.hip and this header as common_exp.h) plus the untouched product ones, which find its declarations through this redirect -
-// the only mention of it in the product sources.
-#ifdef COTR_EXPERIMENTAL
-#include "experimental/common_exp.h"
-#else
+// RESEARCH LIBRARY COPY of csrc/common.h (reached through its redirect under -DCOTR_EXPERIMENTAL): the product header plus the research
+// knobs, GemmParams::h2_flags and the declarations of csrc/experimental/.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -52,7 +47,8 @@ struct PerDeviceFlag {
 // handle-less op-level entry points (cotr_op_*, cotr_bench_*, cotr_train_*: tests and tools; cotr_set_knob(NULL, ...)).  Every
 // ABI call makes its set current for the calling thread (KnobScope, api.hip); the launch helpers read it through knob(): two
 // handles - or two threads - can run with different settings, and a new handle always starts from the shipped defaults.
-// (The research library appends its own knobs in its copy of this header; the product has neither those knobs nor the code behind them.)
+// The experimental build (-DCOTR_EXPERIMENTAL, libcotr_hip_exp.so, csrc/experimental/) appends the knobs of the measured dead
+// ends; the product library has neither those knobs nor the code behind them.
 // ---------------------------------------------------------------------------------------------
 enum KnobId {
   KN_ENCODE_CHUNK,               // pairs per backbone / encoder pass (<= 128).  64: +2-3 % over 32 from 64 pairs up, 128: -20 %
@@ -76,6 +72,15 @@ enum KnobId {
   KN_ATTENTION_RESIDENT,         // K_h / V_h resident in LDS (attention_res_kernel) for many rows
   KN_ATT_ROWS_MIN_ROWS,          // attention sub-layer ([q projection,] attention, out projection, residual, LayerNorm) as ONE launch (att_rows.hip) from this many query rows
   KN_FFN_ROWS_MIN_ROWS,          // FFN block + residual + LayerNorm as ONE launch (ffn_rows.hip: 64-row tiles, hidden units dealt to the wavefronts) from this many rows
+  KN_HEAD_FUSION_MAX_ROWS,       // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower; 0)
+  KN_FFN_PRELN,                  // the norm before the FFN folded into the fused FFN block (measured neutral; 0)
+  KN_FFN_TAIL,                   // last-arriver reduce + LayerNorm inside the fused FFN launch (measured slower; 0)
+  KN_COOP_TAIL,                  // row tiles finished by their own workgroups (coop_tail.h; measured slower; 0)
+  KN_COOP_TAIL_SPIN,             // polls before a member leaves its share to the last arriver
+  KN_GEMM_LN_MIN_ROWS,           // 256-wide projection + LayerNorm as one launch from this many rows (measured neutral; off)
+  KN_L2_WARM,                    // ln_reduce launches also touch the next launch's weights (weights-ahead L2 warmer; bit 0 FFN weights, bit 1 attention weights; measured slower)
+  KN_SPLIT_F16,                  // RESEARCH (experimental/gemm_h2.h): 1 = the backbone + input_proj of a pass run on packed split-f16 activations / weights (three f16 MFMAs per fp32 product), 2 = also the transformer's projections and FFN GEMMs of the unfused (many-row) path
+  KN_SPLIT_F16_MIN_PAIRS,        // ... the backbone pass only from this many pairs per pass (below, the tuned small-tile fp32 kernels win: 8)
   KN_COUNT
 };
 struct KnobSet {
@@ -153,6 +158,7 @@ struct GemmParams {
   const float* zeros;  // >= 16 B of zeros in global memory (source of padded / out-of-range tiles for LDS-DMA)
   int xcd_msplit;      // workgroup -> tile mapping, see gemm_tile_coords
   int ws_flags;        // wave-specialised large tiles (gemm_big.hip): priorities, see gemm_set_ws_flags
+  int h2_flags;        // configurations 46 / 47 (packed split-f16 operands): bit 0 = C is written packed, bit 1 = the residual is packed
   // launch-time divisors (gemm_fill_divs, called by every launch helper): column tiles of the launch's tile shape; the
   // convolution's pixel decomposition (Hout * 2*Wout, 2*Wout, Wout), channel tiles per tap (Cin / 32), ksize; the x + pos
   // prologue's row period and column period; the row period of a table residual
@@ -303,4 +309,6 @@ int launch_bottleneck(const float* x, float* y, int B, int cin, const float* w1,
                       const float* sd, const float* bd, hipStream_t s);
 void bottleneck_pack_w2(const float* w2 /*[64][576]*/, float* w2p /*[36864]*/);
 void bottleneck_pack_w3(const float* w3 /*[256][64]*/, float* w3p /*[16384]*/);
-#endif   // COTR_EXPERIMENTAL
+
+
+#include "experimental.h"

@@ -1,3 +1,5 @@
+// RESEARCH LIBRARY COPY of csrc/ffn.hip (libcotr_hip_exp.so only): the product file with the research / dead-end paths that used to sit
+// behind #ifdef COTR_EXPERIMENTAL in it resolved IN (tools/unifdef_exp.py -D).  The product never compiles this file.
 // Fused transformer feed-forward block for the small-M (one pair / ~1000 query rows) regime, fp32 MFMA, gfx950:
 //     P[c] = relu(X . W1_c^T + b1_c) . W2[:, c]^T          c = hidden-unit chunk
 // i.e. linear1 + ReLU + linear2 of COTR/models/transformer.py:156,199 (`linear2(dropout(activation(linear1(x))))`)
@@ -14,7 +16,7 @@
 // X and W1 sub-chunks arrive by LDS-DMA (one wave instruction = one padded 1040-B row).
 #include <string.h>
 
-#include "common.h"
+#include "../common.h"
 
 #define FF_D 256
 #define FF_H 1024
@@ -31,6 +33,20 @@ struct FfnParams {
   int M, nch, chunk_major;
   int wt_partials;   // partial outputs with write-through stores
   unsigned long long* dbg;  // nullptr, or [workgroups][8] phase timestamps (100 MHz wall clock), cotr_debug_ffn_times
+  // optional LayerNorm applied to the X tile after it landed in LDS: X is then the PRE-norm tensor (x + attention output)
+  // and norm1 / norm2 of the layer never needs its own launch (its only consumers are this block and its residual)
+  const float* pre_w;
+  const float* pre_b;
+  // tail (optional): the LAST of the nch workgroups of a row tile to finish sums the partial outputs in chunk order, adds
+  // bias + residual and applies LayerNorm - what ln_reduce_kernel does in a second launch.  No workgroup waits for
+  // another (arrival counter per row tile, reset by the last arriver), the sum order is fixed: same bits as ln_reduce.
+  int* counters;     // [row tiles], zero between launches; nullptr = no tail
+  const float* b2;   // linear2 bias [256]
+  const float* residual;  // [M][256]
+  const float* ln_w;
+  const float* ln_b;
+  float* Y;          // [M][256]
+  CoopTail ct;       // ct.state != nullptr: the workgroups of a row tile finish it themselves (coop_tail.h) - no ln_reduce launch
 };
 
 __device__ __forceinline__ float ffn_wave_sum(float v) {
@@ -81,6 +97,26 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   dma_w1(0);
   FFN_STAMP(1);
 
+  if (p.pre_w != nullptr) {
+    LDS_DMA_WAIT_ALL();
+    __syncthreads();                                  // X (and the first W1 sub-chunk) have landed
+    // same arithmetic as layernorm_kernel (pointwise.hip): lane holds 4 consecutive channels, two wave reductions
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(p.pre_w + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.pre_b + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* row = Xs + (wave * 4 + i) * FF_LD + lane * 4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row);
+      const float mean = ffn_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+      const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+      const float var = ffn_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+      const float rstd = 1.f / sqrtf(var + 1e-5f);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = d[e] * rstd * ww[e] + bb[e];
+      *reinterpret_cast<f32x4*>(row) = o;
+    }
+  }
 
   f32x16 acc2;
 #pragma unroll
@@ -145,6 +181,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
   FFN_STAMP(6);
   // partial output block of this wave: rows m0 + (r&3) + 8*(r>>2) + 4*hh, columns 32*wave + l31
   float* out = p.P + (size_t)chunk * p.M * FF_D;
+  if (p.counters == nullptr)
   {
     // through a wave-private LDS tile (the W1 stage is free: no DMA is in flight after the last sub-chunk and every wave is
     // past its last read of it, barrier "H complete") so that the rows leave as float4 - one instruction = 8 rows x 128 B.
@@ -161,8 +198,64 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnParams p) {
       if (m0 + row < p.M) store_f32x4(out + (size_t)(m0 + row) * FF_D + 32 * wave + sc, val, p.wt_partials != 0);
     }
     FFN_STAMP(7);
+    if (p.ct.state != nullptr) {
+      __shared__ int coop_flags[2];
+      coop_tail_run(p.ct, p.P, (size_t)p.M * FF_D, m0 >> 5, m0, (p.M - m0) < 32 ? (p.M - m0) : 32, chunk, p.nch, coop_flags);
+    }
     return;
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    // with the tail, partials are exchanged between workgroups of different XCDs inside this launch: agent-scope
+    // (sc1) stores / loads go to the memory side and bypass the per-XCD L2s, so no L2 write-back / invalidate is needed
+    if (m < p.M) __hip_atomic_store(&out[(size_t)m * FF_D + 32 * wave + l31], acc2[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- tail: last arriver of this row tile reduces + normalises ----------------------------------------------------
+  __shared__ int s_last;
+  __builtin_amdgcn_s_waitcnt(0);                     // this thread's partial stores have reached the memory side ...
+  __syncthreads();                                   // ... and so have everybody's, before the arrival is counted
+  const int tile = m0 / 32;
+  if (t == 0) s_last = (atomicAdd(&p.counters[tile], 1) == p.nch - 1);
+  __syncthreads();
+  if (!s_last) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + wave * 4 + i;
+    if (row >= p.M) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p.b2 + lane * 4);
+    {
+      f32x4 rr = *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * FF_D + lane * 4);
+      if (p.pre_w != nullptr) {                         // the residual is LayerNorm(pre-norm row)
+        const float mu = ffn_wave_sum(rr[0] + rr[1] + rr[2] + rr[3]) * (1.f / 256.f);
+        const f32x4 dd = {rr[0] - mu, rr[1] - mu, rr[2] - mu, rr[3] - mu};
+        const float va = ffn_wave_sum(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3]) * (1.f / 256.f);
+        const float rs = 1.f / sqrtf(va + 1e-5f);
+        const f32x4 pw = *reinterpret_cast<const f32x4*>(p.pre_w + lane * 4);
+        const f32x4 pb = *reinterpret_cast<const f32x4*>(p.pre_b + lane * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rr[e] = dd[e] * rs * pw[e] + pb[e];
+      }
+      v += rr;
+    }
+    for (int c = 0; c < p.nch; ++c) {
+      const float* src = p.P + ((size_t)c * p.M + row) * FF_D + lane * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float mean = ffn_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+    const f32x4 d = {v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+    const float var = ffn_wave_sum(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / 256.f);
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(p.ln_w + lane * 4);
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln_b + lane * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = d[e] * rstd * ww[e] + bb[e];
+    *reinterpret_cast<f32x4*>(p.Y + (size_t)row * FF_D + lane * 4) = o;
+  }
+  if (t == 0) p.counters[tile] = 0;                  // everybody has arrived: ready for the next launch
 }
 
 static const size_t kFfnSmem = (size_t)(32 * FF_LD + 64 * FF_LD + 32 * FF_HLD) * sizeof(float);
@@ -180,9 +273,55 @@ int ffn_fused_chunks(int M) {
   return nch;
 }
 
+// per-device arrival counters of the tail (1024 rows / 32 = at most 32 row tiles are ever fused)
+static int* ffn_counters() {
+  static int* c[COTR_MAX_DEVICES] = {};
+  int*& cd = c[cotr_current_device()];
+  if (cd == nullptr) {
+    int* p = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p), 4096) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 4096) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    cd = p;
+  }
+  return cd;
+}
+
+static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
+                           const float* W2, float* P, int M, int nch, const float* b2, const float* residual,
+                           const float* ln_w, const float* ln_b, float* Y, hipStream_t s);
 
 int launch_ffn_fused(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
                      hipStream_t s) {
+  return launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+// the same with the cooperative tail (coop_tail.h): Y = [post norm] LN(residual + sum of partials + b2) by the row tile's own workgroups
+static thread_local const CoopTail* g_ffn_ct = nullptr;
+int launch_ffn_fused_coop(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                          const CoopTail& ct, hipStream_t s) {
+  if (nch != 8 && nch != 16) return -1;
+  g_ffn_ct = &ct;
+  const int r = launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+  g_ffn_ct = nullptr;
+  return r;
+}
+
+// X is the pre-norm tensor: LayerNorm(pre_w, pre_b) is applied to the X tile inside the kernel
+int launch_ffn_fused_pre(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
+                         const float* W2, float* P, int M, int nch, hipStream_t s) {
+  return launch_ffn_impl(X, pre_w, pre_b, W1, b1, W2, P, M, nch, nullptr, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+// with b2 != nullptr the kernel also does  Y = LayerNorm(residual + sum of partials + b2)  (no second launch)
+int launch_ffn_fused_ln(const float* X, const float* W1, const float* b1, const float* W2, float* P, int M, int nch,
+                        const float* b2, const float* residual, const float* ln_w, const float* ln_b, float* Y,
+                        hipStream_t s) {
+  return launch_ffn_impl(X, nullptr, nullptr, W1, b1, W2, P, M, nch, b2, residual, ln_w, ln_b, Y, s);
+}
+
+static int launch_ffn_impl(const float* X, const float* pre_w, const float* pre_b, const float* W1, const float* b1,
+                           const float* W2, float* P, int M, int nch, const float* b2, const float* residual,
+                           const float* ln_w, const float* ln_b, float* Y, hipStream_t s) {
   if (M <= 0) return 0;
   if (nch < 1 || nch > 16 || FF_H % (nch * 64) != 0) return -1;
   static PerDeviceFlag attr_set;
@@ -197,6 +336,15 @@ int launch_ffn_fused(const float* X, const float* W1, const float* b1, const flo
   p.chunk_major = (knob(KN_XCD_MAPPING) >> 2) & 1;
   p.wt_partials = ((knob(KN_XCD_MAPPING) >> 4) & 1) == 0;
   p.dbg = g_ffn_dbg;
+  p.counters = nullptr; p.b2 = b2; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y;
+  p.pre_w = pre_w; p.pre_b = pre_b;
+  memset(&p.ct, 0, sizeof(p.ct));
+  if (g_ffn_ct != nullptr) p.ct = *g_ffn_ct;
+  if (b2 != nullptr) {
+    if (!residual || !ln_w || !ln_b || !Y || (M + 31) / 32 > 1024) return -1;
+    p.counters = ffn_counters();
+    if (p.counters == nullptr) return -2;
+  }
   if (p.zeros == nullptr) return -2;
   hipLaunchKernelGGL(ffn_fused_kernel, dim3(((M + 31) / 32) * nch), dim3(512), kFfnSmem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;

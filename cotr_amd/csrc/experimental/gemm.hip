@@ -1,3 +1,5 @@
+// RESEARCH LIBRARY COPY of csrc/gemm.hip (libcotr_hip_exp.so only): the product file with the research / dead-end paths that used to sit
+// behind #ifdef COTR_EXPERIMENTAL in it resolved IN (tools/unifdef_exp.py -D).  The product never compiles this file.
 // fp32 MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
 //
 // One kernel template covers every dense contraction of the COTR forward path: the 43 ResNet
@@ -17,7 +19,7 @@
 // Fragment trick: lane l = (row l&31, half l>>5) reads ONE float4 = columns j*8+half*4 .. +3 of its
 // row and feeds element e to the e-th of 4 MFMAs; both operands use the same column permutation so
 // the contraction is unchanged, and each operand costs one ds_read_b128 per 4 MFMAs.
-#include "common.h"
+#include "../common.h"
 
 #define BK 32
 #define LDSLD 36
@@ -726,8 +728,8 @@ static const GemmCfg kCfgs[] = {
     {1, 4, 1, 0},   // 25 k-split 4 waves, 32x16
     {4, 0, 2, 2},   // 26 large tile 128x128 (gemm_big.hip)
     {4, 0, 2, 1},   // 27 large tile 128x64
-    {12, 0, 2, 2},  // 28 (research library only: large tile 128x128 with three LDS stages; kind 12 = never fits here, the index stays)
-    {12, 0, 2, 1},  // 29 (research library only: 128x64, three LDS stages)
+    {5, 0, 2, 2},   // 28 large tile 128x128, three LDS stages (two tiles of LDS-DMA in flight, counted vmcnt)
+    {5, 0, 2, 1},   // 29 large tile 128x64, three LDS stages
     {6, 8, 1, 0},   // 30 k-split 8 waves, 32x16, LDS-DMA with THREE stages (two tiles in flight, counted vmcnt)
     {7, 8, 1, 0},   // 31 the same for 3x3 stride-1 convolutions over 256 channels with the input patch loaded once (DB == 4)
     // kind 8: wave-private K chunks (gemm_wp.hip): every wavefront requests and reads its own run of 32-wide K chunks through
@@ -742,6 +744,18 @@ static const GemmCfg kCfgs[] = {
     {8, 7, 1, 0},   // 39 wave-private, 8 waves, 32x16, 2 slots
     {5, 0, 2, 2},   // 40 large tile 128x128, wave-specialised: 4 loader + 4 MFMA wavefronts, three LDS stages (gemm_big.hip, gemm_ws_body)
     {5, 0, 2, 1},   // 41 large tile 128x64, wave-specialised
+    // kind 9: PERSISTENT large tiles (experimental/gemm_pp.hip): one workgroup per CU walks its tiles, 4 loader wavefronts run ahead across
+    // tile boundaries, two groups of 4 MFMA wavefronts alternate tiles so that a tile's epilogue runs beside the next tile's MFMAs
+    {9, 0, 2, 1},   // 42 persistent ping-pong 128x64
+    {9, 0, 2, 1},   // 43 persistent ping-pong 128x64, LDS-free write-out
+    {5, 0, 2, 2},   // 44 large tile 128x128 (26) with the LDS-free epilogue: dword stores straight from the accumulators
+    {5, 0, 2, 1},   // 45 large tile 128x64 (27) with the LDS-free epilogue
+    {5, 0, 2, 2},   // 46 large tile 128x128 on PACKED SPLIT-f16 operands (experimental/gemm_h2.h): 3 f16 MFMAs per fp32 product
+    {5, 0, 2, 1},   // 47 the same, 128x64
+    {5, 0, 2, 2},   // 48 packed split-f16 operands on the wave-specialised 128x128 tile (4 loader + 4 MFMA wavefronts)
+    {5, 0, 2, 1},   // 49 the same, 128x64
+    {10, 0, 2, 2},  // 50 packed split-f16, K = 256 dense: A tile resident in REGISTERS, W through an 8-stage ring across column tiles (experimental/gemm_h2r.hip)
+    {11, 0, 2, 2},  // 51 packed split-f16 on a 256 x 128 tile (8 wavefronts, three LDS stages, one workgroup per CU): 25 % fewer bytes per flop
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 int gemm_num_configs() { return kNumCfgs; }
@@ -852,9 +866,21 @@ static int launch_cfg(int cfg, const GemmParams& p, hipStream_t s) {
     case 25: return launch_ks<4, 1, 0, MODE, 0>(p, s);
     case 26: return launch_gemm_big(MODE, 0, p, s);
     case 27: return launch_gemm_big(MODE, 1, p, s);
+    case 28: return launch_gemm_big(MODE, 2, p, s);
+    case 29: return launch_gemm_big(MODE, 3, p, s);
     case 30: return launch_ks<8, 1, 0, MODE, 3>(p, s);
     case 31: return launch_ks<8, 1, 0, MODE, 4>(p, s);
     case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39: return launch_gemm_wp(MODE, kCfgs[cfg].a, p, s);
+    case 42: return launch_gemm_pp(MODE, 1, p, s);
+    case 43: return launch_gemm_pp(MODE, 3, p, s);
+    case 44: return launch_gemm_big(MODE, 6, p, s);
+    case 45: return launch_gemm_big(MODE, 7, p, s);
+    case 46: return launch_gemm_big(MODE, 8, p, s);
+    case 47: return launch_gemm_big(MODE, 9, p, s);
+    case 48: return launch_gemm_big(MODE, 10, p, s);
+    case 49: return launch_gemm_big(MODE, 11, p, s);
+    case 50: return MODE == GEMM_DENSE ? launch_gemm_h2r(p, s) : -1;
+    case 51: return launch_gemm_big(MODE, 12, p, s);
     case 40: return launch_gemm_big(MODE, 4, p, s);
     case 41: return launch_gemm_big(MODE, 5, p, s);
     default: return -1;
@@ -890,13 +916,14 @@ struct TunedEntry {
   int cfg_reg;  // fastest among the register-staged ones (needed when the x+pos prologue is in use)
 };
 static const TunedEntry kTuned[] = {
-#include "gemm_tuned.inc"
+#include "../gemm_tuned.inc"
     {-1, 0, 0, 0, 0, 0}};
 
 static bool cfg_fits(int cfg, const GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  if (c.kind == 12) return false;   // a configuration of the research library: not compiled into this one
-  if (c.kind == 4 || c.kind == 5) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
+  if (c.kind == 10) return p.K == 256 && p.N % 128 == 0 && p.A2 == nullptr && p.lda % 4 == 0;
+  if (c.kind == 4 || c.kind == 5 || c.kind == 9 || c.kind == 11) {  // LDS-DMA operands (no x + pos prologue), float4 epilogue
+    if (c.kind == 9 && p.K < 64) return false;
     if (p.A2 != nullptr || p.ldc % 4 != 0 || ((uintptr_t)p.C & 15)) return false;
     if (p.residual && (p.ldr % 4 != 0 || ((uintptr_t)p.residual & 15))) return false;
     return p.N % (64 * c.tn) == 0;
@@ -998,7 +1025,7 @@ static int gemm_pick_config_table(int mode, const GemmParams& p) {
 // which operand should cross the fabric once: the one that is larger (gemm_tile_coords, common.h)
 static void set_xcd_split(int mode, int cfg, GemmParams& p) {
   const GemmCfg& c = kCfgs[cfg];
-  const int bm = (c.kind == 4 || c.kind == 5) ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
+  const int bm = c.kind == 11 ? 256 : (c.kind == 4 || c.kind == 5 || c.kind == 9) ? 128 : (c.kind == 0 ? 2 : 1) * c.tm * 32;
   const double a_bytes = mode == GEMM_CONV ? (double)p.M * p.stride * p.stride * p.Cin * 4.0 : (double)p.M * p.K * 4.0;
   const double w_bytes = (double)p.N * p.K * 4.0;
   const bool fits = (p.M + bm - 1) / bm >= 8;

@@ -1,3 +1,5 @@
+// RESEARCH LIBRARY COPY of csrc/gemm_big.hip (libcotr_hip_exp.so only): the product file with the research / dead-end paths that used to sit
+// behind #ifdef COTR_EXPERIMENTAL in it resolved IN (tools/unifdef_exp.py -D).  The product never compiles this file.
 // Large-tile fp32 MFMA GEMM / implicit-GEMM convolution for the batched regime (many image pairs per call: zoom-in
 // engine at B=32, dense pass, config 3), gfx950.  Same contract and fused epilogue as gemm.hip (GemmParams).
 //
@@ -17,15 +19,26 @@
 // exactly this traffic.
 #include <type_traits>
 
-#include "common.h"
+#include "../common.h"
 
 #define BK 32
+#include "gemm_h2.h"
 
-// (The research library keeps its own copy of this file with three-stage, direct-epilogue and split-f16 forms of the same tile:
-// csrc/experimental/gemm_big.hip.)
-template <int TN, int MODE>
+// NST = LDS stages: 2 = every barrier drains the LDS-DMA queue (vmcnt(0)); 3 = ring with TWO tiles in flight: the wait before
+// the barrier of step t is a counted vmcnt that covers tile t only, tile t+1 stays in flight across the barrier (raw s_barrier,
+// no fence: __syncthreads() would drain the queue) and tile t+2 is requested right after it.
+// DIRECT (experiment, configurations 44 / 45): the epilogue stores straight from the accumulators - a wave store = rows r and r + 4 of a
+// 32-column block = two full 128-B lines - instead of staging 32 rows at a time through LDS for float4 row stores: no LDS round trip, no
+// barrier between the K loop and the epilogue, 4x the store instructions.  Same arithmetic per element: bit-identical.
+// X selects an experimental form (libcotr_hip_exp.so only): 0 = the product kernel, 1 = DIRECT, 2 = H2 (configurations 46 / 47,
+// experimental/gemm_h2.h): both operands arrive as PACKED SPLIT-f16 dwords (cotr_op_split_h2) and every fp32 product becomes three
+// v_mfma_f32_32x32x16_f16 - research, NOT bit-identical to the fp32 path.
+// NW = wavefronts (4: the 128-row tile of every product configuration; 8: a 256-row tile, experimental configuration 51: a wavefront still
+// fetches 32 A rows, half as many W rows, and the tile moves 25 % fewer bytes per flop)
+template <int TN, int MODE, int NST, int X = 0, int NW = 4>
 __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid) {
-  constexpr int NW = 4;                   // wavefronts: 2 x 2, each 64 x (32*TN)
+  constexpr bool DIRECT = X == 1;
+  [[maybe_unused]] constexpr bool H2 = X == 2;
   constexpr int BM = 32 * NW, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage
   constexpr int QW = BN / (8 * NW);       // W-tile DMA instructions per wavefront
@@ -108,6 +121,15 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  f32x16 accx[H2 ? 2 : 1][H2 ? TN : 1];                 // H2: the cross terms (hi x lo + lo x hi), scaled by 2^11
+  if constexpr (H2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[a][b][r] = 0.f;
+  }
 
   // both stages are requested up front; the residual tile (epilogue layout: row it*RPI + er, 4 columns at ec) follows
   // them so that its HBM latency is paid under the first barrier / the MFMAs instead of after them
@@ -119,7 +141,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
   const int er = lane / C4, ec = (lane % C4) * 4;
   const int ncol = n0 + wn * 32 * TN + ec;
   f32x4 res[2][NIT];
-  if (p.residual) {
+  if (!DIRECT && p.residual) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -129,13 +151,32 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
         res[a][it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)mr * p.ldr + ncol);
       }
   }
+  int st = 0;                                           // stage of tile kt
   for (int kt = 0; kt < KT; ++kt) {
-    LDS_DMA_WAIT_ALL();                                 // this wavefront's share of tile kt (and kt+1) has landed ...
-    __syncthreads();                                    // ... and so has everybody else's; stage (kt+1)&1 is free
-    if (kt >= 1 && kt + 1 < KT) dma_tile(kt + 1, (kt + 1) & 1);
-    const int st = kt & 1;                              // stage of tile kt
+    if constexpr (NST == 2) {
+      LDS_DMA_WAIT_ALL();                               // this wavefront's share of tile kt (and kt+1) has landed ...
+      __syncthreads();                                  // ... and so has everybody else's; stage (kt+1)&1 is free
+      if (kt >= 1 && kt + 1 < KT) dma_tile(kt + 1, (kt + 1) & 1);
+      st = kt & 1;
+    } else {
+      // in flight, oldest first: [tile kt] [tile kt+1]; one tile = 4 + QW DMA instructions per wavefront.  (In the first
+      // steps the residual prefetch sits behind tile 1 and is waited for too - conservative, not wrong.)
+      if (kt + 1 < KT) {
+        static_assert(QW == 4 || QW == 2, "counted wait: one tile = 4 + QW DMA instructions per wavefront");
+        if constexpr (QW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                     // everybody's share of tile kt is in LDS; stage (kt+2)%3 is free
+      asm volatile("" ::: "memory");                    // no LDS access of this step may be scheduled above the barrier
+      if (kt + 2 < KT) dma_tile(kt + 2, st == 0 ? 2 : st - 1);
+    }
     const float* As = smem + st * STAGE + (wm * 64 + l31) * BK;
     const float* Ws = smem + st * STAGE + BM * BK + (wn * 32 * TN + l31) * BK;
+    if constexpr (H2) {
+      h2_kstep<TN>(As, Ws, hh, sw, acc, accx);
+    } else
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ch = ((j * 2 + hh) ^ sw) * 4;
@@ -152,6 +193,46 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
           for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
     }
+    if constexpr (NST == 3) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this step's fragment reads are retired before the next barrier
+      st = st == 2 ? 0 : st + 1;
+    }
+  }
+  if constexpr (H2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = fmaf(accx[a][b][r], 0x1p-11f, acc[a][b][r]);
+  }
+  if constexpr (DIRECT) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * 32 * TN + b * 32 + l31;
+        const float scv = p.scale ? p.scale[col] : 1.f, biv = p.bias ? p.bias[col] : 0.f;
+        const float csv = col < p.colscale_n ? p.colscale : 1.f;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          rv[r] = 0.f;
+          if (p.residual && m < p.M) rv[r] = p.residual[(size_t)(p.res_row_mod > 0 ? fastmod(m, p.fd_resrow) : m) * p.ldr + col];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          float x = acc[a][b][r];
+          x = p.scale ? fmaf(x, scv, biv) : x + biv;
+          x *= csv;
+          if (p.residual) x += rv[r];
+          if (p.relu) x = (x < 0.f) ? 0.f : x;
+          if (m < p.M) p.C[(size_t)m * p.ldc + col] = x;
+        }
+      }
+    return;
   }
   __syncthreads();                                      // every wavefront is done reading the operand stages
 
@@ -182,9 +263,14 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
           float x = v[e];
           x = p.scale ? fmaf(x, sc[e], bi[e]) : x + bi[e];
           x *= cs[e];
+          if constexpr (H2) {
+            const float rv = res[a][it][e];   // (a scalar copy: __builtin_bit_cast on the vector element reads element 0 with this hipcc)
+            if (p.residual) x += (p.h2_flags & 2) ? h2_unpack(__float_as_uint(rv)) : rv;
+          } else
           if (p.residual) x += res[a][it][e];
           if (p.relu) x = (x < 0.f) ? 0.f : x;
           v[e] = x;
+          if constexpr (H2) if (p.h2_flags & 1) v[e] = __uint_as_float(h2_pack(x));
         }
         *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + ncol) = v;
       }
@@ -203,7 +289,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
 // Three LDS stages, ONE barrier per K step: the loaders wait (counted vmcnt) until tile kt has landed, everybody meets at the
 // barrier, the loaders request tile kt+2 into the stage whose readers passed this very barrier after finishing tile kt-1, the MFMA
 // wavefronts consume tile kt.  Same tile decomposition, same k order, same epilogue as gemm_big_body: bit-identical results.
-template <int TN, int MODE>
+template <int TN, int MODE, bool H2 = false>   // H2 (experimental, configurations 48 / 49): packed split-f16 operands, experimental/gemm_h2.h
 __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr int STAGE = (BM + BN) * BK;   // floats per stage (one 32-deep K tile)
@@ -309,6 +395,15 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  f32x16 accx[H2 ? 2 : 1][H2 ? TN : 1];                 // H2: the cross terms, scaled by 2^11
+  if constexpr (H2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accx[a][b][r] = 0.f;
+  }
   constexpr int C4 = 8 * TN;
   constexpr int RPI = 64 / C4;
   constexpr int NIT = 32 / RPI;
@@ -343,6 +438,11 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
       for (int b = 0; b < TN; ++b) r.b[b] = *reinterpret_cast<const f32x4*>(Ws + b * 32 * BK + ch);
       return r;
     };
+    if constexpr (H2) {
+      h2_kstep<TN>(As, Ws, hh, sw, acc, accx);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      continue;
+    }
     // the reads of slice j+1 are issued before the 8 TN MFMAs of slice j (hipcc on its own leaves a read two MFMAs of cover)
     Frag cur = load_frag(0);
 #pragma unroll
@@ -363,6 +463,14 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
   if (p.ws_flags & 1) __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_s_barrier();                         // every MFMA wavefront is done reading the operand stages
   asm volatile("" ::: "memory");
+  if constexpr (H2) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = fmaf(accx[a][b][r], 0x1p-11f, acc[a][b][r]);
+  }
 
   float* Es = smem + wave * 32 * EP;
   f32x4 sc, bi, cs;
@@ -390,9 +498,14 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
           float x = v[e];
           x = p.scale ? fmaf(x, sc[e], bi[e]) : x + bi[e];
           x *= cs[e];
+          if constexpr (H2) {
+            const float rv = res[a][it][e];
+            if (p.residual) x += (p.h2_flags & 2) ? h2_unpack(__float_as_uint(rv)) : rv;
+          } else
           if (p.residual) x += res[a][it][e];
           if (p.relu) x = (x < 0.f) ? 0.f : x;
           v[e] = x;
+          if constexpr (H2) if (p.h2_flags & 1) v[e] = __uint_as_float(h2_pack(x));
         }
         *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + ncol) = v;
       }
@@ -400,14 +513,14 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
   }
 }
 
-template <int TN, int MODE>
+template <int TN, int MODE, bool H2 = false>
 __global__ __launch_bounds__(512) void gemm_ws_kernel(const GemmParams p) {
-  gemm_ws_body<TN, MODE>(p, blockIdx.x);
+  gemm_ws_body<TN, MODE, H2>(p, blockIdx.x);
 }
 
 // knob KN_WS_FLAGS: bit 0 = s_setprio(1) around the MFMA wavefronts' loop, bit 1 = s_setprio(3) for the loaders
 
-template <int TN, int MODE>
+template <int TN, int MODE, bool H2 = false>
 static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   constexpr int BM = 128, BN = 64 * TN;
   constexpr size_t smem = (size_t)4 * (BM + BN) * BK * sizeof(float);
@@ -420,7 +533,7 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   if (p.zeros == nullptr) return -2;
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<TN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<TN, MODE, H2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
       return -2;
     attr_set.set();
@@ -428,20 +541,20 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
   p.ws_flags = knob(KN_WS_FLAGS);
   const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_ws_kernel<TN, MODE>), dim3(tiles), dim3(512), smem, s, p);
+  hipLaunchKernelGGL((gemm_ws_kernel<TN, MODE, H2>), dim3(tiles), dim3(512), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-template <int TN, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_big_kernel(const GemmParams p) {
-  gemm_big_body<TN, MODE>(p, blockIdx.x);
+template <int TN, int MODE, int NST, int X = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void gemm_big_kernel(const GemmParams p) {
+  gemm_big_body<TN, MODE, NST, X, NW>(p, blockIdx.x);
 }
 
 // two independent problems in one grid (common.h: launch_gemm_dual_cfg)
-template <int TN, int MODE>
+template <int TN, int MODE, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_big_dual_kernel(const GemmParams p0, const GemmParams p1, const int tiles0) {
-  if ((int)blockIdx.x < tiles0) gemm_big_body<TN, MODE>(p0, blockIdx.x);
-  else gemm_big_body<TN, MODE>(p1, (int)blockIdx.x - tiles0);
+  if ((int)blockIdx.x < tiles0) gemm_big_body<TN, MODE, NST>(p0, blockIdx.x);
+  else gemm_big_body<TN, MODE, NST>(p1, (int)blockIdx.x - tiles0);
 }
 
 template <int TN>
@@ -458,14 +571,14 @@ static int launch_big_dual_t(const GemmParams& a, const GemmParams& b, hipStream
   }
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_dual_kernel<TN, GEMM_CONV>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_dual_kernel<TN, GEMM_CONV, 2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set.set();
   }
   if (!gemm_fill_divs(p0, GEMM_CONV, BM, BN) || !gemm_fill_divs(p1, GEMM_CONV, BM, BN)) return -1;
   const int tiles0 = gemm_grid_tiles(p0, BM, BN), tiles1 = gemm_grid_tiles(p1, BM, BN);
-  hipLaunchKernelGGL((gemm_big_dual_kernel<TN, GEMM_CONV>), dim3(tiles0 + tiles1), dim3(256), smem, s, p0, p1, tiles0);
+  hipLaunchKernelGGL((gemm_big_dual_kernel<TN, GEMM_CONV, 2>), dim3(tiles0 + tiles1), dim3(256), smem, s, p0, p1, tiles0);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -474,11 +587,11 @@ int launch_gemm_big_dual(int mode, int variant, const GemmParams& p0, const Gemm
   return variant == 0 ? launch_big_dual_t<2>(p0, p1, s) : variant == 1 ? launch_big_dual_t<1>(p0, p1, s) : -1;
 }
 
-template <int TN, int MODE>
+template <int TN, int MODE, int NST, int X = 0, int NW = 4>
 static int launch_big_t(const GemmParams& p0, hipStream_t s) {
-  constexpr int BM = 128, BN = 64 * TN;
-  constexpr size_t smem = (size_t)2 * (BM + BN) * BK * sizeof(float);
-  static_assert(smem >= (size_t)4 * 32 * (32 * TN + 4) * sizeof(float), "epilogue staging fits in the operand stages");
+  constexpr int BM = 32 * NW, BN = 64 * TN;
+  constexpr size_t smem = (size_t)NST * (BM + BN) * BK * sizeof(float);
+  static_assert(smem >= (size_t)NW * 32 * (32 * TN + 4) * sizeof(float), "epilogue staging fits in the operand stages");
   GemmParams p = p0;
   if (p.N % BN != 0 || p.K % BK != 0 || p.M <= 0 || p.A2 != nullptr) return -1;
   if (p.ldc % 4 != 0 || (p.residual && p.ldr % 4 != 0)) return -1;
@@ -487,26 +600,35 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
   if (p.zeros == nullptr) return -2;
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<TN, MODE, NST, X, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return -2;
     attr_set.set();
   }
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
   const int tiles = gemm_grid_tiles(p, BM, BN);
-  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE>), dim3(tiles), dim3(256), smem, s, p);
+  hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST, X, NW>), dim3(tiles), dim3(64 * NW), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
-// variant 0: 128 x 128 tile, 1: 128 x 64 (two LDS stages); 4, 5: the same
+// variant 0: 128 x 128 tile, 1: 128 x 64 (two LDS stages); 2, 3: the same tiles with the three-stage ring; 4, 5: the same
 // tiles with 4 loader + 4 MFMA wavefronts (gemm_ws_body)
 int launch_gemm_big(int mode, int variant, const GemmParams& p, hipStream_t s) {
   if (mode == GEMM_DENSE && p.lda % 4 != 0) return -1;
   if (mode != GEMM_DENSE && mode != GEMM_CONV) return -1;
   const bool d = mode == GEMM_DENSE;
   switch (variant) {
-    case 0: return d ? launch_big_t<2, GEMM_DENSE>(p, s) : launch_big_t<2, GEMM_CONV>(p, s);
-    case 1: return d ? launch_big_t<1, GEMM_DENSE>(p, s) : launch_big_t<1, GEMM_CONV>(p, s);
+    case 0: return d ? launch_big_t<2, GEMM_DENSE, 2>(p, s) : launch_big_t<2, GEMM_CONV, 2>(p, s);
+    case 1: return d ? launch_big_t<1, GEMM_DENSE, 2>(p, s) : launch_big_t<1, GEMM_CONV, 2>(p, s);
+    case 2: return d ? launch_big_t<2, GEMM_DENSE, 3>(p, s) : launch_big_t<2, GEMM_CONV, 3>(p, s);
+    case 3: return d ? launch_big_t<1, GEMM_DENSE, 3>(p, s) : launch_big_t<1, GEMM_CONV, 3>(p, s);
+    case 6: return d ? launch_big_t<2, GEMM_DENSE, 2, 1>(p, s) : launch_big_t<2, GEMM_CONV, 2, 1>(p, s);   // direct epilogue
+    case 7: return d ? launch_big_t<1, GEMM_DENSE, 2, 1>(p, s) : launch_big_t<1, GEMM_CONV, 2, 1>(p, s);
+    case 8: return d ? launch_big_t<2, GEMM_DENSE, 2, 2>(p, s) : launch_big_t<2, GEMM_CONV, 2, 2>(p, s);   // packed split-f16 operands
+    case 9: return d ? launch_big_t<1, GEMM_DENSE, 2, 2>(p, s) : launch_big_t<1, GEMM_CONV, 2, 2>(p, s);
+    case 10: return d ? launch_ws_t<2, GEMM_DENSE, true>(p, s) : launch_ws_t<2, GEMM_CONV, true>(p, s);   // packed split-f16, wave-specialised
+    case 11: return d ? launch_ws_t<1, GEMM_DENSE, true>(p, s) : launch_ws_t<1, GEMM_CONV, true>(p, s);
+    case 12: return d ? launch_big_t<2, GEMM_DENSE, 3, 2, 8>(p, s) : launch_big_t<2, GEMM_CONV, 3, 2, 8>(p, s);   // packed split-f16, 256 x 128 tile, 8 wavefronts, 3 stages
     case 4: return d ? launch_ws_t<2, GEMM_DENSE>(p, s) : launch_ws_t<2, GEMM_CONV>(p, s);   // wave-specialised 128 x 128
     case 5: return d ? launch_ws_t<1, GEMM_DENSE>(p, s) : launch_ws_t<1, GEMM_CONV>(p, s);   // wave-specialised 128 x 64
     default: return -1;

@@ -1,6 +1,8 @@
+// RESEARCH LIBRARY COPY of csrc/pointwise.hip (libcotr_hip_exp.so only): the product file with the research / dead-end paths that used to sit
+// behind #ifdef COTR_EXPERIMENTAL in it resolved IN (tools/unifdef_exp.py -D).  The product never compiles this file.
 // HBM-bound kernels of the COTR forward path: LayerNorm, lin_sine positional encoding,
 // 3x3/2 max-pool on NHWC side-by-side activations, and the final 256 -> 2 regression head.
-#include "common.h"
+#include "../common.h"
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over rows of 256 (nn.LayerNorm(256), eps 1e-5, biased variance): one wavefront per
@@ -34,16 +36,56 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // LayerNorm of (sum of `np` partial outputs [np][rows][256] + bias + residual): the tail of the fused FFN block
 // (ffn.hip): y = LN(residual + linear2(...)) with linear2's bias (transformer.py:156-158, 199-201).
+// (Experimental build only: with pre_w != nullptr the residual is LayerNorm(pre_w, pre_b) of the given (pre-norm) row: the norm
+// after the attention sub-layer, whose only consumers are the FFN (ffn_fused_kernel normalises its X tile itself) and this residual.)
+struct LnWarm {
+  const float* p[2];
+  int lines[2];
+};
+static thread_local LnWarm g_ln_warm = {{nullptr, nullptr}, {0, 0}};
+// the next ln_reduce launch of this thread also touches these two regions (bytes): experiment of knob l2_warm
+void set_ln_reduce_warm(const float* p0, size_t b0, const float* p1, size_t b1) {
+  g_ln_warm.p[0] = p0; g_ln_warm.lines[0] = (int)(b0 / 128);
+  g_ln_warm.p[1] = p1; g_ln_warm.lines[1] = (int)(b1 / 128);
+}
+
 __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ parts, int np, const float* __restrict__ bias,
-                                                        const float* __restrict__ residual, const float* __restrict__ w,
+                                                        const float* __restrict__ residual, const float* __restrict__ pre_w,
+                                                        const float* __restrict__ pre_b, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ post_w,
-                                                        const float* __restrict__ post_b, float* __restrict__ y, int rows) {
+                                                        const float* __restrict__ post_b, float* __restrict__ y, int rows
+                                                        , const LnWarm warm
+) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // experiment (knob l2_warm): pull the NEXT launch's weights through this XCD's L2 while this (latency-bound) launch runs - workgroup
+  // b runs on XCD b % 8 and touches slice b / 8 of each region, one 128-B line per lane and load; the values are never used
+  float warm_acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (warm.p[k] != nullptr) {
+      const int slots = gridDim.x >> 3, slot = blockIdx.x >> 3;
+      if (slots > 0 && slot < slots) {
+        const int per = (warm.lines[k] + slots - 1) / slots;
+        const int l0 = slot * per, l1 = l0 + per < warm.lines[k] ? l0 + per : warm.lines[k];
+        for (int l = l0 + (int)threadIdx.x; l < l1; l += 256) warm_acc += warm.p[k][(size_t)l * 32];   // (consumed at the very end)
+      }
+    }
+  }
   if (row >= rows) return;
   f32x4 v = *reinterpret_cast<const f32x4*>(bias + lane * 4);
   f32x4 rr = {0.f, 0.f, 0.f, 0.f};
   if (residual != nullptr) rr = *reinterpret_cast<const f32x4*>(residual + (size_t)row * 256 + lane * 4);
+  if (pre_w != nullptr) {
+    const float mu = wave_sum(rr[0] + rr[1] + rr[2] + rr[3]) * (1.f / 256.f);
+    const f32x4 dd = {rr[0] - mu, rr[1] - mu, rr[2] - mu, rr[3] - mu};
+    const float va = wave_sum(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3]) * (1.f / 256.f);
+    const float rs = 1.f / sqrtf(va + 1e-5f);
+    const f32x4 pw = *reinterpret_cast<const f32x4*>(pre_w + lane * 4);
+    const f32x4 pb = *reinterpret_cast<const f32x4*>(pre_b + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rr[i] = dd[i] * rs * pw[i] + pb[i];
+  }
   v += rr;
   // the partial rows are independent loads: request 8 at a time and add them in order afterwards (a plain
   // "for c: v += load" is np dependent L2 round trips - the loop is not unrolled for a runtime np); same sum order as before
@@ -78,16 +120,26 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict_
     for (int i = 0; i < 4; ++i) out[i] = d2[i] * r2 * w2[i] + b2[i];
   }
   *reinterpret_cast<f32x4*>(y + (size_t)row * 256 + lane * 4) = out;
+  if (warm_acc == 1.2345678e33f) y[0] = warm_acc;   // never true: keeps the warm loads (and their registers) alive to the end
 }
 
 int launch_ln_reduce_post(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                           const float* post_w, const float* post_b, float* y, int rows, hipStream_t s) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, w, b,
-                     post_w, post_b, y, rows);
+  const LnWarm warm = g_ln_warm;
+  g_ln_warm = LnWarm{{nullptr, nullptr}, {0, 0}};
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, nullptr, nullptr, w, b,
+                     post_w, post_b, y, rows, warm);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+int launch_ln_reduce_pre(const float* parts, int np, const float* bias, const float* residual, const float* pre_w,
+                         const float* pre_b, const float* w, const float* b, float* y, int rows, hipStream_t s) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, parts, np, bias, residual, pre_w, pre_b, w, b,
+                     nullptr, nullptr, y, rows, LnWarm{{nullptr, nullptr}, {0, 0}});
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 int launch_ln_reduce(const float* parts, int np, const float* bias, const float* residual, const float* w, const float* b,
                      float* y, int rows, hipStream_t s) {

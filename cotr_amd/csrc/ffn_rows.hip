@@ -54,7 +54,8 @@ constexpr int FR_XS = 8 * FR_BM * 32;                    // floats of the X tile
 constexpr int FR_RING = FR_NSLOT * FR_PIECE;             // floats of one wavefront's ring
 constexpr int FR_MAIN = FR_XS + 4 * FR_RING + FR_H;       // floats of the main loop's LDS: X tile, rings, b1
 constexpr int FR_EPI = 4 * 32 * FR_LDT;                   // floats of the epilogue tiles (they alias the main loop's)
-constexpr size_t kFfnRowsSmem = (size_t)(FR_MAIN > FR_EPI ? FR_MAIN : FR_EPI) * sizeof(float);
+constexpr int FR_PAR = FR_MAIN > FR_EPI ? FR_MAIN : FR_EPI;   // behind both: b2, ln_w, ln_b, post_w, post_b (staged once: the epilogue reads them from LDS)
+constexpr size_t kFfnRowsSmem = (size_t)(FR_PAR + 5 * FR_D) * sizeof(float);
 static_assert(kFfnRowsSmem <= 160 * 1024, "LDS");
 
 // sum over the 8 lanes of an aligned group (all of them get it): two quad permutes and a half-row mirror, DPP - no LDS crossbar
@@ -232,6 +233,14 @@ __global__ __launch_bounds__(256, 1) void ffn_rows_kernel(const FfnRowsParams p)
     fr_dma16(src, Xs + kt * (FR_BM * 32) + rg * 256);
   }
   *reinterpret_cast<f32x4*>(b1s + t * 4) = *reinterpret_cast<const f32x4*>(p.b1 + t * 4);
+  float* pars = smem + FR_PAR;
+  pars[t] = p.b2[t];
+  pars[FR_D + t] = p.ln_w[t];
+  pars[2 * FR_D + t] = p.ln_b[t];
+  if (p.post_w != nullptr) {
+    pars[3 * FR_D + t] = p.post_w[t];
+    pars[4 * FR_D + t] = p.post_b[t];
+  }
 #pragma unroll
   for (int s = 0; s < FR_NSLOT - 1; ++s)
 #pragma unroll
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void ffn_rows_kernel(const FfnRowsParams p)
       f32x4 v = *reinterpret_cast<const f32x4*>(src);
 #pragma unroll
       for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(src + w * (32 * FR_LDT));   // fixed order w0 + w1 + w2 + w3
-      v += *reinterpret_cast<const f32x4*>(p.b2 + c * 32 + eseg);
+      v += *reinterpret_cast<const f32x4*>(pars + c * 32 + eseg);
       x[c] += v;
       s1 += (x[c][0] + x[c][1]) + (x[c][2] + x[c][3]);
     }
@@ -311,8 +320,8 @@ __global__ __launch_bounds__(256, 1) void ffn_rows_kernel(const FfnRowsParams p)
     s1 = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const f32x4 lw = *reinterpret_cast<const f32x4*>(p.ln_w + c * 32 + eseg);
-      const f32x4 lb = *reinterpret_cast<const f32x4*>(p.ln_b + c * 32 + eseg);
+      const f32x4 lw = *reinterpret_cast<const f32x4*>(pars + FR_D + c * 32 + eseg);
+      const f32x4 lb = *reinterpret_cast<const f32x4*>(pars + 2 * FR_D + c * 32 + eseg);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         x[c][e] = x[c][e] * rstd * lw[e] + lb[e];
@@ -332,8 +341,8 @@ __global__ __launch_bounds__(256, 1) void ffn_rows_kernel(const FfnRowsParams p)
       const float r2 = 1.f / sqrtf(fr_group8_sum(s2) * (1.f / 256.f) + 1e-5f);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const f32x4 pw = *reinterpret_cast<const f32x4*>(p.post_w + c * 32 + eseg);
-        const f32x4 pb = *reinterpret_cast<const f32x4*>(p.post_b + c * 32 + eseg);
+        const f32x4 pw = *reinterpret_cast<const f32x4*>(pars + 3 * FR_D + c * 32 + eseg);
+        const f32x4 pb = *reinterpret_cast<const f32x4*>(pars + 4 * FR_D + c * 32 + eseg);
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[c][e] = x[c][e] * r2 * pw[e] + pb[e];
       }

@@ -193,11 +193,15 @@ class COTR(nn.Module):
             self._release()
             handle = ctypes.c_void_p()
             _lib.check(lib.cotr_create(ctypes.byref(handle), index), None, 'cotr_create')
+            try:                                          # the remembered knobs go on BEFORE the handle is published: a knob the library
+                for name, value in self.__dict__.get('_knobs', {}).items():   # refuses must not leave a half-configured handle behind
+                    _lib.set_knob(name, value, handle)
+            except Exception:
+                lib.cotr_destroy(handle)
+                raise
             self._handle, self._handle_device = handle, index
             self._weights_dirty = True
             self._ws, self._ws_shape = None, (0, 0)
-            for name, value in self.__dict__.get('_knobs', {}).items():
-                _lib.set_knob(name, value, handle)
         if self._weights_dirty:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             bad = [k for k, v in sd.items() if v.dtype != torch.float32]
@@ -381,10 +385,13 @@ class COTR(nn.Module):
         """One tuning knob of this model's library handle (cotr_set_knob(h, ...)): other models - and other threads - keep theirs.
         Remembered, so it survives a move to another GPU; fusion thresholds / encode_chunk change the scratch the library needs,
         so the workspace is re-sized at the next call."""
+        if self.__dict__.get('_ws_pins'):
+            raise _lib.CotrHipError('tuning knobs change the carving of the workspace, and a captured training step (GraphedTrainStep) has '
+                                    'its addresses baked in: set knobs before capturing, or close() the captured step first')
         if self._handle is not None:
             _lib.set_knob(name, value, self._handle)
         else:
-            _lib.load_library()
+            _lib.validate_knob(name, value)               # no handle yet: checked against the library's registry now, applied later
         self._knobs[name] = int(value)
         self._ws_stale = True
 
@@ -395,6 +402,8 @@ class COTR(nn.Module):
         return {k: (self._knobs.get(k, v[1]), v[1]) for k, v in _lib.knobs(None).items()}
 
     def reset_knobs(self):
+        if self.__dict__.get('_ws_pins') and self._knobs:
+            raise _lib.CotrHipError('tuning knobs cannot change while a captured training step has the workspace pinned')
         if self._handle is not None:
             _lib.reset_knobs(self._handle)
         self._knobs = {}

@@ -38,6 +38,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden and linked with a version script made from this header (cotr_amd/build.py): the
+ * functions declared here are its ONLY dynamic symbols. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define COTR_HIP_ABI_VERSION 2   /* 2: tuning knobs per handle (cotr_set_knob(h, ...)), the cotr_set_<knob>(int) functions are gone;
                                   cotr_train_attention_bwd takes a scratch argument; experiments live in libcotr_hip_exp.so */
@@ -436,6 +441,9 @@ int cotr_op_attention_h2(const float* q, int ldq, int q_packed, const float* k, 
                          int nb, int nq, cotr_stream stream);
 #endif
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

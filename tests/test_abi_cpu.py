@@ -33,6 +33,13 @@ def exported_functions(path):
     return sorted(l.split()[-1] for l in out.splitlines() if ' T cotr_' in l)
 
 
+def dynamic_symbols(path):
+    """every defined dynamic symbol of a shared object, whatever its type"""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+
+
 def test_library_builds_and_exports_every_declared_symbol():
     """Both ways round, for both libraries: every declared function is exported and every exported cotr_* function is declared
     (the experimental library = the product's declarations + the #ifdef COTR_EXPERIMENTAL block)."""
@@ -43,6 +50,10 @@ def test_library_builds_and_exports_every_declared_symbol():
         names = declared_functions(experimental)
         assert len(names) >= 20
         assert exported_functions(path) == names, (set(names) ^ set(exported_functions(path)))
+        # a sealed C ABI: the header's functions are the ONLY dynamic symbols - no kernel host stubs (_Z...), no thread-local knob /
+        # device slots (cotr_tls_*), no C++ runtime leftovers (-fvisibility=hidden + a version script made from the header)
+        extra = [n for n in dynamic_symbols(path) if n not in names]
+        assert not extra, extra[:10]
     assert set(_lib.EXPORTED_SYMBOLS) <= set(declared_functions())          # the ctypes binding binds only declared symbols
     assert set(_lib.EXPERIMENTAL_SYMBOLS) == set(declared_functions(True)) - set(declared_functions())
     assert _lib.load_library().cotr_abi_version() == _lib.ABI_VERSION == 2
@@ -114,7 +125,7 @@ def test_knob_registry_round_trip_without_a_gpu():
     op-level entry points read.  count / name / get / set / reset need no device; the model object remembers knobs set before
     its handle exists.  The product library does not know the knobs of the measured dead ends."""
     k0 = _lib.knobs()
-    assert len(k0) == 18 and all(cur == dflt for cur, dflt in k0.values())
+    assert len(k0) == 20 and all(cur == dflt for cur, dflt in k0.values())
     assert k0['attention_fusion_max_rows'] == (1024, 1024) and k0['encode_chunk'] == (64, 64)
     for exp_only in ('head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail', 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs'):
         assert exp_only not in k0
@@ -150,7 +161,7 @@ def test_experimental_library_has_the_dead_ends_and_their_knobs():
     assert _lib.load_library().cotr_is_experimental() == 0
     lib.cotr_knob_name.restype = ctypes.c_char_p
     names = [lib.cotr_knob_name(i).decode() for i in range(lib.cotr_knob_count())]
-    assert names[:18] == list(_lib.knobs()) and names[18:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
+    assert names[:20] == list(_lib.knobs()) and names[20:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
                                                                  'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs']
     for n, want in (('head_fusion_max_rows', 0), ('ffn_preln', 0), ('ffn_tail', 0), ('coop_tail', 0), ('gemm_ln_min_rows', 1 << 30),
                     ('l2_warm', 0), ('split_f16', 0), ('split_f16_min_pairs', 8)):

@@ -61,3 +61,14 @@ def test_every_multi_rank_line_names_its_ranks():
     assert line['rccl_ranks'] == 2 and len(line['ranks']) == 2
     single = _run(['--workload', 'dense', '--dry-run', '--backend', 'gloo'], _clean_env())
     assert single['rccl_ranks'] == 1 and single['dense_check']['queries_this_rank'] == 1031
+
+
+def test_dense_workload_on_eight_ranks_shards_the_full_query_grid():
+    """SURVEY 8(e) without the node: `python bench.py --workload dense --gpus 8` starts eight ranks, shards the 131 072 queries of the
+    dense pass (inference_helper.py:105-165) 16 384 per rank, gathers them inside the timed region and names its eight ranks."""
+    line = _run(['--gpus', '8', '--workload', 'dense', '--backend', 'gloo', '--dry-run', '--dry-queries', '131072', '--steps', '2', '--warmup', '1'],
+                _clean_env())
+    assert line['n_gpus'] == 8 and line['rccl_ranks'] == 8 and line['scaling'] == 'strong'
+    assert line['dense_check'] == {'equals_unsharded': True, 'queries_this_rank': 16384, 'queries_total': 131072}
+    assert line['gathered_rows'] == 131072
+    assert [r['rank'] for r in line['ranks']] == list(range(8)) and len({r['pid'] for r in line['ranks']}) == 8
