@@ -22,7 +22,8 @@ FORKED = ['gemm.hip', 'gemm_big.hip', 'attention.hip', 'pointwise.hip', 'ffn.hip
 SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip',
            'dense_post.hip', 'ffn.hip', 'ffn_rows.hip', 'att_rows.hip', 'train.hip', 'attention_train.hip', 'api.hip']
 EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip'), os.path.join('experimental', 'gemm_pp.hip'),
-               os.path.join('experimental', 'gemm_h2.hip'), os.path.join('experimental', 'attention_h2.hip'), os.path.join('experimental', 'gemm_h2r.hip')]
+               os.path.join('experimental', 'gemm_h2.hip'), os.path.join('experimental', 'attention_h2.hip'), os.path.join('experimental', 'gemm_h2r.hip'),
+               os.path.join('experimental', 'linear_rows.hip')]
 # Pillow-exact resamples and the torch-CPU-exact cycle map (8-bit, float and double code whose products must not be contracted into
 # FMAs behind the source's back; the FMAs that belong there are explicit)
 EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ffp-contract=off'],

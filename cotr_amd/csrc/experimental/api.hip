@@ -99,6 +99,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"l2_warm", 0, 0, 3},
     {"split_f16", 0, 0, 3},
     {"split_f16_min_pairs", 8, 1, INT_MAX},
+    {"linear_rows_min_rows", 1 << 30, 0, INT_MAX},
 };
 bool knob_value_ok(int id, int v) {
   if (v < kKnobs[id].lo || v > kKnobs[id].hi) return false;

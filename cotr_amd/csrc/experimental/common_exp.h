@@ -81,6 +81,7 @@ enum KnobId {
   KN_L2_WARM,                    // ln_reduce launches also touch the next launch's weights (weights-ahead L2 warmer; bit 0 FFN weights, bit 1 attention weights; measured slower)
   KN_SPLIT_F16,                  // RESEARCH (experimental/gemm_h2.h): 1 = the backbone + input_proj of a pass run on packed split-f16 activations / weights (three f16 MFMAs per fp32 product), 2 = also the transformer's projections and FFN GEMMs of the unfused (many-row) path
   KN_SPLIT_F16_MIN_PAIRS,        // ... the backbone pass only from this many pairs per pass (below, the tuned small-tile fp32 kernels win: 8)
+  KN_LINEAR_ROWS_MIN_ROWS,       // round 5, measured slower: K = 128 / 256 products on 64-row tiles with the A tile resident (experimental/linear_rows.hip) from this many rows (off)
   KN_COUNT
 };
 struct KnobSet {
@@ -303,6 +304,9 @@ int launch_ffn_rows(const float* X, const float* W1, const float* b1, const floa
 int launch_att_rows(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq, float qscale,
                     const float* k, const float* v, int ldkv, const float* wo, const float* bo, const float* residual,
                     const float* ln_w, const float* ln_b, float* Y, int nb, int nq, hipStream_t s);
+// K-short dense products for many rows (linear_rows.hip); launch_gemm takes it where linear_rows_applies
+bool linear_rows_applies(int mode, const GemmParams& p);
+int launch_linear_rows(const GemmParams& p, hipStream_t s);
 // one whole layer1 bottleneck in one launch (bottleneck.hip); w2p / w3p / wdp are the packed fragment arrays (bottleneck_pack_*)
 int launch_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2p, const float* w3p, const float* wdp,
                       const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,

@@ -1086,6 +1086,10 @@ const float* gemm_zero_buffer() {
 }
 
 int launch_gemm(int mode, const GemmParams& p, hipStream_t s) {
+  if (linear_rows_applies(mode, p)) {   // K-short products over many rows: the A tile resident, the weights streamed (linear_rows.hip)
+    const int r = launch_linear_rows(p, s);
+    if (r != -1) return r;
+  }
   const int cfg = gemm_pick_config(mode, p);
   if (cfg < 0) return -1;
   return launch_gemm_cfg(mode, cfg, p, s);

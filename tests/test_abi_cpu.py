@@ -162,7 +162,8 @@ def test_experimental_library_has_the_dead_ends_and_their_knobs():
     lib.cotr_knob_name.restype = ctypes.c_char_p
     names = [lib.cotr_knob_name(i).decode() for i in range(lib.cotr_knob_count())]
     assert names[:20] == list(_lib.knobs()) and names[20:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
-                                                                 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs']
+                                                                 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs',
+                                                                 'linear_rows_min_rows']
     for n, want in (('head_fusion_max_rows', 0), ('ffn_preln', 0), ('ffn_tail', 0), ('coop_tail', 0), ('gemm_ln_min_rows', 1 << 30),
                     ('l2_warm', 0), ('split_f16', 0), ('split_f16_min_pairs', 8)):
         cur, dflt = ctypes.c_int(), ctypes.c_int()

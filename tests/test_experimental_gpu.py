@@ -599,3 +599,56 @@ def test_split_f16_packed_residual_and_packed_output(B, H, cin, cout, k, stride)
     finally:
         lib.cotr_op_set_h2_flags(0)
     assert ran >= 8
+
+
+@pytest.mark.parametrize('M,N,K,bn,res,relu', [(16384, 768, 256, False, True, False), (32760, 512, 128, True, True, True),
+                                                 (16384, 256, 256, False, False, True), (16384, 3072, 256, False, True, False)])
+def test_linear_rows_kernel_matches_the_tile_kernels(M, N, K, bn, res, relu):
+    """experimental/linear_rows.hip (round 5, measured slower, off by default: K = 128 / 256 products over many rows, A tile resident):
+    against fp64, and against the tile kernels (knob linear_rows_min_rows at its default) - same contract: FrozenBN scale / bias, residual, ReLU; ragged last tile."""
+    from cotr_amd import _lib
+    g = _g(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    scale = torch.rand(N, generator=g) + 0.5 if bn else None
+    bias = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    ref = x.double() @ w.double().t()
+    ref = ref * scale.double() + bias.double() if bn else ref + bias.double()
+    if res:
+        ref = ref + r.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    d = G.dev()
+    xd, wd = x.to(d), w.to(d)
+    kw = dict(scale=scale.to(d) if bn else None, bias=bias.to(d), residual=r.to(d) if res else None, relu=relu)
+    y_tiles = G.op_linear(xd, wd, **kw)
+    try:
+        _lib.set_knob('linear_rows_min_rows', 8192)
+        y = G.op_linear(xd, wd, **kw)
+        y2 = G.op_linear(xd, wd, **kw)
+    finally:
+        _lib.reset_knobs()
+    assert G.rel_err(y, ref) < 2e-5
+    assert torch.equal(y, y2)
+    assert G.rel_err(y, y_tiles) < 1e-5
+
+
+def test_linear_rows_serves_the_1x1_expansion_of_a_bottleneck():
+    from cotr_amd import _lib
+    """conv3 1x1 + bn3 + identity + ReLU of a layer2 bottleneck (torchvision Bottleneck.forward) over 8 pairs: 16384 pixel rows,
+    128 -> 512 channels - a dense product of the pixel rows, so launch_gemm hands it to linear_rows.hip."""
+    g = _g(5)
+    B, H, W, cin, cout = 8, 32, 32, 128, 512
+    x = torch.randn(B, cin, H, 2 * W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    scale, bias = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    idt = torch.randn(B, cout, H, 2 * W, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double()) * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1) + idt.double())
+    d = G.dev()
+    try:
+        _lib.set_knob('linear_rows_min_rows', 8192)
+        y = G.op_conv(G.nchw_to_sbs(x).to(d), G.pack_conv_weight(w).to(d), scale.to(d), bias.to(d), G.nchw_to_sbs(idt).to(d), True, cout, 1, 1)
+    finally:
+        _lib.reset_knobs()
+    assert G.rel_err(G.sbs_to_nchw(y), ref) < 2e-5
