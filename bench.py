@@ -453,9 +453,23 @@ def run_train(args, dev, world, rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ident = rank_identity(world, dev)
+    # FLOP of one step (DESIGN.md "Training step"): forward = backbone once (the cycle pass sees the same image) + input_proj, encoder and
+    # decoder K/V projection on 2 x pairs (prediction and cycle pass, each with its own dropout) + two decodes; backward = 2 x the forward
+    # FLOP of every trainable contraction (dX and dW): decoder, K/V projection, encoder, input_proj always, layer2 / layer3 in stage 2
+    G = 1e9
+    fwd = pairs * 17.126 * G + 2 * pairs * (0.268 + 6.442 + 0.805) * G + 2 * pairs * nq * 11.273e6
+    bwd = 2 * (2 * pairs * (0.268 + 6.442 + 0.805) * G + 2 * pairs * nq * 11.273e6) + (2 * pairs * (5.37 + 7.65) * G if args.stage == 2 else 0.0)
+    flop_step = fwd + bwd
+    ms = elapsed / args.steps * 1e3
     if rank == 0:
         print(json.dumps({
             **ident,
+            'roofline': {'bound': 'mfma', 'achieved': world * flop_step / ms / 1e9, 'peak': 157.3 * world, 'unit': 'TFLOP/s', 'frac': flop_step / ms / 1e9 / 157.3,
+                         'flop_per_step_per_gpu': flop_step,
+                         'flop_note': ('forward %.0f GFLOP (backbone once, input_proj / encoder / decoder K/V on 2 x 16 pairs, two decodes of 16 x 200 queries) + backward %.0f GFLOP '
+                                       '(dX and dW = 2 x the forward FLOP of every trainable contraction%s); traffic not measured for this workload'
+                                       % (fwd / G, bwd / G, ', layer2 / layer3 of the backbone included' if args.stage == 2 else '; backbone frozen')),
+                         'traffic': None},
             'metric': 'training pairs/sec (COTRTrainer.train_batch step, cycle + bidirectional)', 'value': world * pairs * args.steps / elapsed,
             'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -772,7 +786,7 @@ def main():
         }
         research = [f'{n}={v}' for n, v in KNOBS if n.startswith('split_f16') and v]
         if research:   # --set split_f16=N on the experimental library: the line is NOT a measurement of the fp32-MFMA product path - say so in it
-            line['dtype'] = 'f32 carried as packed split-f16 (RESEARCH: three f16 MFMAs per fp32 product, DESIGN.md 3e)'
+            line['dtype'] = 'f32 carried as packed split-f16 (RESEARCH: three f16 MFMAs per fp32 product, docs/LABNOTES.md 3e)'
             line['RESEARCH_not_the_product_path'] = ('measured with --set ' + ' '.join(research) + ' on libcotr_hip_exp.so: results are as close to fp64 as the '
                                                      'fp32-MFMA path but not bit-identical to it; "roofline" below divides fp32-EQUIVALENT work by the fp32-MFMA '
                                                      'peak and is not a fraction of any roofline of the kernels that ran')

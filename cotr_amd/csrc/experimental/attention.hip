@@ -465,7 +465,7 @@ __global__ __launch_bounds__(NS * 64, OCC) void attention_wide_kernel(const floa
 // where a wavefront ran one quarter each) merged in registers in the same order: results are bit-identical to those kernels, and the
 // four chains are independent instruction streams - the softmax VALU of one sits under the matrix instructions of the others.  The
 // output tile goes out as float4 stores straight from the D registers (rows = head dim: 4 consecutive dims per register quad).
-//   32 pairs x 512 (encoder): attention_wide 94 us;  32 x 1000 (decoder): 171 us - numbers of this kernel in DESIGN.md 3
+//   32 pairs x 512 (encoder): attention_wide 94 us;  32 x 1000 (decoder): 171 us - numbers of this kernel in docs/LABNOTES.md 3
 constexpr size_t ATT_RES_SMEM = (size_t)2 * ATT_KEYS * ATT_HD * sizeof(float);
 __global__ __launch_bounds__(512) void attention_res_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                             const float* __restrict__ v, int ldkv, float* __restrict__ o, int ldo, int nq,

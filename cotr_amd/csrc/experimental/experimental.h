@@ -1,4 +1,4 @@
-// Declarations of the MEASURED DEAD ENDS: compiled only into libcotr_hip_exp.so (-DCOTR_EXPERIMENTAL), never into
+// Declarations of the MEASURED DEAD ENDS (docs/LABNOTES.md 4b / 3c): compiled only into libcotr_hip_exp.so (-DCOTR_EXPERIMENTAL), never into
 // the product library.  Each is correct and tested (tests/test_experimental_gpu.py runs against the experimental library); each lost
 // its A/B on the MI355X and is kept so that the measurement can be repeated.
 //   coop_tail.h      row tiles finished by their own workgroups instead of ln_reduce launches      +7.4 us per tail

@@ -1,9 +1,9 @@
 // RESEARCH (knob split_f16, libcotr_hip_exp.so only): the K = 256 projections on packed split-f16 operands with the A tile RESIDENT IN
 // REGISTERS - configuration 50.
 //
-// Why: configurations 46 - 49 are not bound by the matrix pipe but by what a CU ingests: a 128 x 128 tile pulls 32 KB per
+// Why (docs/LABNOTES.md 3e): configurations 46 - 49 are not bound by the matrix pipe but by what a CU ingests: a 128 x 128 tile pulls 32 KB per
 // 32-deep K step (40 GB/s per CU, 0.79 us per step and tile slot at 4096^3) against 0.32 us of MFMAs, and at K = 256 a tile lives for 8
-// steps only, so the 2.4-9 us it costs around its K loop dominate.  Here a workgroup (4 wavefronts, ONE per SIMD: 512
+// steps only, so the 2.4-9 us it costs around its K loop (docs/LABNOTES.md 3d) dominate.  Here a workgroup (4 wavefronts, ONE per SIMD: 512
 // registers each) owns 128 rows for ALL its column tiles: each wavefront loads the hi / lo halves of its 32 rows x 256 k ONCE, already
 // separated, into 128 registers (it computes 32 rows x 128 columns of a tile: with 64 x 64 per wavefront the 256 A registers + two accumulator
 // sets spill) (the MFMA A operands of every step come from there: no LDS read, no v_perm for A), and only W streams -

@@ -370,7 +370,7 @@ int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd,
  *   train_attention_form       training attention backward: 0 (default) = by shape, 1-3 = force the first / second / one-pass form
  * libcotr_hip_exp.so (the experimental build, -DCOTR_EXPERIMENTAL) adds the knobs of the measured dead ends, all off by default:
  *   head_fusion_max_rows, ffn_preln, ffn_tail, coop_tail, coop_tail_spin, gemm_ln_min_rows, l2_warm  (cotr_amd/csrc/experimental/experimental.h)
- * and the RESEARCH path of DESIGN.md 3e (not a dead end; off by default, results as close to fp64 as the fp32 path but not its bits):
+ * and the RESEARCH path of docs/LABNOTES.md 3e (not a dead end; off by default, results as close to fp64 as the fp32 path but not its bits):
  *   split_f16                  0 (default) = off; 1 = the backbone + input_proj of a pass on packed split-f16 tensors (three f16 MFMAs per
  *                              fp32 product); 2 = also the projections / FFN blocks / corr_embed of the many-row (>= 8192 rows) transformer
  *                              path; 3 = also attention in both stacks.  |activations| must stay below 65504

@@ -1,4 +1,4 @@
-"""The error model behind the RESEARCH knob split_f16 (tools/split_mfma_numerics.py) pinned on the CPU: which split
+"""The error model behind the RESEARCH knob split_f16 (docs/LABNOTES.md 3e, tools/split_mfma_numerics.py) pinned on the CPU: which split
 low-precision scheme keeps the fp32-MFMA path's accuracy, and where its range ends.  numpy only - no GPU, no library."""
 import importlib.util
 import os

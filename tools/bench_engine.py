@@ -1,7 +1,7 @@
 """End-to-end zoom-in refinement throughput on the MI355X: ZoomEngine (one crop launch + batched model calls per
 level) vs the reference's loop shape (32 tasks per call, PIL crops on the host, H2D per batch) with the same HIP model.
     python tools/bench_engine.py [n_queries] [--config2] [KNOB=INT ...]     (knobs of the model's handle, e.g. split_f16=3 with
-    COTR_HIP_EXPERIMENTAL=1: the research path of DESIGN.md 3e at engine level)"""
+    COTR_HIP_EXPERIMENTAL=1: the research path of docs/LABNOTES.md 3e at engine level)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

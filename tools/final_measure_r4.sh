@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/r4_final_* (parts a-c) and profiles/r4_split_f16_* (part d: the research path of DESIGN.md 3e, experimental library) is
+# Everything profiles/r4_final_* (parts a-c) and profiles/r4_split_f16_* (part d: the research path of docs/LABNOTES.md 3e, experimental library) is
 # built from, in one go on the GPU box.  usage: tools/final_measure_r4.sh [part a|b|c|d|all]
 part=${1:-all}
 o=gpurun_out/r4_final
