@@ -461,6 +461,34 @@ def test_att_rows_one_launch(nb, nq, qp, with_x, with_res):
     assert bool((y[R] == 7.0).all()), 'rows past the last pair were written'
 
 
+def test_att_rows_passes_nan_like_the_reference():
+    """A NaN query row stays NaN through softmax, out projection and LayerNorm; its neighbours - same tile, same wavefronts - are
+    untouched (the lazy softmax reference is raised by a wave-wide vote: a NaN lane must not poison the vote of the others)."""
+    import ctypes
+    from cotr_amd import _lib
+    g = _g(11)
+    nb, nq = 1, 130
+    kvw = torch.randn(nb * 512, 768, generator=g)
+    qw = torch.randn(nb * nq, 768, generator=g) * 0.5
+    qw[70, 5] = float('nan')
+    wo, bo = torch.randn(256, 256, generator=g) / 16, torch.zeros(256)
+    lw, lb = torch.ones(256), torch.zeros(256)
+    ref = _att_rows_ref(qw[:, :256], kvw[:, 256:512], kvw[:, 512:768], wo, bo, None, lw, lb, nb, nq)
+    d = G.dev()
+    t = [qw.to(d), kvw.to(d), wo.to(d), bo.to(d), lw.to(d), lb.to(d)]
+    y = torch.empty(nb * nq, 256, device=d)
+    rc = _lib.load_library().cotr_op_att_rows(G.P(t[0]), 768, None, None, None, None, 0.0, ctypes.c_void_p(t[1].data_ptr() + 1024),
+                                              ctypes.c_void_p(t[1].data_ptr() + 2048), 768, G.P(t[2]), G.P(t[3]), None, G.P(t[4]), G.P(t[5]),
+                                              G.P(y), nb, nq, G.sptr())
+    assert rc == 0
+    y = y.cpu()
+    assert bool(torch.isnan(y[70]).all())
+    ok = torch.ones(nb * nq, dtype=torch.bool)
+    ok[70] = False
+    assert not bool(torch.isnan(y[ok]).any())
+    assert G.rel_err(y[ok], ref[ok]) < 2e-5
+
+
 # ---- every launch configuration of the GEMM / implicit-GEMM kernels on the same problem -----------------------------
 def _cfgs():
     """every GEMM configuration of the loaded library that takes fp32 operands (46 - 51 of the experimental library take packed
