@@ -289,7 +289,7 @@ def research_split_f16():
     note = ('RESEARCH, opt-in (knob split_f16 of libcotr_hip_exp.so, off by default, never on the product path): every fp32 product of the '
             'large GEMMs / convolutions / attention products (level 3) as three v_mfma_f32_32x32x16_f16 on packed split-f16 tensors (hi = f16(a), lo = f16((a - hi) * 2^11)); '
             'as close to the fp64 truth as the fp32-MFMA path on all 9 goldens of the reference (tests/test_experimental_gpu.py), not '
-            'bit-identical to it, range-limited to |x| < 65504; "fp32_equivalent_tflops" counts the fp32 work; its own roofline is 2517 / 3 = 839 '
+            'bit-identical to it; range: a pass that packs |x| >= 65504 anywhere is re-run on the fp32 kernels (cotr_h2_fallbacks); "fp32_equivalent_tflops" counts the fp32 work; its own roofline is 2517 / 3 = 839 '
             'TFLOP/s-equivalent (dense f16 MFMA peak over three matrix instructions per product): "roofline.frac" of each split_f16 entry')
     try:
         env = dict(os.environ, COTR_HIP_EXPERIMENTAL='1')

@@ -134,6 +134,7 @@ _EXP_PROTOS = {
     'cotr_op_split_h2': (ctypes.c_int, [c_float_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'cotr_op_unsplit_h2': (ctypes.c_int, [ctypes.c_void_p, c_float_p, ctypes.c_size_t, ctypes.c_void_p]),
     'cotr_op_set_h2_flags': (ctypes.c_int, [ctypes.c_int]),
+    'cotr_h2_fallbacks': (ctypes.c_long, []),
     'cotr_op_attention_h2': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
 }

@@ -1002,7 +1002,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   return COTR_OK;
 }
 
-int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) { return encode_impl(h, img, B, stream, nullptr); }
+int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream);   // (guarded: defined behind h2_guarded)
 
 int cotr_backbone(cotr_handle h, const float* img, int B, float* features, cotr_stream stream) {
   if (!features) return COTR_ERR_ARG;
@@ -1159,9 +1159,43 @@ int decode_check(cotr_ctx* h, const float* queries, int B, int Q, float* out) {
   return COTR_OK;
 }
 
+// RESEARCH range safety (round 5): a pass that ran with knob split_f16 on is followed by a look at the device's overflow flag (raised
+// wherever an activation outside f16's range was packed: gemm_h2.h); if it is set the SAME pass is run again with the knob off - on the
+// fp32-MFMA kernels of the product schedule - so the caller gets the fp32 path's answer instead of inf / NaN.  Costs one 4-byte copy and a
+// stream synchronisation per pass (so: not capturable; research only).  With the knob off this is a plain call.
+long g_h2_fallbacks = 0;
+template <class Pass>
+int h2_guarded(cotr_ctx* h, hipStream_t s, Pass&& pass) {
+  if (h->knobs.v[KN_SPLIT_F16] == 0) return pass();
+  int* flag = h2_overflow_flag();
+  if (flag == nullptr) { h->err = "split_f16: no overflow flag"; return COTR_ERR_HIP; }
+  HIPCHK(h, hipMemsetAsync(flag, 0, sizeof(int), s));
+  if (int r = pass()) return r;
+  int raised = 0;
+  HIPCHK(h, hipMemcpyAsync(&raised, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  if (!raised) return COTR_OK;
+  ++g_h2_fallbacks;
+  const int keep = h->knobs.v[KN_SPLIT_F16];
+  h->knobs.v[KN_SPLIT_F16] = 0;
+  h->h2_pass = h->h2_in_packed = h->h2_out_packed = false;
+  h->h2_prepacked_src = h->h2_prepacked_add = h->h2_ln_add = nullptr;
+  const int r = pass();
+  h->knobs.v[KN_SPLIT_F16] = keep;
+  return r;
+}
+
 }  // namespace
 
 extern "C" {
+
+long cotr_h2_fallbacks(void) { return g_h2_fallbacks; }
+
+int cotr_encode(cotr_handle h, const float* img, int B, cotr_stream stream) {
+  if (!h) return COTR_ERR_ARG;
+  DEVICE_SCOPE(h);
+  return h2_guarded(h, static_cast<hipStream_t>(stream), [&]() { return encode_impl(h, img, B, stream, nullptr); });
+}
 
 int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, cotr_stream stream) {
   if (!h) return COTR_ERR_ARG;
@@ -1174,20 +1208,23 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
   DEVICE_SCOPE(h);
   DecPlan d;
   if (int r = dec_plan(h, B, Q, d)) return r;
-  return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return h2_guarded(h, s, [&]() { return decode_impl(h, queries, B, Q, out, s, d); });
 }
 
 int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, int Q, float* out,
                  cotr_stream stream) {
   if (!h) return COTR_ERR_ARG;
   if (int r = decode_check(h, queries, B, Q, out)) return r;
-  int r = cotr_encode(h, img, B, stream);
-  if (r) return r;
-  if (Q == 0) return COTR_OK;
   DEVICE_SCOPE(h);
-  DecPlan d;
-  if ((r = dec_plan(h, B, Q, d))) return r;
-  return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return h2_guarded(h, s, [&]() {
+    int r = encode_impl(h, img, B, stream, nullptr);
+    if (r || Q == 0) return r;
+    DecPlan d;
+    if ((r = dec_plan(h, B, Q, d))) return r;
+    return decode_impl(h, queries, B, Q, out, s, d);
+  });
 }
 
 // bytes of the three arenas a call of that size carves (each rounded up to 256 B): what cotr_set_workspace must be given

@@ -47,7 +47,7 @@ __device__ __forceinline__ void h2_split8(const float (&p)[8], f16x8& hi, f16x8&
 
 __global__ __launch_bounds__(512) void attention_res_h2_kernel(const float* __restrict__ q, int ldq, int q_packed, const float* __restrict__ k,
                                                                const float* __restrict__ v, int ldkv, float* __restrict__ o, int ldo,
-                                                               int out_packed, int nq, int tiles_per_chunk) {
+                                                               int out_packed, int nq, int tiles_per_chunk, int* ovf) {
   extern __shared__ __attribute__((aligned(16))) float res_smem[];
   float* k_s = res_smem;
   float* v_s = res_smem + ATT_KEYS * ATT_HD;
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(512) void attention_res_h2_kernel(const float* __re
       u32x4 d0, d1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        d0[e] = h2_pack(qv[e]);
-        d1[e] = h2_pack(qv[4 + e]);
+        d0[e] = h2_pack_chk(qv[e], ovf);
+        d1[e] = h2_pack_chk(qv[4 + e], ovf);
       }
       h2_unzip(d0, d1, qh[s2], ql[s2]);
     }
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512) void attention_res_h2_kernel(const float* __re
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc += f[c] * oacc[c][g * 4 + i];
           const float y = acc * inv;
-          out[i] = out_packed ? __uint_as_float(h2_pack(y)) : y;
+          out[i] = out_packed ? __uint_as_float(h2_pack_chk(y, ovf)) : y;
         }
         *reinterpret_cast<f32x4*>(dst + 8 * g) = out;
       }
@@ -215,7 +215,9 @@ int launch_attention_h2(const float* q, int ldq, int q_packed, const float* k, c
     attr_set.set();
   }
   const int chunks = (tiles + tpc - 1) / tpc;
+  int* ovf = h2_overflow_flag();
+  if (ovf == nullptr) return -2;
   hipLaunchKernelGGL(attention_res_h2_kernel, dim3(chunks * 8, 1, nb), dim3(512), ATT_H2_SMEM, s, q, ldq, q_packed, k, v, ldkv, o, ldo,
-                     out_packed, nq, tpc);
+                     out_packed, nq, tpc, ovf);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -160,6 +160,7 @@ struct GemmParams {
   int xcd_msplit;      // workgroup -> tile mapping, see gemm_tile_coords
   int ws_flags;        // wave-specialised large tiles (gemm_big.hip): priorities, see gemm_set_ws_flags
   int h2_flags;        // configurations 46 / 47 (packed split-f16 operands): bit 0 = C is written packed, bit 1 = the residual is packed
+  int* h2_ovf;         // ... where C is written packed: the overflow flag (h2_overflow_flag()), set by the launch helpers
   // launch-time divisors (gemm_fill_divs, called by every launch helper): column tiles of the launch's tile shape; the
   // convolution's pixel decomposition (Hout * 2*Wout, 2*Wout, Wout), channel tiles per tap (Cin / 32), ksize; the x + pos
   // prologue's row period and column period; the row period of a table residual

@@ -44,6 +44,7 @@ int gemm_pp_workgroups();
 // gemm_h2.hip / gemm_h2.h (research): fp32 -> packed split-f16 dwords, the operand format of GEMM configurations 46 / 47
 int launch_split_h2(const float* x, void* y, size_t n, hipStream_t s, const float* x2 = nullptr);   // y = pack(x [+ x2])
 int launch_unsplit_h2(const void* x, float* y, size_t n, hipStream_t s);
+int* h2_overflow_flag();   // per-device flag raised by every kernel that packs an activation outside f16's range (round 5: range safety)
 // y = LayerNorm(x) (bits of launch_layernorm) and yp = pack(y [+ add]) in one launch
 // gemm_h2r.hip: K = 256 dense GEMM on packed operands, A tile resident in registers (configuration 50)
 int launch_gemm_h2r(const GemmParams& p, hipStream_t s);

@@ -270,7 +270,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmParams& p, const int bid
           if (p.residual) x += res[a][it][e];
           if (p.relu) x = (x < 0.f) ? 0.f : x;
           v[e] = x;
-          if constexpr (H2) if (p.h2_flags & 1) v[e] = __uint_as_float(h2_pack(x));
+          if constexpr (H2) if (p.h2_flags & 1) v[e] = __uint_as_float(h2_pack_chk(x, p.h2_ovf));
         }
         *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + ncol) = v;
       }
@@ -505,7 +505,7 @@ __device__ __forceinline__ void gemm_ws_body(const GemmParams& p, const int bid)
           if (p.residual) x += res[a][it][e];
           if (p.relu) x = (x < 0.f) ? 0.f : x;
           v[e] = x;
-          if constexpr (H2) if (p.h2_flags & 1) v[e] = __uint_as_float(h2_pack(x));
+          if constexpr (H2) if (p.h2_flags & 1) v[e] = __uint_as_float(h2_pack_chk(x, p.h2_ovf));
         }
         *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + ncol) = v;
       }
@@ -539,6 +539,7 @@ static int launch_ws_t(const GemmParams& p0, hipStream_t s) {
     attr_set.set();
   }
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
+  if constexpr (H2) { p.h2_ovf = h2_overflow_flag(); if (p.h2_ovf == nullptr) return -2; }
   p.ws_flags = knob(KN_WS_FLAGS);
   const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_ws_kernel<TN, MODE, H2>), dim3(tiles), dim3(512), smem, s, p);
@@ -606,6 +607,7 @@ static int launch_big_t(const GemmParams& p0, hipStream_t s) {
     attr_set.set();
   }
   if (!gemm_fill_divs(p, MODE, BM, BN)) return -1;
+  if constexpr (X == 2) { p.h2_ovf = h2_overflow_flag(); if (p.h2_ovf == nullptr) return -2; }
   const int tiles = gemm_grid_tiles(p, BM, BN);
   hipLaunchKernelGGL((gemm_big_kernel<TN, MODE, NST, X, NW>), dim3(tiles), dim3(64 * NW), smem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;

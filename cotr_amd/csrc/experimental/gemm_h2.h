@@ -20,6 +20,14 @@ __device__ __forceinline__ unsigned int h2_pack(const float a) {
   return (unsigned int)__half_as_ushort(h) | ((unsigned int)__half_as_ushort(l) << 16);
 }
 
+// ... and with the RANGE CHECK of round 5: f16(a) overflows from |a| >= 65504 on (inf where fp32 is finite).  Every place that packs
+// ACTIVATIONS raises a device flag there (h2_overflow_flag(), gemm_h2.hip); the ABI entry points of the research library read it
+// after a split-f16 pass and re-run the pass on the fp32-MFMA kernels when it is set (experimental/api.hip: h2_guarded).
+__device__ __forceinline__ unsigned int h2_pack_chk(const float a, int* ovf) {
+  if (!(fabsf(a) < 65504.f)) *ovf = 1;                  // (also NaN / inf inputs: the fp32 path decides what they mean)
+  return h2_pack(a);
+}
+
 __device__ __forceinline__ float h2_unpack(const unsigned int d) {
   return fmaf(__half2float(__ushort_as_half((unsigned short)(d >> 16))), 0x1p-11f, __half2float(__ushort_as_half((unsigned short)(d & 0xFFFFu))));
 }

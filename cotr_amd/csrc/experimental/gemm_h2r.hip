@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             x += (p.h2_flags & 2) ? h2_unpack(__float_as_uint(rv)) : rv;
           }
           if (p.relu) x = (x < 0.f) ? 0.f : x;
-          crow[(size_t)dr * p.ldc] = (p.h2_flags & 1) ? __uint_as_float(h2_pack(x)) : x;
+          crow[(size_t)dr * p.ldc] = (p.h2_flags & 1) ? __uint_as_float(h2_pack_chk(x, p.h2_ovf)) : x;
         }
       }
   }
@@ -141,6 +141,8 @@ int launch_gemm_h2r(const GemmParams& p0, hipStream_t s) {
   const int row_tiles = (p.M + 127) / 128, ntiles = p.N / 128;
   int nsplit = 1;
   while (row_tiles * nsplit < 224 && nsplit * 2 <= ntiles) nsplit *= 2;   // every CU a workgroup before column tiles are shared out
+  p.h2_ovf = h2_overflow_flag();
+  if (p.h2_ovf == nullptr) return -2;
   hipLaunchKernelGGL(gemm_h2r_kernel, dim3(row_tiles * nsplit), dim3(256), H2R_SMEM, s, p, nsplit);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

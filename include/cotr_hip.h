@@ -436,6 +436,9 @@ int cotr_op_unsplit_h2(const void* x, float* y, size_t n, cotr_stream stream);  
 /* flags of the following cotr_op_linear_cfg / cotr_op_conv_cfg calls of this thread on configurations 46 / 47: bit 0 = y is written packed,
  * bit 1 = the residual is packed (what a chain of such launches passes from one to the next); 0 restores fp32 residual / output */
 int cotr_op_set_h2_flags(int flags);
+/* RANGE SAFETY of the research path: a cotr_encode / cotr_decode / cotr_forward that ran with split_f16 on and packed an activation outside f16's
+ * range (|x| >= 65504) is run again on the fp32-MFMA kernels before it returns; this counts those re-runs (process-wide) */
+long cotr_h2_fallbacks(void);
 /* cotr_op_attention on PACKED k / v (q fp32 or packed: q_packed; o fp32 or packed: out_packed), csrc/experimental/attention_h2.hip */
 int cotr_op_attention_h2(const float* q, int ldq, int q_packed, const float* k, const float* v, int ldkv, float* o, int ldo, int out_packed,
                          int nb, int nq, cotr_stream stream);

@@ -652,3 +652,30 @@ def test_linear_rows_serves_the_1x1_expansion_of_a_bottleneck():
     finally:
         _lib.reset_knobs()
     assert G.rel_err(G.sbs_to_nchw(y), ref) < 2e-5
+
+
+def test_split_f16_range_safety_falls_back_to_the_fp32_kernels():
+    """RESEARCH range safety (round 5): f16 overflows from |x| >= 65504 on.  A pass that ran with split_f16 on and packed such an
+    activation anywhere is run again on the fp32-MFMA kernels before the call returns: the answer is the fp32 path's, bit for bit,
+    and the re-run is counted.  Inputs in range: no re-run, the split-f16 result."""
+    lib = _lib.load_library()
+    m = hip_model()
+    img, qs = synth_inputs(8, 64, seed=13)
+    img, qs = img.cuda(), qs.cuda()
+    big = img * 3.0e4                                      # the stem's outputs reach ~1e6: out of f16's range
+    try:
+        m.set_knob('split_f16_min_pairs', 1)
+        m.set_knob('split_f16', 0)
+        want_big, want = m(big, qs)['pred_corrs'].clone(), m(img, qs)['pred_corrs'].clone()
+        for level in (1, 3):
+            m.set_knob('split_f16', level)
+            n0 = lib.cotr_h2_fallbacks()
+            got = m(img, qs)['pred_corrs'].clone()
+            assert lib.cotr_h2_fallbacks() == n0, 'in-range inputs must not fall back'
+            assert not torch.equal(got, want) and cotr_oracle.px_err(got.cpu(), want.cpu()) < PX_BAR
+            got_big = m(big, qs)['pred_corrs'].clone()
+            assert lib.cotr_h2_fallbacks() == n0 + 1, 'the overflow was not noticed'
+            assert torch.equal(got_big, want_big), 'the re-run must be the fp32 path'
+            assert bool(torch.isfinite(got_big).all())
+    finally:
+        m.reset_knobs()
