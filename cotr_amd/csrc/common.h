@@ -76,6 +76,7 @@ enum KnobId {
   KN_ATTENTION_RESIDENT,         // K_h / V_h resident in LDS (attention_res_kernel) for many rows
   KN_ATT_ROWS_MIN_ROWS,          // attention sub-layer ([q projection,] attention, out projection, residual, LayerNorm) as ONE launch (att_rows.hip) from this many query rows
   KN_FFN_ROWS_MIN_ROWS,          // FFN block + residual + LayerNorm as ONE launch (ffn_rows.hip: 64-row tiles, hidden units dealt to the wavefronts) from this many rows
+  KN_CONV23_MIN_PAIRS,           // layer1: conv2 (3x3) -> conv3 (1x1 expansion) + identity + ReLU as ONE launch (conv23.hip) from this many pairs per pass
   KN_COUNT
 };
 struct KnobSet {
@@ -297,6 +298,9 @@ int launch_ffn_rows(const float* X, const float* W1, const float* b1, const floa
 int launch_att_rows(const float* q, int ldq, const float* x, const float* x2, const float* wq, const float* bq, float qscale,
                     const float* k, const float* v, int ldkv, const float* wo, const float* bo, const float* residual,
                     const float* ln_w, const float* ln_b, float* Y, int nb, int nq, hipStream_t s);
+// conv2 (3x3) -> conv3 (1x1) of a layer1 bottleneck in one launch for many pairs (conv23.hip): t1 [B][64][128][64] -> y [B][64][128][256]
+int launch_conv23(const float* t1, const float* w2, const float* s2, const float* b2, const float* w3, const float* s3, const float* b3,
+                  const float* residual, float* y, int B, hipStream_t s);
 // one whole layer1 bottleneck in one launch (bottleneck.hip); w2p / w3p / wdp are the packed fragment arrays (bottleneck_pack_*)
 int launch_bottleneck(const float* x, float* y, int B, int cin, const float* w1, const float* w2p, const float* w3p, const float* wdp,
                       const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3,

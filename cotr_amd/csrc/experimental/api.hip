@@ -90,6 +90,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"attention_resident", 1, 0, 1},
     {"att_rows_min_rows", 8192, 0, INT_MAX},
     {"ffn_rows_min_rows", 8192, 0, INT_MAX},
+    {"conv23_min_pairs", 5, 1, INT_MAX},
     {"head_fusion_max_rows", 0, 0, INT_MAX},
     {"ffn_preln", 0, 0, 1},
     {"ffn_tail", 0, 0, 1},
@@ -919,8 +920,14 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
           idt = b_d;
         }
         if (!c1_done && (r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
-        if ((r = conv(h, c2, b_t1, nullptr, 1, b_t2, Bc, H, W, s))) return r;
-        if ((r = conv(h, c3, b_t2, idt, 1, y, Bc, Ho, Wo, s))) return r;
+        if (st == 0 && H == 64 && W == 64 && Bc >= knob(KN_CONV23_MIN_PAIRS)) {
+          // many pairs: conv2 -> conv3 + identity + ReLU in one launch, t2 never leaves the CU (conv23.hip)
+          KCHK(h, launch_conv23(b_t1, c2.w, c2.scale, c2.bias, c3.w, c3.scale, c3.bias, idt, y, Bc, s), "conv23");
+          if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "conv23 layer1.%d %d pairs", b, Bc); prof_mark(h, nm, s, 2); }
+        } else {
+          if ((r = conv(h, c2, b_t1, nullptr, 1, b_t2, Bc, H, W, s))) return r;
+          if ((r = conv(h, c3, b_t2, idt, 1, y, Bc, Ho, Wo, s))) return r;
+        }
         x = y;
         H = Ho; W = Wo;
       }
@@ -1814,6 +1821,12 @@ int cotr_op_att_rows(const float* q, int ldq, const float* x, const float* x2, c
                      const float* ln_w, const float* ln_b, float* y, int nb, int nq, cotr_stream stream) {
   return op_ret(launch_att_rows(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, wo, bo, residual, ln_w, ln_b, y, nb, nq,
                                 static_cast<hipStream_t>(stream)));
+}
+
+// conv2 (3x3, 64 -> 64) -> conv3 (1x1, 64 -> 256) + identity + ReLU of a layer1 bottleneck in ONE launch (conv23.hip)
+int cotr_op_conv23(const float* t1, const float* w2, const float* s2, const float* b2, const float* w3, const float* s3, const float* b3,
+                   const float* residual, float* y, int B, cotr_stream stream) {
+  return op_ret(launch_conv23(t1, w2, s2, b2, w3, s3, b3, residual, y, B, static_cast<hipStream_t>(stream)));
 }
 
 // the same block in ONE launch for many rows (ffn_rows.hip); post_w / post_b: optional second LayerNorm (decoder.norm); y != x

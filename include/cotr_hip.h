@@ -180,6 +180,11 @@ int cotr_op_att_rows(const float* q, int ldq, const float* x, const float* x2, c
  * second LayerNorm of the result]); y must not alias x */
 int cotr_op_ffn_rows(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
                      const float* ln_b, const float* post_w, const float* post_b, float* y, int M, cotr_stream stream);
+/* conv2 (3x3, padding 1 per half) + FrozenBN + ReLU -> conv3 (1x1) + FrozenBN + identity + ReLU of a layer1 bottleneck in ONE launch
+ * (conv23.hip; torchvision Bottleneck.forward with COTR/models/backbone.py:46-56): t1 [B,64,128,64] NHWC side-by-side, w2 [64][3][3][64],
+ * w3 [256][64], residual / y [B,64,128,256] */
+int cotr_op_conv23(const float* t1, const float* w2, const float* s2, const float* b2, const float* w3, const float* s3, const float* b3,
+                   const float* residual, float* y, int B, cotr_stream stream);
 /* lin_sine encoding of pts [n,2] -> y [n,256] (COTR/models/position_encoding.py:41-45) */
 int cotr_op_posenc(const float* pts, float* y, int n, cotr_stream stream);
 

@@ -657,6 +657,47 @@ def test_fused_layer1_bottleneck(B, cin):
     assert lib.cotr_op_bottleneck(G.P(xd), G.P(y), B, 128, *[G.P(a) for a in args], G.sptr()) != 0
 
 
+@pytest.mark.parametrize('B', [1, 3, 8])
+def test_conv23_one_launch(B):
+    """conv23.hip: conv2 3x3 (+ FrozenBN + ReLU) -> conv3 1x1 (+ FrozenBN + identity + ReLU) of a layer1 bottleneck in ONE launch,
+    against torchvision's Bottleneck.forward per 64-wide half (COTR/models/backbone.py:46-56,79-92): the zero padding of every half's
+    border rows / columns (also at the seam), the transposed first product handing its registers to the second, the W3 ring.  Also
+    against the two launches it replaces (same contract; equal to fp32 rounding)."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(B * 13 + 5)
+    t1 = F.relu(torch.randn(B, 64, 64, 128, generator=g))
+    w2 = torch.randn(64, 64, 3, 3, generator=g) / math.sqrt(576)
+    w3 = torch.randn(256, 64, 1, 1, generator=g) / 8
+    idt = torch.randn(B, 256, 64, 128, generator=g)
+    sb = lambda n: (torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g))
+    (s2, b2), (s3, b3) = sb(64), sb(256)
+    bn = lambda t, s_, b_: t * s_.view(1, -1, 1, 1) + b_.view(1, -1, 1, 1)
+    t2_ref = G.per_half(lambda h: F.relu(bn(F.conv2d(h, w2, padding=1), s2, b2)), t1)
+    ref = F.relu(bn(F.conv2d(t2_ref, w3), s3, b3) + idt)
+    d = G.dev()
+    t1d, idtd = G.nchw_to_sbs(t1).to(d), G.nchw_to_sbs(idt).to(d)
+    w2d, w3d = G.pack_conv_weight(w2).to(d), G.pack_conv_weight(w3).to(d)
+    s2d, b2d, s3d, b3d = s2.to(d), b2.to(d), s3.to(d), b3.to(d)
+    y = torch.full((B, 64, 128, 256), float('nan'), device=d)
+    rc = lib.cotr_op_conv23(G.P(t1d), G.P(w2d), G.P(s2d), G.P(b2d), G.P(w3d), G.P(s3d), G.P(b3d), G.P(idtd), G.P(y), B, G.sptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    e = G.rel_err(G.sbs_to_nchw(y.cpu()), ref)
+    assert e < 3e-5, e
+    t2 = G.op_conv(t1d, w2d, s2d, b2d, None, True, 64, 3, 1)
+    y2 = G.op_conv(t2, w3d, s3d, b3d, idtd, True, 256, 1, 1)
+    assert G.rel_err(y, y2) < 1e-5
+    # NaN in, NaN out - where the reference has them (one pixel of t1 reaches its 3 x 3 neighbourhood of one half, every channel)
+    t1n = t1d.clone()
+    t1n[0, 10, 20, 3] = float('nan')
+    assert lib.cotr_op_conv23(G.P(t1n), G.P(w2d), G.P(s2d), G.P(b2d), G.P(w3d), G.P(s3d), G.P(b3d), G.P(idtd), G.P(y), B, G.sptr()) == 0
+    torch.cuda.synchronize()
+    nan = torch.isnan(y)
+    assert bool(nan[0, 9:12, 19:22, :].all()) and int(nan.sum()) == 9 * 256
+    assert lib.cotr_op_conv23(G.P(t1d), G.P(w2d), G.P(s2d), G.P(b2d), G.P(w3d), G.P(s3d), G.P(b3d), None, G.P(y), B, G.sptr()) != 0
+
+
 def test_large_tile_configs_are_repeatable():
     """The LDS-DMA kernels order other wavefronts' reads by an explicit vmcnt(0) before the barrier (common.h,
     LDS_DMA_WAIT_ALL); without it thousands of workgroups in flight produced rare stale tiles.  Many workgroups, several

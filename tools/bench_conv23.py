@@ -1,0 +1,50 @@
+"""A/B of layer1's conv2 -> conv3 for many pairs: ONE launch (conv23.hip) against the two tuned launches it replaces (3x3 conv + FrozenBN +
+ReLU, 1x1 expansion + FrozenBN + identity + ReLU).  Prints microseconds per block and TFLOP/s of the fp32-MFMA peak (157.3).
+
+    python tools/bench_conv23.py [pairs ...]          -> profiles/r5_ab_conv23.txt is its output on the MI355X
+"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cotr_amd import _lib  # noqa: E402
+from tests import gpu_helpers as G  # noqa: E402
+from tools.bench_ffn_rows import timeit  # noqa: E402
+
+
+def main():
+    pairs = [int(a) for a in sys.argv[1:]] or [5, 8, 16, 32, 64]
+    lib = _lib.load_library()
+    d = G.dev()
+    g = torch.Generator().manual_seed(0)
+    w2 = (torch.randn(64, 3, 3, 64, generator=g) / math.sqrt(576)).to(d)
+    w3 = (torch.randn(256, 64, generator=g) / 8).to(d)
+    s2, b2 = (torch.rand(64, generator=g) + 0.5).to(d), torch.randn(64, generator=g).to(d)
+    s3, b3 = (torch.rand(256, generator=g) + 0.5).to(d), torch.randn(256, generator=g).to(d)
+    print('# pairs | one launch us (TFLOP/s, of peak) | two launches us (TFLOP/s, of peak) | max rel diff')
+    for B in pairs:
+        t1 = torch.relu(torch.randn(B, 64, 128, 64, generator=g)).to(d)
+        idt = torch.randn(B, 64, 128, 256, generator=g).to(d)
+        y = torch.empty(B, 64, 128, 256, device=d)
+        t2 = torch.empty(B, 64, 128, 64, device=d)
+        y2 = torch.empty(B, 64, 128, 256, device=d)
+        s = G.sptr()
+
+        def one():
+            assert lib.cotr_op_conv23(G.P(t1), G.P(w2), G.P(s2), G.P(b2), G.P(w3), G.P(s3), G.P(b3), G.P(idt), G.P(y), B, s) == 0
+
+        def two():
+            assert lib.cotr_op_conv(G.P(t1), G.P(w2), G.P(s2), G.P(b2), None, 1, G.P(t2), B, 64, 64, 64, 64, 3, 1, s) == 0
+            assert lib.cotr_op_conv(G.P(t2), G.P(w3), G.P(s3), G.P(b3), G.P(idt), 1, G.P(y2), B, 64, 64, 64, 256, 1, 1, s) == 0
+
+        ta, tb = timeit(one), timeit(two)
+        fl = 2 * B * 8192 * 64 * (576 + 256)
+        print(f'{B:4d} | {ta:8.1f} ({fl / ta * 1e-6:6.1f}, {fl / ta * 1e-6 / 157.3:.3f}) | {tb:8.1f} ({fl / tb * 1e-6:6.1f}, {fl / tb * 1e-6 / 157.3:.3f}) | '
+              f'{G.rel_err(y, y2):.2e}')
+
+
+if __name__ == '__main__':
+    main()
