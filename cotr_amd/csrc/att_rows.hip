@@ -6,22 +6,31 @@
 // launches whose tiles pay their fixed cost per 128 rows (profiles/r4_tile_fixed_cost_vs_k_steps.txt) and the attention output's
 // round trip through HBM.  Same "rows" decomposition and wave-private operand streams as ffn_rows.hip:
 //
-//   workgroup = 64 query rows of ONE pair, 4 wavefronts (one per SIMD); wavefront w owns heads w and w + 4.
+//   workgroup = 64 query rows of ONE pair, 8 wavefronts (two per SIMD); wavefront w owns head w.
 //   T    [64 x 256] tile in LDS (k-tiled [8][64][32], 16-B chunks XOR-swizzled): QP: tgt + query_pos, else the q columns; after the
 //        attention phase the same 64 KB hold the concatenated head outputs O.
-//   QP   q_h^T [32 d x 64 rows] = Wq_h . T^T for both heads (8 pieces of Wq_h each): lands in the MFMA D layout, which IS the
-//        B-operand layout of S^T = K_h . q_h^T (attention.hip's trick: lane = query, register r = head dim (r&3) + 8(r>>2) + 4*half)
-//   KV   per head, per 32-key block: one K piece and one V piece (4 KB each) -
+//   QP   q_h^T [32 d x 64 rows] = Wq_h . T^T (8 pieces of Wq_h): lands in the MFMA D layout, which IS the B-operand layout of
+//        S^T = K_h . q_h^T (attention.hip's trick: lane = query, register r = head dim (r&3) + 8(r>>2) + 4*half)
+//   KV   per 32-key block: one K piece and one V piece (4 KB each) -
 //          S^T = K_blk . q^T  (16 MFMAs per 32-query block u), online softmax in the log2 domain (lane = one query, 16 scores in
 //          registers + one cross-half swap), O^T += V_blk^T . P^T (16 MFMAs, P registers feed the B operand directly).
-//        The two query blocks are staggered: S(u0) | S(u1) beside softmax(u0) | PV(u0) beside softmax(u1) | PV(u1), so the softmax
-//        VALU of one block sits under the matrix instructions of the other (one wavefront per SIMD: nobody else would cover it).
-//   OUT  after a barrier (all eight O_h are in T): Y[64 x 64 columns of this wavefront] = O . Wo[64w .. 64w+64, :]^T, 16 pieces of Wo,
+//   OUT  after a barrier (all eight O_h are in T): Y[64 x 32 columns of this wavefront] = O . Wo[32w .. 32w+32, :]^T, 8 pieces of Wo,
 //        then + bias + residual, LayerNorm over the whole row through LDS (ffn_rows.hip's epilogue: 8 lanes per row, DPP sums).
 //   Every operand that is not the T tile - Wq_h, K_h, V_h, the wavefront's rows of Wo - is used by exactly ONE wavefront of the
-//   workgroup: each wavefront requests its own 4 KB pieces ([32 rows][32 floats]) by LDS-DMA into its own 4-slot ring, three pieces
-//   ahead, and reads them back itself - no barrier in the main loops, ordering by the wavefront's own counted vmcnt.  A piece feeds
-//   32 MFMAs whatever its kind, so the request cadence is one piece per ~2000 cycles throughout.
+//   workgroup: each wavefront requests its own 4 KB pieces ([32 rows][32 floats]) by LDS-DMA into its own TWO-slot ring (slot 0: K
+//   pieces / even pieces of a GEMM phase, slot 1: V / odd) and reads them back itself - no barrier in the main loops, ordering by the
+//   wavefront's own counted vmcnt.  A slot is requested again as soon as its fragments are in registers (the K fragments of block b+1
+//   are read during the PV product of block b, the V fragments of block b at the start of its S product), so every piece is one
+//   whole block - 64 matrix instructions of this wavefront, ~4000-8000 cycles beside its neighbour - ahead of its use.
+//
+//   Two wavefronts per SIMD (round 5, second form; the first had 4 wavefronts x 2 heads and four-slot rings): 240 k -> 232 k cycles
+//   per encoder tile, 273 k -> 261 k per decoder tile (tools/micro/att_rows_probe.hip), 2107 -> 2016 us of the 32 x 1000 forward.
+//   That is all two symmetric wavefronts give: each still pays its own softmax and its own request / wait instructions in the
+//   matrix pipe's time - the SIMD grants the pipe to ONE of them until it stalls (two wavefronts of matrix instructions only: the
+//   first finishes in 259 k cycles, the second in 518 k), and a wavefront's VALU block waits for ITS matrix results whoever else runs
+//   (tools/micro/kv_model.hip: matrix pipe 0.826 busy with one such wavefront per SIMD, 0.862 with two, whatever the start offset or
+//   s_setprio; a VALU-only neighbour costs a matrix wavefront nothing - mfma_beside.hip - but handing S / P to one through LDS with
+//   a barrier per block gave 0.714).
 #include <type_traits>
 #include <utility>
 
@@ -30,7 +39,8 @@
 #define AR_D 256
 #define AR_KEYS 512
 #define AR_BM 64
-#define AR_NSLOT 4
+#define AR_NSLOT 2               // ring slots per wavefront: slot 0 = K pieces (even pieces of a phase), slot 1 = V pieces (odd)
+#define AR_NW 8                  // wavefronts per workgroup: one per head, two per SIMD
 #define AR_PIECE 1024            // floats per piece: 32 rows x 32 floats
 #define AR_LDT 288               // row of the epilogue tile: consecutive rows 32 banks apart (ffn_rows.hip)
 
@@ -58,7 +68,7 @@ struct AttRowsParams {
 
 constexpr int AR_T = 8 * AR_BM * 32;                      // floats of the T tile
 constexpr int AR_RING = AR_NSLOT * AR_PIECE;
-constexpr int AR_MAIN = AR_T + 4 * AR_RING + 4 * AR_D;    // T, rings, then bq, bo, ln_w, ln_b (staged once: the epilogue reads them from LDS)
+constexpr int AR_MAIN = AR_T + AR_NW * AR_RING + 4 * AR_D;    // T, rings, then bq, bo, ln_w, ln_b (staged once: the epilogue reads them from LDS)
 constexpr int AR_EPI = AR_BM * AR_LDT;
 constexpr size_t kAttRowsSmem = (size_t)(AR_MAIN > AR_EPI ? AR_MAIN : AR_EPI) * sizeof(float);
 static_assert(kAttRowsSmem <= 160 * 1024, "LDS");
@@ -99,29 +109,28 @@ struct ArLane {
                         // (odd q: offset ^ 16 - the other half of the chunk swizzle; row strides are multiples of 32 floats)
 };
 
-// ---- the piece sequence of a wavefront: [QP: 8 pieces of Wq per head, both heads] then per head 16 x (K block, V block), then 16
-// pieces of Wo.  The consumer walks it in program order; this iterator walks it NSLOT-1 pieces ahead for the requests. ----
+// ---- the piece sequence of a wavefront: [QP: 8 pieces of Wq_h] then 16 x (K block, V block), then 8 pieces of Wo.  The consumer
+// walks it in program order; this iterator walks ahead of it for the requests (two pieces in the GEMM phases, three in the KV phase). ----
 struct ArPiece {
   const float* base;    // first row, first column of the piece (wave-uniform)
   int kv;               // rows are ldkv apart (K / V) instead of 256
 };
 template <bool QP>
 struct ArIter {
-  int phase, hd, i;
-  __device__ __forceinline__ void init() { phase = QP ? 0 : 1; hd = 0; i = 0; }
+  int phase, i;
+  __device__ __forceinline__ void init() { phase = QP ? 0 : 1; i = 0; }
   __device__ __forceinline__ ArPiece next(const AttRowsParams& p, const int wave, const size_t key0) {
     ArPiece r;
-    const int head = wave + 4 * hd;
     if (QP && phase == 0) {
-      r.base = p.wq + (size_t)head * 32 * AR_D + i * 32;
+      r.base = p.wq + (size_t)wave * 32 * AR_D + i * 32;
       r.kv = 0;
-      if (++i == 8) { i = 0; if (++hd == 2) { hd = 0; phase = 1; } }
+      if (++i == 8) { i = 0; phase = 1; }
     } else if (phase == 1) {
-      r.base = ((i & 1) ? p.v : p.k) + (key0 + (size_t)(i >> 1) * 32) * p.ldkv + head * 32;
+      r.base = ((i & 1) ? p.v : p.k) + (key0 + (size_t)(i >> 1) * 32) * p.ldkv + wave * 32;
       r.kv = 1;
-      if (++i == 32) { i = 0; if (++hd == 2) { hd = 0; phase = 2; } }
+      if (++i == 32) { i = 0; phase = 2; }
     } else {
-      r.base = p.wo + (size_t)(64 * wave + 32 * (i >> 3)) * AR_D + (i & 7) * 32;
+      r.base = p.wo + (size_t)(32 * wave) * AR_D + i * 32;
       r.kv = 0;
       ++i;
     }
@@ -152,29 +161,30 @@ __device__ __forceinline__ ArFrag ar_load_frag(const ArLane& L) {
 
 // ---- QP phase, one head: q^T[d][row] = Wq_h . T^T over 8 pieces (32 steps of 8 MFMAs) ------------------------------------------------
 // Step order as in ffn_rows.hip: first MFMA pair, then the next step's fragment requests (behind the counted wait where the next
-// step opens a new piece), then the other pairs with the request of piece +3 interleaved during step (piece, 1).
+// step opens a new piece), then the other pairs; during a piece's LAST step (its fragments are all in registers) the request of
+// piece +2 goes into its slot.
 template <bool QP, int S_>
 __device__ __forceinline__ void ar_q_step(const AttRowsParams& p, const ArLane& L, const int wave, const size_t key0, ArIter<QP>& it,
                                           ArFrag& cur, f32x16 (&qacc)[2]) {
   constexpr int sub = S_ >> 2, j = S_ & 3;
   ArFrag nxt = cur;
   ArPiece np = {};
-  if constexpr (j == 1) np = it.next(p, wave, key0);
+  if constexpr (j == 3) np = it.next(p, wave, key0);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     qacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[e], cur.x0[e], qacc[0], 0, 0, 0);
     qacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[e], cur.x1[e], qacc[1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (j == 1) {
-      ar_dma_q(p, L, np, (sub + AR_NSLOT - 1) % AR_NSLOT, e);
-      __builtin_amdgcn_sched_barrier(0);
-    }
     if (e == 0) {
       if constexpr (S_ + 1 < 32) {
-        if constexpr (j == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the next piece has landed; two younger may be in flight
+        if constexpr (j == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next piece has landed (nothing younger is in flight)
         nxt = ar_load_frag<((S_ + 1) >> 2) % AR_NSLOT, ((S_ + 1) >> 2), ((S_ + 1) & 3)>(L);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if constexpr (j == 3) {   // this piece's last fragment is in registers (cur): its slot takes piece +2
+      ar_dma_q(p, L, np, sub % AR_NSLOT, e);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   cur = nxt;
@@ -186,17 +196,17 @@ __device__ __forceinline__ void ar_q_steps(const AttRowsParams& p, const ArLane&
 }
 
 // ---- online softmax of one 32-key block for both 32-query blocks, log2 domain, with a LAZY reference ---------------------------------------
-// On gfx950 the fp32 matrix instruction runs on the SIMD's fp32 vector datapath ("equal rate, not a missing opcode",
-// MI355X_MICROARCH.md): VALU work of the same wavefront does NOT overlap with it, however the two are interleaved - measured three
-// ways (compiler-scheduled, sched_group_barrier patterns, one softmax slice pinned behind every matrix instruction: the K/V phase took
-// 205 k cycles each time against 131 k of matrix instructions, 132 k with the softmax compiled out; profiles/r5_att_rows_probe.txt).
-// So the softmax is priced in VALU cycles and written to need few of them:
+// VALU work of a wavefront does NOT overlap with that wavefront's own matrix instructions, however the two are interleaved - measured
+// three ways in the 4-wavefront form (compiler-scheduled, sched_group_barrier patterns, one softmax slice pinned behind every matrix
+// instruction: the K/V phase took 205 k cycles each time against 131 k of matrix instructions, 132 k with the softmax compiled out;
+// profiles/r5_att_rows_probe.txt), and a second wavefront of the same kind on the SIMD hides little of it (header).  So the softmax
+// is priced in VALU cycles and written to need few of them:
 //   * p = 2^(s - m_ref) with a per-query reference m_ref that is only raised when some query of the wavefront sees a block maximum more
 //     than AR_LAZY above it (p <= 2^AR_LAZY: sums of 512 such terms are far inside fp32).  In the common case - every block after the
 //     first few - there is no alpha and no rescaling of the 32 output accumulators.  The result, 2^(-m_ref) . (sum_k 2^s_k V_k) /
 //     (2^(-m_ref) . sum_k 2^s_k), does not depend on the reference up to rounding.
 //   * matrix results live in VGPRs (build flag -amdgpu-mfma-vgpr-form): no v_accvgpr_read / write around every VALU use.
-//   * independent instructions back to back (one wavefront per SIMD: a dependent chain pays its full latency): the 32 subtractions,
+//   * independent instructions back to back (a dependent chain pays its full latency): the 32 subtractions,
 //     then the 32 exponentials, then tree sums; 3-input maxima.
 #define AR_LAZY 8.f
 __device__ __forceinline__ float ar_max16(const f32x16& s) {
@@ -262,7 +272,7 @@ template <bool QP, int KB_, bool DBG = false, int ABL = 0>   // ABL (probe only)
 __device__ __forceinline__ void ar_kv_block(const AttRowsParams& p, const ArLane& L, const int wave, const size_t key0, ArIter<QP>& it,
                                             const bool last, f32x4 (&kf)[4], const f32x16 (&q16)[2], f32x16 (&o)[2], float (&m_run)[2],
                                             float (&l_run)[2], const bool dump = false) {
-  constexpr int KS = 2 * KB_, VS = 2 * KB_ + 1;            // ring slots of this block's K and V pieces
+  constexpr int KS = 0, VS = 1;                            // ring slots of the K and V pieces
   f32x16 s[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -270,9 +280,9 @@ __device__ __forceinline__ void ar_kv_block(const AttRowsParams& p, const ArLane
     for (int r = 0; r < 16; ++r) s[u][r] = 0.f;
   float vf[16];
   // ---- S^T of both query blocks: 32 matrix instructions, the two accumulators alternating (a v_mfma that accumulates onto the result
-  // of the one right before it waits for it); the V fragments are requested behind the first pair, piece +3 (the next block's V)
-  // behind the next four ----
-  const ArPiece npa = it.next(p, wave, key0);
+  // of the one right before it waits for it); the V fragments are read behind the first pair, the next block's V piece is requested
+  // into the same slot behind the next four ----
+  const ArPiece npa = it.next(p, wave, key0);               // the next block's V piece (the last block: Wo piece 1)
 #pragma unroll
   for (int n = 0; n < 16; ++n) {
     s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[n >> 2][n & 3], q16[0][n], s[0], 0, 0, 0);
@@ -284,15 +294,17 @@ __device__ __forceinline__ void ar_kv_block(const AttRowsParams& p, const ArLane
       __builtin_amdgcn_sched_barrier(0);
     }
     if (n >= 1 && n <= 4) {
-      if constexpr (!(ABL & 2)) ar_dma_q(p, L, npa, (VS + 2) % AR_NSLOT, n - 1);    // -> the slot of the previous block's V piece
+      if (n == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the V fragments are in registers: the slot is free
+      if constexpr (!(ABL & 2)) ar_dma_q(p, L, npa, VS, n - 1);                     // -> the V slot
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   if constexpr (!(ABL & 1)) ar_softmax2(s, m_run, l_run, o);
   __builtin_amdgcn_sched_barrier(0);
   // ---- O^T += V^T . P^T of both query blocks: 32 matrix instructions, alternating; the next block's K fragments behind the first
-  // pair, piece +3 (the K piece two blocks ahead) behind the next four ----
-  const ArPiece npb = it.next(p, wave, key0);
+  // pair, the K piece two blocks ahead is requested into the same slot behind the next four ----
+  ArPiece npb = {};
+  if (!last) npb = it.next(p, wave, key0);                  // the K piece two blocks ahead (the last but one block: Wo piece 0)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], s[0][r], o[0], 0, 0, 0);
@@ -300,11 +312,12 @@ __device__ __forceinline__ void ar_kv_block(const AttRowsParams& p, const ArLane
     __builtin_amdgcn_sched_barrier(0);
     if (r == 0 && !last) {
       if constexpr (!(ABL & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the next block's K piece has landed (its V piece may be in flight)
-      ar_load_k<(KS + 2) % AR_NSLOT>(L, kf);
+      ar_load_k<KS>(L, kf);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (r >= 1 && r <= 4) {
-      if constexpr (!(ABL & 2)) ar_dma_q(p, L, npb, KS, r - 1);                     // -> this block's K slot (its fragments are in registers)
+    if (r >= 1 && r <= 4 && !last) {                                                // (the last block: both slots hold Wo pieces already)
+      if (r == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the next block's K fragments are in registers: the slot is free
+      if constexpr (!(ABL & 2)) ar_dma_q(p, L, npb, KS, r - 1);                     // -> the K slot
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -323,47 +336,42 @@ __device__ __forceinline__ void ar_kv_block(const AttRowsParams& p, const ArLane
 // ---- OUT phase: Y[64 x 64 columns of this wavefront] = O . Wo_rows^T, 16 pieces (64 steps), the tail of the wavefront's stream ----
 template <bool QP, int S_>
 __device__ __forceinline__ void ar_out_step(const AttRowsParams& p, const ArLane& L, const int wave, const size_t key0, ArIter<QP>& it,
-                                            ArFrag& cur, f32x16 (&yacc)[2][2]) {
+                                            ArFrag& cur, f32x16 (&yacc)[2]) {
   constexpr int sub = S_ >> 2, j = S_ & 3;
-  constexpr bool refill = j == 1 && sub + AR_NSLOT - 1 <= 15;
+  constexpr bool refill = j == 3 && sub + AR_NSLOT <= 7;
   ArFrag nxt = cur;
   ArPiece np = {};
   if constexpr (refill) np = it.next(p, wave, key0);
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    yacc[0][sub >> 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.x0[e], cur.a[e], yacc[0][sub >> 3], 0, 0, 0);
-    yacc[1][sub >> 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.x1[e], cur.a[e], yacc[1][sub >> 3], 0, 0, 0);
+    yacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.x0[e], cur.a[e], yacc[0], 0, 0, 0);
+    yacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.x1[e], cur.a[e], yacc[1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (refill) {
-      ar_dma_q(p, L, np, (sub + AR_NSLOT - 1) % AR_NSLOT, e);
-      __builtin_amdgcn_sched_barrier(0);
-    }
     if (e == 0) {
-      if constexpr (S_ + 1 < 64) {
-        if constexpr (j == 3) {
-          constexpr int younger = (sub + AR_NSLOT - 1 > 15) ? 15 - (sub + 1) : AR_NSLOT - 2;
-          if constexpr (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else if constexpr (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        nxt = ar_load_frag<((S_ + 1) >> 2) % AR_NSLOT, (((S_ + 1) >> 2) & 7), ((S_ + 1) & 3)>(L);
+      if constexpr (S_ + 1 < 32) {
+        if constexpr (j == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next piece has landed (nothing younger is in flight)
+        nxt = ar_load_frag<((S_ + 1) >> 2) % AR_NSLOT, ((S_ + 1) >> 2), ((S_ + 1) & 3)>(L);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if constexpr (refill) {
+      ar_dma_q(p, L, np, sub % AR_NSLOT, e);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   cur = nxt;
 }
 template <bool QP, int... S_>
 __device__ __forceinline__ void ar_out_steps(const AttRowsParams& p, const ArLane& L, const int wave, const size_t key0, ArIter<QP>& it,
-                                             ArFrag& cur, f32x16 (&yacc)[2][2], std::integer_sequence<int, S_...>) {
+                                             ArFrag& cur, f32x16 (&yacc)[2], std::integer_sequence<int, S_...>) {
   (ar_out_step<QP, S_>(p, L, wave, key0, it, cur, yacc), ...);
 }
 
 template <bool QP, bool DBG = false, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p) {
+__global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* T = smem;
-  float* bqs = smem + AR_T + 4 * AR_RING;
+  float* bqs = smem + AR_T + AR_NW * AR_RING;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -391,13 +399,13 @@ __global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p)
   L.T = T; L.ring = smem + AR_T + wave * AR_RING; L.bqs = bqs; L.l31 = l31; L.hh = hh; L.sw = (l31 >> 1) & 7;
   L.drow = drow; L.lch4 = lch_e * 4;
 
-  // ---- prologue: the T tile, bq -> LDS, the first NSLOT-1 pieces ----
+  // ---- prologue: the T tile, bq -> LDS, the first two pieces ----
   if constexpr (QP) {
     // T = x + x2 through registers, in the LDS-DMA pattern (a wave instruction = 8 rows x 128 B of one k-tile: conflict-free 16-B
     // writes); rows past the pair's last query re-read the tile's first row (never stored)
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const int idx = wave * 16 + i;
+    for (int i = 0; i < 8; ++i) {
+      const int idx = wave * 8 + i;
       const int kt = idx >> 3, rg = idx & 7;
       const int row = rg * 8 + drow;
       const int lch = pch ^ ((row >> 1) & 7);
@@ -406,25 +414,27 @@ __global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p)
       if (p.x != nullptr) v += *reinterpret_cast<const f32x4*>(p.x + g);
       *reinterpret_cast<f32x4*>(T + kt * (AR_BM * 32) + row * 32 + pch * 4) = v;
     }
-    bqs[t] = p.bq[t];
+    if (t < AR_D) bqs[t] = p.bq[t];
   } else {
     // T = the q columns by LDS-DMA: 64 instructions (k-tile = head, 8 rows each), 16 per wavefront
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int idx = wave * 16 + i;
+    for (int i = 0; i < 8; ++i) {
+      const int idx = wave * 8 + i;
       const int kt = idx >> 3, rg = idx & 7;
       const int row = rg * 8 + drow;
       const int lch = pch ^ ((row >> 1) & 7);
       ar_dma16(p.q + (row0 + (row < nvalid ? row : 0)) * p.ldq + kt * 32 + lch * 4, T + kt * (AR_BM * 32) + rg * 256);
     }
   }
-  bqs[AR_D + t] = p.bo[t];
-  bqs[2 * AR_D + t] = p.ln_w[t];
-  bqs[3 * AR_D + t] = p.ln_b[t];
+  if (t < AR_D) {
+    bqs[AR_D + t] = p.bo[t];
+    bqs[2 * AR_D + t] = p.ln_w[t];
+    bqs[3 * AR_D + t] = p.ln_b[t];
+  }
   ArIter<QP> it;
   it.init();
 #pragma unroll
-  for (int s = 0; s < AR_NSLOT - 1; ++s) {
+  for (int s = 0; s < AR_NSLOT; ++s) {   // both slots: Wq pieces 0, 1 / K block 0, V block 0
     const ArPiece pc = it.next(p, wave, key0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) ar_dma_q(p, L, pc, s, q);
@@ -434,58 +444,59 @@ __global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p)
 
   if constexpr (DBG) {   // [57344 .. 54096): wavefront 0's ring right after the prologue
     if (blockIdx.x == 0 && blockIdx.y == 0 && wave == 0)
-      for (int i = lane; i < 4096; i += 64) p.dbg[57344 + i] = L.ring[i];
+      for (int i = lane; i < AR_RING; i += 64) p.dbg[57344 + i] = L.ring[i];
   }
   AR_STAMP(1);
-  // ---- q of this wavefront's two heads, as B operands of S^T: q16[hd][u][r] = q[row 32u + l31][d = (r&3) + 8(r>>2) + 4hh] * log2(e) ----
-  f32x16 q16[2][2];
+  // ---- q of this wavefront's head, as B operands of S^T: q16[u][r] = q[row 32u + l31][d = (r&3) + 8(r>>2) + 4hh] * log2(e) ----
+  f32x16 q16[2];
   if constexpr (QP) {
     const float qs = p.qscale * 1.44269504088896340736f;
 #pragma unroll
-    for (int hd = 0; hd < 2; ++hd) {
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) q16[u][r] = 0.f;
+    ArFrag cur = ar_load_frag<0, 0, 0>(L);
+    ar_q_steps<QP>(p, L, wave, key0, it, cur, q16, std::make_integer_sequence<int, 32>{});
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // K block 0 has landed (V block 0 may be in flight)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bqs + wave * 32 + 8 * g + 4 * hh);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) q16[hd][u][r] = 0.f;
-      ArFrag cur = ar_load_frag<0, 0, 0>(L);
-      ar_q_steps<QP>(p, L, wave, key0, it, cur, q16[hd], std::make_integer_sequence<int, 32>{});
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // the first piece of what follows (the other head's Wq / the first K block)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(bqs + (wave + 4 * hd) * 32 + 8 * g + 4 * hh);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) q16[hd][u][g * 4 + e] = (q16[hd][u][g * 4 + e] + bv[e]) * qs;
-      }
+        for (int e = 0; e < 4; ++e) q16[u][g * 4 + e] = (q16[u][g * 4 + e] + bv[e]) * qs;
     }
   } else {
 #pragma unroll
-    for (int hd = 0; hd < 2; ++hd)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(T + wave * (AR_BM * 32) + (u * 32 + l31) * 32 + ((j * 2 + hh) ^ L.sw) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(T + (wave + 4 * hd) * (AR_BM * 32) + (u * 32 + l31) * 32 + ((j * 2 + hh) ^ L.sw) * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) q16[hd][u][j * 4 + e] = qv[e] * 1.44269504088896340736f;
-        }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // (the first K piece landed with the prologue's wait; keeps the two paths alike)
+        for (int e = 0; e < 4; ++e) q16[u][j * 4 + e] = qv[e] * 1.44269504088896340736f;
+      }
   }
 
   if constexpr (DBG) {   // [0 .. 16384): q16 as [wave][hd][u][r][lane]
     if (blockIdx.x == 0 && blockIdx.y == 0)
-      for (int hd = 0; hd < 2; ++hd)
-        for (int u = 0; u < 2; ++u)
-          for (int r = 0; r < 16; ++r) p.dbg[(((wave * 2 + hd) * 2 + u) * 16 + r) * 64 + lane] = q16[hd][u][r];
+      for (int u = 0; u < 2; ++u)
+        for (int r = 0; r < 16; ++r) p.dbg[((wave * 2 + u) * 16 + r) * 64 + lane] = q16[u][r];
   }
   AR_STAMP(2);
-  // ---- KV phase: 16 key blocks per head ----
+  // ---- KV phase: 16 key blocks ----
   f32x4 kf[4];
   ar_load_k<0>(L, kf);
-  f32x16 onorm[2][2];                                      // normalised O_h^T of the two heads (D layout), written to T behind a barrier
+  {
+    // K block 1 -> the K slot, once block 0's fragments are in registers
+    const ArPiece pc = it.next(p, wave, key0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (!(ABL & 2)) {
 #pragma unroll
-  for (int hd = 0; hd < 2; ++hd) {
+      for (int q = 0; q < 4; ++q) ar_dma_q(p, L, pc, 0, q);
+    }
+  }
+  f32x16 onorm[2];                                         // normalised O_h^T (D layout), written to T behind a barrier
+  {
     f32x16 o[2];
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
 #pragma unroll
@@ -493,20 +504,20 @@ __global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
     for (int kb2 = 0; kb2 < 8; ++kb2) {
-      ar_kv_block<QP, 0, DBG, ABL>(p, L, wave, key0, it, false, kf, q16[hd], o, m_run, l_run,
-                              DBG && hd == 0 && kb2 == 0 && wave == 0 && blockIdx.x == 0 && blockIdx.y == 0);
-      ar_kv_block<QP, 1, DBG, ABL>(p, L, wave, key0, it, hd == 1 && kb2 == 7, kf, q16[hd], o, m_run, l_run);
+      ar_kv_block<QP, 0, DBG, ABL>(p, L, wave, key0, it, false, kf, q16, o, m_run, l_run,
+                              DBG && kb2 == 0 && wave == 0 && blockIdx.x == 0 && blockIdx.y == 0);
+      ar_kv_block<QP, 1, DBG, ABL>(p, L, wave, key0, it, kb2 == 7, kf, q16, o, m_run, l_run);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float inv = 1.f / ar_xhalf_sum(l_run[u]);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) onorm[hd][u][r] = o[u][r] * inv;
-      if constexpr (DBG) {   // [16384 .. 32768): onorm as [wave][hd][u][r][lane]; [32768 .. ): l, m per [wave][hd][u][lane]
+      for (int r = 0; r < 16; ++r) onorm[u][r] = o[u][r] * inv;
+      if constexpr (DBG) {   // [16384 .. 32768): onorm as [wave][u][r][lane]; [32768 .. ): l, m per [wave][u][lane]
         if (blockIdx.x == 0 && blockIdx.y == 0) {
-          for (int r = 0; r < 16; ++r) p.dbg[16384 + (((wave * 2 + hd) * 2 + u) * 16 + r) * 64 + lane] = onorm[hd][u][r];
-          p.dbg[32768 + ((wave * 2 + hd) * 2 + u) * 64 + lane] = l_run[u];
-          p.dbg[32768 + 1024 + ((wave * 2 + hd) * 2 + u) * 64 + lane] = m_run[u];
+          for (int r = 0; r < 16; ++r) p.dbg[16384 + ((wave * 2 + u) * 16 + r) * 64 + lane] = onorm[u][r];
+          p.dbg[32768 + (wave * 2 + u) * 64 + lane] = l_run[u];
+          p.dbg[32768 + 1024 + (wave * 2 + u) * 64 + lane] = m_run[u];
         }
       }
     }
@@ -515,71 +526,60 @@ __global__ __launch_bounds__(256, 1) void att_rows_kernel(const AttRowsParams p)
   // ---- O -> T (k-tile = head; register group g of lane (row l31, half hh) = head dims 8g + 4hh .. +3: one 16-B chunk) ----
   __syncthreads();                                         // everybody is done reading T (QP: the rows to project; else: its own q columns)
 #pragma unroll
-  for (int hd = 0; hd < 2; ++hd)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 ov = {onorm[hd][u][g * 4], onorm[hd][u][g * 4 + 1], onorm[hd][u][g * 4 + 2], onorm[hd][u][g * 4 + 3]};
-        *reinterpret_cast<f32x4*>(T + (wave + 4 * hd) * (AR_BM * 32) + (u * 32 + l31) * 32 + (((g * 2 + hh) ^ L.sw) << 2)) = ov;
-      }
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 ov = {onorm[u][g * 4], onorm[u][g * 4 + 1], onorm[u][g * 4 + 2], onorm[u][g * 4 + 3]};
+      *reinterpret_cast<f32x4*>(T + wave * (AR_BM * 32) + (u * 32 + l31) * 32 + (((g * 2 + hh) ^ L.sw) << 2)) = ov;
+    }
   __syncthreads();                                         // all eight heads' outputs are in T
 
   AR_STAMP(4);
-  // ---- OUT phase ----
-  f32x16 yacc[2][2];
+  // ---- OUT phase: Y[64 rows x columns 32 wave .. +31] ----
+  f32x16 yacc[2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) yacc[a][b][r] = 0.f;
+    for (int r = 0; r < 16; ++r) yacc[a][r] = 0.f;
   {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // Wo piece 0 has landed (pieces 1, 2 may be in flight)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // Wo piece 0 has landed (piece 1 may be in flight)
     ArFrag cur = ar_load_frag<0, 0, 0>(L);
-    ar_out_steps<QP>(p, L, wave, key0, it, cur, yacc, std::make_integer_sequence<int, 64>{});
+    ar_out_steps<QP>(p, L, wave, key0, it, cur, yacc, std::make_integer_sequence<int, 32>{});
   }
 
-  if constexpr (DBG) {   // [36864 .. ): yacc as [wave][mb][nb][r][lane]
+  if constexpr (DBG) {   // [36864 .. ): yacc as [wave][mb][r][lane]
     if (blockIdx.x == 0 && blockIdx.y == 0)
       for (int mb = 0; mb < 2; ++mb)
-        for (int nb = 0; nb < 2; ++nb)
-          for (int r = 0; r < 16; ++r) p.dbg[36864 + (((wave * 2 + mb) * 2 + nb) * 16 + r) * 64 + lane] = yacc[mb][nb][r];
+        for (int r = 0; r < 16; ++r) p.dbg[36864 + ((wave * 2 + mb) * 16 + r) * 64 + lane] = yacc[mb][r];
   }
   AR_STAMP(5);
   // ---- epilogue: Y tile -> LDS, + bias + residual, LayerNorm (8 lanes per row, ffn_rows.hip) ----
   __syncthreads();                                         // nobody reads T any more; no DMA is in flight
   AR_STAMP(6);
-  const int erow = wave * 8 + (lane >> 3), eseg = (lane & 7) * 4;
-  f32x4 xr[2][8];
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int row = mb * 32 + erow;
-    const float* rsrc = p.residual + (row0 + (row < nvalid ? row : 0)) * AR_D + eseg;
+  const int erow = wave * 8 + (lane >> 3), eseg = (lane & 7) * 4;   // 8 lanes per row, 64 rows: one pass
+  f32x4 xr[8];
+  {
+    const float* rsrc = p.residual + (row0 + (erow < nvalid ? erow : 0)) * AR_D + eseg;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      xr[mb][c] = p.residual != nullptr ? *reinterpret_cast<const f32x4*>(rsrc + c * 32) : z;
+      xr[c] = p.residual != nullptr ? *reinterpret_cast<const f32x4*>(rsrc + c * 32) : z;
     }
   }
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        smem[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * AR_LDT + 64 * wave + nb * 32 + l31] = yacc[mb][nb][r];
+    for (int r = 0; r < 16; ++r) smem[(mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * AR_LDT + 32 * wave + l31] = yacc[mb][r];
   __syncthreads();
-#pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int row = mb * 32 + erow;
+  {
+    const int row = erow;
     f32x4 x[8];
     float s1 = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       x[c] = *reinterpret_cast<const f32x4*>(smem + row * AR_LDT + c * 32 + eseg);
       x[c] += *reinterpret_cast<const f32x4*>(bqs + AR_D + c * 32 + eseg);
-      x[c] += xr[mb][c];
+      x[c] += xr[c];
       s1 += (x[c][0] + x[c][1]) + (x[c][2] + x[c][3]);
     }
     const float mean = ar_group8_sum(s1) * (1.f / 256.f);
@@ -636,7 +636,7 @@ int launch_att_rows(const float* q, int ldq, const float* x, const float* x2, co
   p.wo = wo; p.bo = bo; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y; p.zeros = gemm_zero_buffer(); p.nq = nq;
   p.dbg = nullptr;
   const dim3 grid((nq + AR_BM - 1) / AR_BM, nb);
-  if (qp) hipLaunchKernelGGL(att_rows_kernel<true>, grid, dim3(256), kAttRowsSmem, s, p);
-  else hipLaunchKernelGGL(att_rows_kernel<false>, grid, dim3(256), kAttRowsSmem, s, p);
+  if (qp) hipLaunchKernelGGL(att_rows_kernel<true>, grid, dim3(64 * AR_NW), kAttRowsSmem, s, p);
+  else hipLaunchKernelGGL(att_rows_kernel<false>, grid, dim3(64 * AR_NW), kAttRowsSmem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -35,7 +35,7 @@ int main() {
   p.q = qd; p.ldq = ldq; p.k = kvd + 256; p.v = kvd + 512; p.ldkv = ldkv; p.wo = wod; p.bo = bod; p.ln_w = lwd; p.ln_b = lbd; p.Y = yd;
   p.zeros = g_zero; p.nq = nq; p.dbg = dbg;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(att_rows_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttRowsSmem));
-  hipLaunchKernelGGL((att_rows_kernel<false, true>), dim3(1, 1), dim3(256), kAttRowsSmem, 0, p);
+  hipLaunchKernelGGL((att_rows_kernel<false, true>), dim3(1, 1), dim3(512), kAttRowsSmem, 0, p);
   CK(hipDeviceSynchronize());
   std::vector<float> d(65536), y(nq * 256);
   CK(hipMemcpy(d.data(), dbg, d.size() * 4, hipMemcpyDeviceToHost));
@@ -63,36 +63,33 @@ int main() {
       }
     }
   double eq = 0, eo = 0, el = 0, em = 0, ey = 0, ef = 0;
-  for (int w = 0; w < 4; ++w)
-    for (int hd = 0; hd < 2; ++hd)
-      for (int u = 0; u < 2; ++u)
-        for (int r = 0; r < 16; ++r)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int h = w + 4 * hd, m = u * 32 + (lane & 31), dd = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const size_t idx = ((((size_t)w * 2 + hd) * 2 + u) * 16 + r) * 64 + lane;
-            eq = fmax(eq, fabs(d[idx] - q[(size_t)m * ldq + h * 32 + dd] * LOG2E));
-            eo = fmax(eo, fabs(d[16384 + idx] - O[(size_t)m * 256 + h * 32 + dd]));
-          }
-  for (int w = 0; w < 4; ++w)
-    for (int hd = 0; hd < 2; ++hd)
-      for (int u = 0; u < 2; ++u)
-        for (int lane = 0; lane < 32; ++lane) {
-          const int h = w + 4 * hd, m = u * 32 + lane;
-          const size_t idx = (((size_t)w * 2 + hd) * 2 + u) * 64;
-          const double l = d[32768 + idx + lane] + d[32768 + idx + lane + 32];
-          const double mm = d[32768 + 1024 + idx + lane];
-          // compare l * 2^m (scale-free)
-          el = fmax(el, fabs(log2(l) + mm - (log2(Lsum[m * 8 + h]) + Mx[m * 8 + h])));
-          em = fmax(em, fabs(mm - Mx[m * 8 + h]));
+  for (int w = 0; w < 8; ++w)
+    for (int u = 0; u < 2; ++u)
+      for (int r = 0; r < 16; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int h = w, m = u * 32 + (lane & 31), dd = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const size_t idx = (((size_t)w * 2 + u) * 16 + r) * 64 + lane;
+          eq = fmax(eq, fabs(d[idx] - q[(size_t)m * ldq + h * 32 + dd] * LOG2E));
+          eo = fmax(eo, fabs(d[16384 + idx] - O[(size_t)m * 256 + h * 32 + dd]));
         }
-  for (int w = 0; w < 4; ++w)
+  for (int w = 0; w < 8; ++w)
+    for (int u = 0; u < 2; ++u)
+      for (int lane = 0; lane < 32; ++lane) {
+        const int h = w, m = u * 32 + lane;
+        const size_t idx = ((size_t)w * 2 + u) * 64;
+        const double l = d[32768 + idx + lane] + d[32768 + idx + lane + 32];
+        const double mm = d[32768 + 1024 + idx + lane];
+        // compare l * 2^m (scale-free)
+        el = fmax(el, fabs(log2(l) + mm - (log2(Lsum[m * 8 + h]) + Mx[m * 8 + h])));
+        em = fmax(em, fabs(mm - Mx[m * 8 + h]));
+      }
+  for (int w = 0; w < 8; ++w)
     for (int mb = 0; mb < 2; ++mb)
-      for (int nb = 0; nb < 2; ++nb)
-        for (int r = 0; r < 16; ++r)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = 64 * w + 32 * nb + (lane & 31);
-            ey = fmax(ey, fabs(d[36864 + ((((size_t)w * 2 + mb) * 2 + nb) * 16 + r) * 64 + lane] - O[(size_t)m * 256 + n]));
-          }
+      for (int r = 0; r < 16; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = 32 * w + (lane & 31);
+          ey = fmax(ey, fabs(d[36864 + (((size_t)w * 2 + mb) * 16 + r) * 64 + lane] - O[(size_t)m * 256 + n]));
+        }
   for (int m = 0; m < nq; ++m) {
     double mean = 0, var = 0;
     for (int n = 0; n < 256; ++n) mean += O[(size_t)m * 256 + n];
@@ -101,8 +98,8 @@ int main() {
     var /= 256;
     for (int n = 0; n < 256; ++n) ef = fmax(ef, fabs(y[(size_t)m * 256 + n] - (O[(size_t)m * 256 + n] - mean) / sqrt(var + 1e-5)));
   }
-  {  // ring of wavefront 0 after the prologue: slots 0, 1, 2 = K block 0, V block 0, K block 1 of head 0, rows swizzled
-    for (int slot = 0; slot < 3; ++slot) {
+  {  // ring of wavefront 0 after the prologue: slots 0, 1 = K block 0, V block 0 of head 0, rows swizzled
+    for (int slot = 0; slot < 2; ++slot) {
       double e = 0;
       const int col0 = slot == 1 ? 512 : 256, key00 = slot == 2 ? 32 : 0;
       for (int row = 0; row < 32; ++row)
@@ -169,11 +166,11 @@ int main() {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         auto launch = [&]() {
-          if (qp == 1) hipLaunchKernelGGL((att_rows_kernel<true, true>), dim3(8, pairs), dim3(256), kAttRowsSmem, 0, pb);
-          else if (qp == 0) hipLaunchKernelGGL((att_rows_kernel<false, true>), dim3(8, pairs), dim3(256), kAttRowsSmem, 0, pb);
-          else if (qp == 2) hipLaunchKernelGGL((att_rows_kernel<false, true, 1>), dim3(8, pairs), dim3(256), kAttRowsSmem, 0, pb);
-          else if (qp == 3) hipLaunchKernelGGL((att_rows_kernel<false, true, 2>), dim3(8, pairs), dim3(256), kAttRowsSmem, 0, pb);
-          else hipLaunchKernelGGL((att_rows_kernel<false, true, 3>), dim3(8, pairs), dim3(256), kAttRowsSmem, 0, pb);
+          if (qp == 1) hipLaunchKernelGGL((att_rows_kernel<true, true>), dim3(8, pairs), dim3(512), kAttRowsSmem, 0, pb);
+          else if (qp == 0) hipLaunchKernelGGL((att_rows_kernel<false, true>), dim3(8, pairs), dim3(512), kAttRowsSmem, 0, pb);
+          else if (qp == 2) hipLaunchKernelGGL((att_rows_kernel<false, true, 1>), dim3(8, pairs), dim3(512), kAttRowsSmem, 0, pb);
+          else if (qp == 3) hipLaunchKernelGGL((att_rows_kernel<false, true, 2>), dim3(8, pairs), dim3(512), kAttRowsSmem, 0, pb);
+          else hipLaunchKernelGGL((att_rows_kernel<false, true, 3>), dim3(8, pairs), dim3(512), kAttRowsSmem, 0, pb);
         };
         for (int i = 0; i < 3; ++i) launch();
         CK(hipDeviceSynchronize());

@@ -84,6 +84,12 @@ int main(int argc, char** argv) {
       snprintf(tag, sizeof tag, "product, stagger %d (%.0f us per slot)", st, st * 8128 / 2250.0);
       run<0>(p, tag);
     }
+    for (int st : {1, 2, 3, 5}) {
+      p.stagger = st;
+      char tag[64];
+      snprintf(tag, sizeof tag, "phase 2 only, stagger %d", st);
+      run<8>(p, tag);
+    }
     p.stagger = 0;
     CK(hipFree(t1)); CK(hipFree(res)); CK(hipFree(y)); CK(hipFree(w2)); CK(hipFree(w3)); CK(hipFree(par));
   }

@@ -52,6 +52,20 @@ __global__ __launch_bounds__(512) void k_beside(float* out, unsigned long long* 
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(v[(i + 1) & 31]), "v"(v[(i + 2) & 31]));
         n_instr += 10;
+      } else if constexpr (KIND == 7) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) asm volatile("v_exp_f32 %0, %1" : "=v"(v[i]) : "v"(v[(i + 1) & 31]));
+        n_instr += 32;
+      } else if constexpr (KIND == 8) {   // the softmax mix of att_rows.hip per 16 scores: 5 max3, 16 sub, 16 exp, 15 add
+#pragma unroll
+        for (int i = 0; i < 5; ++i) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(v[i + 8]), "v"(v[i + 16]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[31]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+#pragma unroll
+        for (int i = 0; i < 15; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[16 + (i & 7)]) : "v"(v[i]));
+        n_instr += 52;
       } else if constexpr (KIND == 6) {
         int s = it;
 #pragma unroll
@@ -138,6 +152,8 @@ int main() {
     run<2>("ds_read_b128 + 8 VALU", out, st, prio);
     run<3>("ds_write_b32", out, st, prio);
     run<5>("2 global_store_x4 + 8 VALU", out, st, prio);
+    run<7>("v_exp_f32 x 32", out, st, prio);
+    run<8>("softmax mix (max3/sub/exp/add)", out, st, prio);
     run<6>("SALU", out, st, prio);
   }
   return 0;
