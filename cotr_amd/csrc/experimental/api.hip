@@ -920,7 +920,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
           idt = b_d;
         }
         if (!c1_done && (r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
-        if (st == 0 && H == 64 && W == 64 && Bc >= knob(KN_CONV23_MIN_PAIRS)) {
+        if (st == 0 && H == 64 && W == 64 && Bc >= knob(KN_CONV23_MIN_PAIRS) && !h->h2_pass) {   // (fp32 activations only: not on a split-f16 pass)
           // many pairs: conv2 -> conv3 + identity + ReLU in one launch, t2 never leaves the CU (conv23.hip)
           KCHK(h, launch_conv23(b_t1, c2.w, c2.scale, c2.bias, c3.w, c3.scale, c3.bias, idt, y, Bc, s), "conv23");
           if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "conv23 layer1.%d %d pairs", b, Bc); prof_mark(h, nm, s, 2); }
