@@ -91,6 +91,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"att_rows_min_rows", 8192, 0, INT_MAX},
     {"ffn_rows_min_rows", 8192, 0, INT_MAX},
     {"conv23_min_pairs", 5, 1, INT_MAX},
+    {"expand_min_rows", 65536, 0, INT_MAX},
     {"head_fusion_max_rows", 0, 0, INT_MAX},
     {"ffn_preln", 0, 0, 1},
     {"ffn_tail", 0, 0, 1},
@@ -913,10 +914,18 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
         bool c1_done = false;
         if (b == 0) {  // downsample branch (1x1, strided)
           const ConvW& cd = h->convs[ci++];
-          const int pr = conv_pair(h, cd, c1, x, b_d, b_t1, Bc, H, W, s);
-          if (pr < 0) return pr;
-          c1_done = pr == 1;
-          if (!c1_done && (r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
+          if (st == 0 && cd.stride == 1 && c1.cin == 64 && Bc * H * 2 * W >= knob(KN_EXPAND_MIN_ROWS) && !h->h2_pass) {
+            // many pairs: downsample branch and conv1 read the pooled stem output once, in one launch (expand.hip)
+            KCHK(h, launch_expand(x, Bc * H * 2 * W, cd.w, cd.scale, cd.bias, 0, b_d, cd.cout, c1.w, c1.scale, c1.bias, 1, b_t1, c1.cout, s),
+                 "expand");
+            if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "expand ds+conv1 layer1.0 %d pairs", Bc); prof_mark(h, nm, s, 2); }
+            c1_done = true;
+          } else {
+            const int pr = conv_pair(h, cd, c1, x, b_d, b_t1, Bc, H, W, s);
+            if (pr < 0) return pr;
+            c1_done = pr == 1;
+            if (!c1_done && (r = conv(h, cd, x, nullptr, 0, b_d, Bc, H, W, s))) return r;
+          }
           idt = b_d;
         }
         if (!c1_done && (r = conv(h, c1, x, nullptr, 1, b_t1, Bc, H, W, s))) return r;
@@ -1821,6 +1830,12 @@ int cotr_op_att_rows(const float* q, int ldq, const float* x, const float* x2, c
                      const float* ln_w, const float* ln_b, float* y, int nb, int nq, cotr_stream stream) {
   return op_ret(launch_att_rows(q, ldq, x, x2, wq, bq, qscale, k, v, ldkv, wo, bo, residual, ln_w, ln_b, y, nb, nq,
                                 static_cast<hipStream_t>(stream)));
+}
+
+// two 1x1 convolutions (K = 64) over the same x in ONE launch (expand.hip: layer1 block 0's downsample + conv1)
+int cotr_op_expand(const float* x, int M, const float* w0, const float* s0, const float* b0, int relu0, float* y0, int n0, const float* w1,
+                   const float* s1, const float* b1, int relu1, float* y1, int n1, cotr_stream stream) {
+  return op_ret(launch_expand(x, M, w0, s0, b0, relu0, y0, n0, w1, s1, b1, relu1, y1, n1, static_cast<hipStream_t>(stream)));
 }
 
 // conv2 (3x3, 64 -> 64) -> conv3 (1x1, 64 -> 256) + identity + ReLU of a layer1 bottleneck in ONE launch (conv23.hip)

@@ -180,6 +180,11 @@ int cotr_op_att_rows(const float* q, int ldq, const float* x, const float* x2, c
  * second LayerNorm of the result]); y must not alias x */
 int cotr_op_ffn_rows(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
                      const float* ln_b, const float* post_w, const float* post_b, float* y, int M, cotr_stream stream);
+/* one or two 1x1 convolutions with K = 64 over the same x in ONE launch for many rows (expand.hip; layer1 block 0's downsample branch
+ * and conv1 of torchvision's Bottleneck with COTR/models/backbone.py:46-56): y_s = [relu](FrozenBN_s(x . w_s^T)); x [M][64], M a multiple
+ * of 128; w_s [n_s][64], y_s [M][n_s], n_s multiples of 64; n1 == 0: one set.  Shapes it is not written for are declined (-1) */
+int cotr_op_expand(const float* x, int M, const float* w0, const float* s0, const float* b0, int relu0, float* y0, int n0, const float* w1,
+                   const float* s1, const float* b1, int relu1, float* y1, int n1, cotr_stream stream);
 /* conv2 (3x3, padding 1 per half) + FrozenBN + ReLU -> conv3 (1x1) + FrozenBN + identity + ReLU of a layer1 bottleneck in ONE launch
  * (conv23.hip; torchvision Bottleneck.forward with COTR/models/backbone.py:46-56): t1 [B,64,128,64] NHWC side-by-side, w2 [64][3][3][64],
  * w3 [256][64], residual / y [B,64,128,256] */

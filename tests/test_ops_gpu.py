@@ -698,6 +698,47 @@ def test_conv23_one_launch(B):
     assert lib.cotr_op_conv23(G.P(t1d), G.P(w2d), G.P(s2d), G.P(b2d), G.P(w3d), G.P(s3d), G.P(b3d), None, G.P(y), B, G.sptr()) != 0
 
 
+@pytest.mark.parametrize('M,n0,n1', [(128, 256, 64), (128 * 7, 256, 64), (128 * 3, 64, 0), (128 * 2, 128, 192)])
+def test_expand_one_launch(M, n0, n1):
+    """expand.hip: one or two 1x1 convolutions (K = 64) over the same x in one launch - FrozenBN scale / bias, ReLU per weight set
+    (torchvision Bottleneck.forward with COTR/models/backbone.py:46-56: layer1 block 0's downsample branch and conv1): the rows kept in
+    registers as the A operand, the W pieces through two LDS slots, two output tensors with different row pitch."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(M + n0 + n1)
+    x = torch.randn(M, 64, generator=g)
+    d = G.dev()
+    sets, outs, refs = [], [], []
+    for n, relu in ((n0, False), (n1, True)) if n1 else ((n0, True),):
+        w = torch.randn(n, 64, generator=g) / 8
+        sc, b = torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g)
+        ref = (x.double() @ w.double().t()) * sc.double() + b.double()
+        refs.append((F.relu(ref) if relu else ref).float())
+        y = torch.full((M, n), float('nan'), device=d)
+        sets.append((w.to(d), sc.to(d), b.to(d), int(relu), y, n))
+        outs.append(y)
+    if len(sets) == 1:
+        sets.append((None, None, None, 0, None, 0))
+    xd = x.to(d)
+    flat = []
+    for w, sc, b, relu, y, n in sets:
+        flat += [G.P(w), G.P(sc), G.P(b), relu, G.P(y), n]
+    assert lib.cotr_op_expand(G.P(xd), M, *flat, G.sptr()) == 0
+    torch.cuda.synchronize()
+    for y, ref in zip(outs, refs):
+        assert G.rel_err(y.cpu(), ref) < 2e-5
+    # NaN in, NaN out - in that row of both outputs, nowhere else
+    xn = xd.clone()
+    xn[77, 5] = float('nan')
+    assert lib.cotr_op_expand(G.P(xn), M, *flat, G.sptr()) == 0
+    torch.cuda.synchronize()
+    for y in outs:
+        nan = torch.isnan(y)
+        assert bool(nan[77].all()) and int(nan.sum()) == y.shape[1]
+    # declined, not mis-computed: a row count that is not a multiple of the tile
+    assert lib.cotr_op_expand(G.P(xd), M - 1, *flat, G.sptr()) != 0
+
+
 def test_large_tile_configs_are_repeatable():
     """The LDS-DMA kernels order other wavefronts' reads by an explicit vmcnt(0) before the barrier (common.h,
     LDS_DMA_WAIT_ALL); without it thousands of workgroups in flight produced rare stale tiles.  Many workgroups, several
