@@ -52,8 +52,6 @@ struct Conv23Params {
 static_assert(2 * C23_STAGE <= C23_PAR, "the operand stages lie under the W3 ring");
 static_assert(C23_STAGE >= C23_SLOT, "W3 piece 0 fits the stage that is free during the last K step");
 
-namespace {
-
 struct C23Lane {
   int lane, l31, hh, sw, drow, pch;
 };
@@ -302,8 +300,6 @@ __global__ __launch_bounds__(256, 3) void conv23_kernel(const Conv23Params p) {
   c23_block<ABL, 6>(p, smem, pars, L, wave, rbase, ybase, t2, res_a, res_b);
   c23_block<ABL, 7>(p, smem, pars, L, wave, rbase, ybase, t2, res_b, res_a);
 }
-
-}  // namespace
 
 // t1 [B][64][128][64] -> y [B][64][128][256]; residual [B][64][128][256]
 int launch_conv23(const float* t1, const float* w2, const float* s2, const float* b2, const float* w3, const float* s3, const float* b3,

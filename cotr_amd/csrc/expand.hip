@@ -36,8 +36,6 @@ struct ExpandParams {
 #define EX_SLOT 4096                             // floats per W piece
 #define EX_SMEM (2 * EX_SLOT * 4)
 
-namespace {
-
 struct ExLane {
   int lane, l31, hh, sw;
 };
@@ -191,8 +189,6 @@ __global__ __launch_bounds__(256, 4) void expand64_kernel(const ExpandParams p) 
     if (!(ABL & 4)) ex_barrier();
   }
 }
-
-}  // namespace
 
 // x [M][64] (M a multiple of 128); two weight sets (n1 == 0: one), each: w [n][64], scale / bias [n], y [M][n], relu flag; n0, n1
 // multiples of 64

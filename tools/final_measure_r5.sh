@@ -23,6 +23,11 @@ if [ "$part" = all ] || [ "$part" = b ]; then
   ./tools/micro/att_rows_probe.exe | grep -v "   ring\[" > $o/att_rows_probe.txt 2>&1
   python tools/bench_ffn_rows.py 8192 16384 32000 32768 65536 > $o/ab_ffn_rows.txt 2>&1
   python tools/bench_att_rows.py > $o/ab_att_rows.txt 2>&1
+  python tools/bench_conv23.py 8 16 32 64 > $o/ab_conv23.txt 2>&1
+  python tools/bench_expand.py 8 16 32 64 > $o/ab_expand.txt 2>&1
+  ./tools/micro/conv23_probe.exe 32 > $o/conv23_probe.txt 2>&1
+  ./tools/micro/expand_probe.exe > $o/expand_probe.txt 2>&1
+  ./tools/micro/kv_model.exe > $o/kv_model.txt 2>&1
 fi
 if [ "$part" = all ] || [ "$part" = c ]; then
   bash tools/prof.sh r5f > /dev/null 2>&1
