@@ -59,6 +59,7 @@ _PROTOS = {
                                         ctypes.c_int] + [c_float_p] * 6 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_ffn_rows': (ctypes.c_int, [c_float_p] * 10 + [ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_conv23': (ctypes.c_int, [c_float_p] * 9 + [ctypes.c_int, ctypes.c_void_p]),
+    'cotr_op_conv23m': (ctypes.c_int, [c_float_p] * 9 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_op_expand': (ctypes.c_int, [c_float_p, ctypes.c_int] + ([c_float_p] * 3 + [ctypes.c_int, c_float_p, ctypes.c_int]) * 2 + [ctypes.c_void_p]),
     'cotr_op_posenc': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_void_p]),
     'cotr_train_add_rowmod': (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_void_p]),

@@ -20,7 +20,7 @@ LIB = os.path.join(CSRC, 'libcotr_hip.so')
 LIB_EXP = os.path.join(CSRC, 'libcotr_hip_exp.so')
 FORKED = ['gemm.hip', 'gemm_big.hip', 'attention.hip', 'pointwise.hip', 'ffn.hip', 'api.hip']
 SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip',
-           'dense_post.hip', 'ffn.hip', 'ffn_rows.hip', 'att_rows.hip', 'conv23.hip', 'expand.hip', 'train.hip', 'attention_train.hip', 'api.hip']
+           'dense_post.hip', 'ffn.hip', 'ffn_rows.hip', 'att_rows.hip', 'conv23.hip', 'conv23m.hip', 'expand.hip', 'train.hip', 'attention_train.hip', 'api.hip']
 EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip'), os.path.join('experimental', 'gemm_pp.hip'),
                os.path.join('experimental', 'gemm_h2.hip'), os.path.join('experimental', 'attention_h2.hip'), os.path.join('experimental', 'gemm_h2r.hip'),
                os.path.join('experimental', 'linear_rows.hip')]

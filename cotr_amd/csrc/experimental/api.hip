@@ -91,6 +91,7 @@ const KnobDesc kKnobs[KN_COUNT] = {
     {"att_rows_min_rows", 8192, 0, INT_MAX},
     {"ffn_rows_min_rows", 8192, 0, INT_MAX},
     {"conv23_min_pairs", 5, 1, INT_MAX},
+    {"conv23m_min_pairs", 16, 1, INT_MAX},
     {"expand_min_rows", 65536, 0, INT_MAX},
     {"head_fusion_max_rows", 0, 0, INT_MAX},
     {"ffn_preln", 0, 0, 1},
@@ -933,6 +934,10 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
           // many pairs: conv2 -> conv3 + identity + ReLU in one launch, t2 never leaves the CU (conv23.hip)
           KCHK(h, launch_conv23(b_t1, c2.w, c2.scale, c2.bias, c3.w, c3.scale, c3.bias, idt, y, Bc, s), "conv23");
           if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "conv23 layer1.%d %d pairs", b, Bc); prof_mark(h, nm, s, 2); }
+        } else if (st == 1 && Ho == 32 && Wo == 32 && Bc >= knob(KN_CONV23M_MIN_PAIRS) && !h->h2_pass) {
+          // many pairs: the same fusion for layer2 (conv23m.hip)
+          KCHK(h, launch_conv23m(b_t1, c2.w, c2.scale, c2.bias, c3.w, c3.scale, c3.bias, idt, y, Bc, stride, s), "conv23m");
+          if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "conv23m layer2.%d %d pairs", b, Bc); prof_mark(h, nm, s, 2); }
         } else {
           if ((r = conv(h, c2, b_t1, nullptr, 1, b_t2, Bc, H, W, s))) return r;
           if ((r = conv(h, c3, b_t2, idt, 1, y, Bc, Ho, Wo, s))) return r;
@@ -1836,6 +1841,12 @@ int cotr_op_att_rows(const float* q, int ldq, const float* x, const float* x2, c
 int cotr_op_expand(const float* x, int M, const float* w0, const float* s0, const float* b0, int relu0, float* y0, int n0, const float* w1,
                    const float* s1, const float* b1, int relu1, float* y1, int n1, cotr_stream stream) {
   return op_ret(launch_expand(x, M, w0, s0, b0, relu0, y0, n0, w1, s1, b1, relu1, y1, n1, static_cast<hipStream_t>(stream)));
+}
+
+// conv2 (3x3, 128 -> 128, stride 1 / 2) -> conv3 (1x1, 128 -> 512) + identity + ReLU of a layer2 bottleneck in ONE launch (conv23m.hip)
+int cotr_op_conv23m(const float* t1, const float* w2, const float* s2, const float* b2, const float* w3, const float* s3, const float* b3,
+                    const float* residual, float* y, int B, int stride, cotr_stream stream) {
+  return op_ret(launch_conv23m(t1, w2, s2, b2, w3, s3, b3, residual, y, B, stride, static_cast<hipStream_t>(stream)));
 }
 
 // conv2 (3x3, 64 -> 64) -> conv3 (1x1, 64 -> 256) + identity + ReLU of a layer1 bottleneck in ONE launch (conv23.hip)

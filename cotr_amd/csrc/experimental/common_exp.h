@@ -73,6 +73,7 @@ enum KnobId {
   KN_ATT_ROWS_MIN_ROWS,          // attention sub-layer ([q projection,] attention, out projection, residual, LayerNorm) as ONE launch (att_rows.hip) from this many query rows
   KN_FFN_ROWS_MIN_ROWS,          // FFN block + residual + LayerNorm as ONE launch (ffn_rows.hip: 64-row tiles, hidden units dealt to the wavefronts) from this many rows
   KN_CONV23_MIN_PAIRS,           // layer1: conv2 (3x3) -> conv3 (1x1 expansion) + identity + ReLU as ONE launch (conv23.hip) from this many pairs per pass
+  KN_CONV23M_MIN_PAIRS,          // layer2: conv2 (3x3) -> conv3 (1x1 expansion) + identity + ReLU as ONE launch (conv23m.hip) from this many pairs per pass
   KN_EXPAND_MIN_ROWS,            // layer1 block 0's downsample + conv1 as one launch (expand.hip) from this many rows
   KN_HEAD_FUSION_MAX_ROWS,       // decoder.norm + corr_embed as one row-local launch up to this many rows (measured slower; 0)
   KN_FFN_PRELN,                  // the norm before the FFN folded into the fused FFN block (measured neutral; 0)
@@ -313,6 +314,9 @@ int launch_linear_rows(const GemmParams& p, hipStream_t s);
 // layer1 block 0's downsample + conv1 over the same x [M][64] in one launch for many pairs (expand.hip)
 int launch_expand(const float* x, int M, const float* w0, const float* s0, const float* b0, int relu0, float* y0, int n0, const float* w1,
                   const float* s1, const float* b1, int relu1, float* y1, int n1, hipStream_t s);
+// the same for a layer2 bottleneck (conv23m.hip): t1 [B][32 S][64 S][128] -> y [B][32][64][512], stride S = 1 / 2
+int launch_conv23m(const float* t1, const float* w2, const float* s2, const float* b2, const float* w3, const float* s3, const float* b3,
+                   const float* residual, float* y, int B, int stride, hipStream_t s);
 // conv2 (3x3) -> conv3 (1x1) of a layer1 bottleneck in one launch for many pairs (conv23.hip): t1 [B][64][128][64] -> y [B][64][128][256]
 int launch_conv23(const float* t1, const float* w2, const float* s2, const float* b2, const float* w3, const float* s3, const float* b3,
                   const float* residual, float* y, int B, hipStream_t s);

@@ -180,6 +180,10 @@ int cotr_op_att_rows(const float* q, int ldq, const float* x, const float* x2, c
  * second LayerNorm of the result]); y must not alias x */
 int cotr_op_ffn_rows(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* ln_w,
                      const float* ln_b, const float* post_w, const float* post_b, float* y, int M, cotr_stream stream);
+/* the same for a layer2 bottleneck (conv23m.hip): t1 [B,32 S,64 S,128] NHWC side-by-side (S = stride of the 3x3: 1 or 2), w2 [128][3][3][128],
+ * w3 [512][128], residual / y [B,32,64,512] */
+int cotr_op_conv23m(const float* t1, const float* w2, const float* s2, const float* b2, const float* w3, const float* s3, const float* b3,
+                    const float* residual, float* y, int B, int stride, cotr_stream stream);
 /* one or two 1x1 convolutions with K = 64 over the same x in ONE launch for many rows (expand.hip; layer1 block 0's downsample branch
  * and conv1 of torchvision's Bottleneck with COTR/models/backbone.py:46-56): y_s = [relu](FrozenBN_s(x . w_s^T)); x [M][64], M a multiple
  * of 128; w_s [n_s][64], y_s [M][n_s], n_s multiples of 64; n1 == 0: one set.  Shapes it is not written for are declined (-1) */

@@ -739,6 +739,40 @@ def test_expand_one_launch(M, n0, n1):
     assert lib.cotr_op_expand(G.P(xd), M - 1, *flat, G.sptr()) != 0
 
 
+@pytest.mark.parametrize('B,stride', [(1, 1), (3, 1), (2, 2)])
+def test_conv23m_one_launch(B, stride):
+    """conv23m.hip: conv2 3x3 (stride 1 / 2, + FrozenBN + ReLU) -> conv3 1x1 (+ FrozenBN + identity + ReLU) of a layer2 bottleneck in ONE
+    launch, against torchvision's Bottleneck.forward per half (COTR/models/backbone.py:46-56,79-92) and against the two launches it
+    replaces: the zero padding of every half's border (also at the seam), the strided taps of block 0, the W3 pieces through registers."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    g = _g(B * 17 + stride)
+    hin = 32 * stride
+    t1 = F.relu(torch.randn(B, 128, hin, 2 * hin, generator=g))
+    w2 = torch.randn(128, 128, 3, 3, generator=g) / math.sqrt(1152)
+    w3 = torch.randn(512, 128, 1, 1, generator=g) / math.sqrt(128)
+    idt = torch.randn(B, 512, 32, 64, generator=g)
+    sb = lambda n: (torch.rand(n, generator=g) + 0.5, torch.randn(n, generator=g))
+    (s2, b2), (s3, b3) = sb(128), sb(512)
+    bn = lambda t, s_, b_: t * s_.view(1, -1, 1, 1) + b_.view(1, -1, 1, 1)
+    t2_ref = G.per_half(lambda h: F.relu(bn(F.conv2d(h, w2, stride=stride, padding=1), s2, b2)), t1)
+    ref = F.relu(bn(F.conv2d(t2_ref, w3), s3, b3) + idt)
+    d = G.dev()
+    t1d, idtd = G.nchw_to_sbs(t1).to(d), G.nchw_to_sbs(idt).to(d)
+    w2d, w3d = G.pack_conv_weight(w2).to(d), G.pack_conv_weight(w3).to(d)
+    s2d, b2d, s3d, b3d = s2.to(d), b2.to(d), s3.to(d), b3.to(d)
+    y = torch.full((B, 32, 64, 512), float('nan'), device=d)
+    rc = lib.cotr_op_conv23m(G.P(t1d), G.P(w2d), G.P(s2d), G.P(b2d), G.P(w3d), G.P(s3d), G.P(b3d), G.P(idtd), G.P(y), B, stride, G.sptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    e = G.rel_err(G.sbs_to_nchw(y.cpu()), ref)
+    assert e < 3e-5, e
+    t2 = G.op_conv(t1d, w2d, s2d, b2d, None, True, 128, 3, stride)
+    y2 = G.op_conv(t2, w3d, s3d, b3d, idtd, True, 512, 1, 1)
+    assert G.rel_err(y, y2) < 1e-5
+    assert lib.cotr_op_conv23m(G.P(t1d), G.P(w2d), G.P(s2d), G.P(b2d), G.P(w3d), G.P(s3d), G.P(b3d), G.P(idtd), G.P(y), B, 3, G.sptr()) != 0
+
+
 def test_large_tile_configs_are_repeatable():
     """The LDS-DMA kernels order other wavefronts' reads by an explicit vmcnt(0) before the barrier (common.h,
     LDS_DMA_WAIT_ALL); without it thousands of workgroups in flight produced rare stale tiles.  Many workgroups, several

@@ -24,7 +24,11 @@ def main():
     w3 = (torch.randn(256, 64, generator=g) / 8).to(d)
     s2, b2 = (torch.rand(64, generator=g) + 0.5).to(d), torch.randn(64, generator=g).to(d)
     s3, b3 = (torch.rand(256, generator=g) + 0.5).to(d), torch.randn(256, generator=g).to(d)
-    print('# pairs | one launch us (TFLOP/s, of peak) | two launches us (TFLOP/s, of peak) | max rel diff')
+    w2m = (torch.randn(128, 3, 3, 128, generator=g) / math.sqrt(1152)).to(d)
+    w3m = (torch.randn(512, 128, generator=g) / math.sqrt(128)).to(d)
+    s2m, b2m = (torch.rand(128, generator=g) + 0.5).to(d), torch.randn(128, generator=g).to(d)
+    s3m, b3m = (torch.rand(512, generator=g) + 0.5).to(d), torch.randn(512, generator=g).to(d)
+    print('# pairs | layer1: one launch us (TFLOP/s, of peak) | two launches us (TFLOP/s, of peak) | max rel diff || layer2: one launch us (of peak) | two launches us (of peak) | max rel diff')
     for B in pairs:
         t1 = torch.relu(torch.randn(B, 64, 128, 64, generator=g)).to(d)
         idt = torch.randn(B, 64, 128, 256, generator=g).to(d)
@@ -42,8 +46,23 @@ def main():
 
         ta, tb = timeit(one), timeit(two)
         fl = 2 * B * 8192 * 64 * (576 + 256)
-        print(f'{B:4d} | {ta:8.1f} ({fl / ta * 1e-6:6.1f}, {fl / ta * 1e-6 / 157.3:.3f}) | {tb:8.1f} ({fl / tb * 1e-6:6.1f}, {fl / tb * 1e-6 / 157.3:.3f}) | '
-              f'{G.rel_err(y, y2):.2e}')
+        line = (f'{B:4d} | {ta:8.1f} ({fl / ta * 1e-6:6.1f}, {fl / ta * 1e-6 / 157.3:.3f}) | {tb:8.1f} ({fl / tb * 1e-6:6.1f}, {fl / tb * 1e-6 / 157.3:.3f}) | '
+                f'{G.rel_err(y, y2):.2e}')
+        # layer2 (conv23m.hip): 128 -> 128 (3x3, stride 1) -> 512
+        u1 = torch.relu(torch.randn(B, 32, 64, 128, generator=g)).to(d)
+        idm = torch.randn(B, 32, 64, 512, generator=g).to(d)
+        ym, u2, ym2 = torch.empty(B, 32, 64, 512, device=d), torch.empty(B, 32, 64, 128, device=d), torch.empty(B, 32, 64, 512, device=d)
+
+        def onem():
+            assert lib.cotr_op_conv23m(G.P(u1), G.P(w2m), G.P(s2m), G.P(b2m), G.P(w3m), G.P(s3m), G.P(b3m), G.P(idm), G.P(ym), B, 1, s) == 0
+
+        def twom():
+            assert lib.cotr_op_conv(G.P(u1), G.P(w2m), G.P(s2m), G.P(b2m), None, 1, G.P(u2), B, 32, 32, 128, 128, 3, 1, s) == 0
+            assert lib.cotr_op_conv(G.P(u2), G.P(w3m), G.P(s3m), G.P(b3m), G.P(idm), 1, G.P(ym2), B, 32, 32, 128, 512, 1, 1, s) == 0
+
+        tc, td = timeit(onem), timeit(twom)
+        flm = 2 * B * 2048 * 128 * (1152 + 512)
+        print(line + f' || {tc:8.1f} ({flm / tc * 1e-6 / 157.3:.3f}) | {td:8.1f} ({flm / td * 1e-6 / 157.3:.3f}) | {G.rel_err(ym, ym2):.2e}')
 
 
 if __name__ == '__main__':
