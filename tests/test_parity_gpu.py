@@ -231,6 +231,22 @@ def test_dual_conv_launch_is_bit_identical_to_two_launches():
     assert cotr_oracle.px_err(dual, cotr_oracle.cotr_forward(sd, img, qs)) < PX_BAR
 
 
+def test_backbone_fusions_are_bit_identical_to_the_launches_they_replace():
+    """conv23.hip / conv23m.hip (conv2 -> conv3 of a layer1 / layer2 bottleneck in one launch) and expand.hip (layer1 block 0's downsample
+    + conv1 in one launch) keep the k order of the large-tile GEMM: a forward with them and one with the knobs that turn them off return
+    the same bits - on a batch that is neither a power of two nor a multiple of the encode chunk's tile counts (17 pairs), and within
+    the 1e-3 px bar of the CPU oracle on its first pairs."""
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(17, 40, seed=29)
+    m = hip_model()
+    on = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    with G.model_knobs(m, conv23_min_pairs=1 << 20, conv23m_min_pairs=1 << 20, expand_min_rows=1 << 30):
+        off = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    assert torch.equal(on, off)
+    ref = cotr_oracle.cotr_forward(sd, img[:2], qs[:2])
+    assert cotr_oracle.px_err(on[:2], ref) < 1e-3
+
+
 def test_caller_supplied_workspace():
     """cotr_set_workspace: the library's encode cache + scratch live in the caller's (torch caching allocator's) memory.
     Growing shapes re-carve a larger workspace; a cached encode survives the move; a workspace that is too small is an error,
