@@ -117,16 +117,23 @@ __device__ __forceinline__ float lin_sine(float px, float py, int c) {
 }
 
 __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ pts, float* __restrict__ y,
-                                                     int nq, int q_total) {
-  const int row = blockIdx.x;  // bi*nq + qi
-  const int bi = row / nq, qi = row - bi * nq;
-  const float* p = pts + ((size_t)bi * q_total + qi) * 2;
-  y[(size_t)row * 256 + threadIdx.x] = lin_sine(p[0], p[1], threadIdx.x);
+                                                     int nq, int q_total, int rows, int rpw) {
+  // rpw rows per workgroup: one row per workgroup is 32000 workgroups of one sinf per thread at 32 x 1000 (launch-rate bound);
+  // few rows keep one row per workgroup (1000 rows = 1000 workgroups fill the chip)
+  for (int i = 0; i < rpw; ++i) {
+    const int row = blockIdx.x * rpw + i;        // bi*nq + qi
+    if (row >= rows) return;
+    const int bi = row / nq, qi = row - bi * nq;
+    const float* p = pts + ((size_t)bi * q_total + qi) * 2;
+    y[(size_t)row * 256 + threadIdx.x] = lin_sine(p[0], p[1], threadIdx.x);
+  }
 }
 
 int launch_posenc(const float* pts, float* y, int nb, int nq, int q_total, hipStream_t s) {
   if (nb * nq <= 0) return 0;
-  hipLaunchKernelGGL(posenc_kernel, dim3(nb * nq), dim3(256), 0, s, pts, y, nq, q_total);
+  const int rows = nb * nq;
+  const int rpw = rows >= 16384 ? 8 : rows >= 4096 ? 2 : 1;
+  hipLaunchKernelGGL(posenc_kernel, dim3((rows + rpw - 1) / rpw), dim3(256), 0, s, pts, y, nq, q_total, rows, rpw);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
