@@ -1,6 +1,6 @@
 """Build libcotr_hip.so (gfx950) in-tree with hipcc.
 
-    python -m cotr_amd.build [--force] [--experimental | --experimental-only]
+    python -m cotr_amd.build [--force] [--experimental | --experimental-only] [--refresh-patches NAME ...]
 
 The shared object lands next to the sources (``cotr_amd/csrc/libcotr_hip.so``): it is
 git-ignored but travels with the gpurun snapshot, so the GPU box never compiles.
@@ -13,12 +13,20 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB = os.path.join(CSRC, 'libcotr_hip.so')
-# The research library (split-f16 products, the measured dead ends and their knobs): built with -DCOTR_EXPERIMENTAL from its OWN copies
-# of the translation units it changes (csrc/experimental/<name>, FORKED below) + the product's other translation units (which reach its
-# declarations through the redirect in common.h) + csrc/experimental/*.hip.  The product sources contain none of its code.  Never loaded
-# by the product path; tests/test_experimental_gpu.py and the A/B tools select it with COTR_HIP_EXPERIMENTAL=1.
+# The research library (split-f16 products, the measured dead ends and their knobs): built with -DCOTR_EXPERIMENTAL from PATCHED copies
+# of the translation units it changes (FORKED below) + the product's other translation units (which reach its declarations through the
+# redirect in common.h) + csrc/experimental/*.hip.  The patched copies are not in the repository: csrc/experimental/patches/<name>.patch
+# (a unified diff against the product file) is applied to the CURRENT product source at build time into csrc/experimental/gen/
+# (git-ignored), so a fix to a product kernel reaches the research library with the next build, and a product edit a patch no longer
+# fits fails that build loudly instead of leaving a stale fork behind (tests/test_abi_cpu.py checks that every patch applies).
+# The product sources contain none of the research code.  Never loaded by the product path; tests/test_experimental_gpu.py and the
+# A/B tools select it with COTR_HIP_EXPERIMENTAL=1.
 LIB_EXP = os.path.join(CSRC, 'libcotr_hip_exp.so')
 FORKED = ['gemm.hip', 'gemm_big.hip', 'attention.hip', 'pointwise.hip', 'ffn.hip', 'api.hip']
+PATCH_DIR = os.path.join(CSRC, 'experimental', 'patches')
+GEN_DIR = os.path.join(CSRC, 'experimental', 'gen')
+# generated name -> (product source, patch)
+GENERATED = {**{f: (f, f + '.patch') for f in FORKED}, 'common_exp.h': ('common.h', 'common_exp.h.patch')}
 SOURCES = ['gemm.hip', 'gemm_big.hip', 'gemm_wp.hip', 'bottleneck.hip', 'attention.hip', 'pointwise.hip', 'stem_pool.hip', 'crop_resize.hip',
            'dense_post.hip', 'ffn.hip', 'ffn_rows.hip', 'att_rows.hip', 'conv23.hip', 'conv23m.hip', 'expand.hip', 'train.hip', 'attention_train.hip', 'api.hip']
 EXP_SOURCES = [os.path.join('experimental', 'head.hip'), os.path.join('experimental', 'gemm_ln.hip'), os.path.join('experimental', 'gemm_pp.hip'),
@@ -33,7 +41,8 @@ EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ff
                # work, whatever the interleaving; profiles/r5_att_rows_probe.txt)
                'att_rows.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 HEADERS = ['common.h', 'train.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
-EXP_HEADERS = [os.path.join('experimental', f) for f in ['coop_tail.h', 'experimental.h', 'api_exp.inc', 'gemm_h2.h', 'common_exp.h'] + FORKED]
+EXP_HEADERS = [os.path.join('experimental', f) for f in ['coop_tail.h', 'experimental.h', 'api_exp.inc', 'gemm_h2.h']] + \
+              [os.path.join('experimental', 'patches', pt) for _, pt in GENERATED.values()]
 # code-object v5: loadable by the ROCm 7.0 runtime torch bundles as well as by ROCm 7.2's
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-mcode-object-version=5', '-fvisibility=hidden',
          '-Wall', '-Wno-unused-function']
@@ -56,6 +65,41 @@ def _version_script(objdir, experimental):
     with open(path, 'w') as f:
         f.write('{\n  global:\n' + ''.join(f'    {n};\n' for n in declared_symbols(experimental)) + '  local:\n    *;\n};\n')
     return path
+
+
+def generate_forks(dest=None, verbose=False):
+    """Apply csrc/experimental/patches/*.patch to the current product sources -> dest (default csrc/experimental/gen/).  Raises with
+    patch(1)'s report when a hunk no longer fits.  Returns the directory."""
+    dest = dest or GEN_DIR
+    os.makedirs(dest, exist_ok=True)
+    exe = shutil.which('patch')
+    if not exe:
+        raise RuntimeError('patch(1) not found (needed to derive the research library\'s sources from the product sources)')
+    for name, (src, pt) in GENERATED.items():
+        out = os.path.join(dest, name)
+        r = subprocess.run([exe, '--no-backup-if-mismatch', '-s', '-F', '3', '-o', out, os.path.join(CSRC, src), os.path.join(PATCH_DIR, pt)],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0 or os.path.exists(out + '.rej'):
+            raise RuntimeError(f'experimental/patches/{pt} no longer applies to csrc/{src} (edit the patch, or regenerate it with '
+                               f'`python -m cotr_amd.build --refresh-patches` after fixing {out} by hand):\n{r.stdout}')
+        if verbose:
+            print(f'generated {out}')
+    return dest
+
+
+def refresh_patches(names):
+    """After editing generated sources under csrc/experimental/gen/ by hand: rewrite the patches of the NAMED ones (e.g. api.hip
+    common_exp.h) as the diff against the product file.  Named explicitly on purpose: a generated file that was not regenerated since
+    its product file changed would otherwise turn the product's change into a reverse hunk of the patch."""
+    for name, (src, pt) in GENERATED.items():
+        gen = os.path.join(GEN_DIR, name)
+        if name not in names:
+            continue
+        if not os.path.exists(gen):
+            raise RuntimeError(f'{gen} does not exist')
+        r = subprocess.run(['diff', '-u', '--label', src, '--label', name, os.path.join(CSRC, src), gen], stdout=subprocess.PIPE, text=True)
+        open(os.path.join(PATCH_DIR, pt), 'w').write(r.stdout)
+        print(f'refreshed experimental/patches/{pt}')
 
 
 def _hipcc():
@@ -85,10 +129,14 @@ def build_library(force=False, verbose=False, experimental=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
-    sources = [os.path.join('experimental', f) if f in FORKED else f for f in SOURCES] + EXP_SOURCES if experimental else SOURCES
+    if experimental:
+        generate_forks(verbose=verbose)
+    sources = [os.path.join('experimental', 'gen', f) if f in FORKED else f for f in SOURCES] + EXP_SOURCES if experimental else SOURCES
+    # (-I csrc/experimental: the generated sources keep the relative includes of a file that lives in csrc/experimental/)
+    exp_flags = ['-DCOTR_EXPERIMENTAL', '-I' + os.path.join(CSRC, 'experimental')] if experimental else []
     for src in sources:
         obj = os.path.join(objdir, os.path.basename(src).replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + (['-DCOTR_EXPERIMENTAL'] if experimental else []) + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + exp_flags + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -107,6 +155,9 @@ def build_library(force=False, verbose=False, experimental=False):
 
 
 if __name__ == '__main__':
+    if '--refresh-patches' in sys.argv:
+        refresh_patches(sys.argv[sys.argv.index('--refresh-patches') + 1:])
+        sys.exit(0)
     force = '--force' in sys.argv
     if '--experimental-only' not in sys.argv:
         print(build_library(force=force, verbose=True))

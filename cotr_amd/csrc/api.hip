@@ -64,34 +64,43 @@ thread_local std::string g_create_error;
 
 // ---- tuning knobs (KnobId in common.h): name, shipped default, accepted range; a few have a value set instead of a range ----
 struct KnobDesc {
+  int id;            // its KnobId: the table below must list the knobs in the enum's order (checked at compile time)
   const char* name;
   int def, lo, hi;
 };
-const KnobDesc kKnobs[KN_COUNT] = {
-    {"encode_chunk", 64, 1, ENC_CHUNK_MAX},
-    {"attention_fusion_max_rows", 1024, 0, INT_MAX},
-    {"ffn_fusion_max_rows", 1024, 0, INT_MAX},
-    {"ks3", 1, 0, 1},
-    {"dual_conv", 1, 0, 1},
-    {"fused_stem", 1, 0, 1},
-    {"xcd_mapping", 1, 0, 31},
-    {"attention_fused_splits", 0, 0, 84},
-    {"conv_patch", 1, 0, 1},
-    {"pos_table_min_rows", 8192, 0, INT_MAX},
-    {"attention_wide_occupancy", 3, 2, 3},
-    {"attention_wide_min_rows", 4096, 0, INT_MAX},
-    {"attention_splits", 0, 0, 16},
-    {"conv1x1_dense", 1, 0, 1},
-    {"ws_flags", 2, 0, 3},
-    {"bottleneck_max_pairs", 4, 0, INT_MAX},
-    {"train_attention_form", 0, 0, 3},
-    {"attention_resident", 1, 0, 1},
-    {"att_rows_min_rows", 8192, 0, INT_MAX},
-    {"ffn_rows_min_rows", 8192, 0, INT_MAX},
-    {"conv23_min_pairs", 5, 1, INT_MAX},
-    {"conv23m_min_pairs", 16, 1, INT_MAX},
-    {"expand_min_rows", 65536, 0, INT_MAX},
+constexpr KnobDesc kKnobs[] = {
+    {KN_ENCODE_CHUNK, "encode_chunk", 64, 1, ENC_CHUNK_MAX},
+    {KN_ATTENTION_FUSION_MAX_ROWS, "attention_fusion_max_rows", 1024, 0, INT_MAX},
+    {KN_FFN_FUSION_MAX_ROWS, "ffn_fusion_max_rows", 1024, 0, INT_MAX},
+    {KN_KS3, "ks3", 1, 0, 1},
+    {KN_DUAL_CONV, "dual_conv", 1, 0, 1},
+    {KN_FUSED_STEM, "fused_stem", 1, 0, 1},
+    {KN_XCD_MAPPING, "xcd_mapping", 1, 0, 63},
+    {KN_ATTENTION_FUSED_SPLITS, "attention_fused_splits", 0, 0, 84},
+    {KN_CONV_PATCH, "conv_patch", 1, 0, 1},
+    {KN_POS_TABLE_MIN_ROWS, "pos_table_min_rows", 8192, 0, INT_MAX},
+    {KN_ATTENTION_WIDE_OCCUPANCY, "attention_wide_occupancy", 3, 2, 3},
+    {KN_ATTENTION_WIDE_MIN_ROWS, "attention_wide_min_rows", 4096, 0, INT_MAX},
+    {KN_ATTENTION_SPLITS, "attention_splits", 0, 0, 16},
+    {KN_CONV1X1_DENSE, "conv1x1_dense", 1, 0, 1},
+    {KN_WS_FLAGS, "ws_flags", 2, 0, 3},
+    {KN_BOTTLENECK_MAX_PAIRS, "bottleneck_max_pairs", 4, 0, INT_MAX},
+    {KN_TRAIN_ATTENTION_FORM, "train_attention_form", 0, 0, 3},
+    {KN_ATTENTION_RESIDENT, "attention_resident", 1, 0, 1},
+    {KN_ATT_ROWS_MIN_ROWS, "att_rows_min_rows", 8192, 0, INT_MAX},
+    {KN_FFN_ROWS_MIN_ROWS, "ffn_rows_min_rows", 8192, 0, INT_MAX},
+    {KN_CONV23_MIN_PAIRS, "conv23_min_pairs", 5, 1, INT_MAX},
+    {KN_CONV23M_MIN_PAIRS, "conv23m_min_pairs", 16, 1, INT_MAX},
+    {KN_EXPAND_MIN_ROWS, "expand_min_rows", 65536, 0, INT_MAX},
+    {KN_ROWS_MIN_FILL, "rows_min_fill", 75, 0, 100},
+    {KN_SIDE_STREAM, "side_stream", 0, 0, 3},
 };
+constexpr bool knobs_in_enum_order() {
+  for (int i = 0; i < (int)(sizeof(kKnobs) / sizeof(kKnobs[0])); ++i)
+    if (kKnobs[i].id != i) return false;
+  return true;
+}
+static_assert(sizeof(kKnobs) / sizeof(kKnobs[0]) == KN_COUNT && knobs_in_enum_order(), "kKnobs must follow enum KnobId entry by entry");
 bool knob_value_ok(int id, int v) {
   if (v < kKnobs[id].lo || v > kKnobs[id].hi) return false;
   if (id == KN_XCD_MAPPING) return (v & 3) != 3;
@@ -148,6 +157,10 @@ struct cotr_ctx {
   // caller-supplied scratch (cotr_set_workspace): the three arenas are carved from it instead of hipMalloc'ed
   char* ws = nullptr;
   size_t ws_bytes = 0, ws_used = 0;
+  // second stream of the handle (knob side_stream): work that depends on the queries only / on the memory only runs beside the chain
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_q = nullptr, ev_mem = nullptr, ev_kv = nullptr;
+  int side_mode = 0;   // the knob's bits for the cotr_forward call in flight (0 outside one, or where its conditions do not hold)
   // profiling
   int prof = 0;  // 0 off, 1 per stage, 2 per kernel launch
   std::vector<std::string> prof_names;
@@ -285,13 +298,13 @@ GemmParams base_params() {
 // y[M,N] = epi( (x (+x2)) . w^T )
 int linear(cotr_ctx* h, const float* x, const float* x2, int x2_row_mod, int a2_period, int a2_width,
            const float* w, const float* bias, const float* residual, int relu, float colscale, int colscale_n,
-           float* y, int M, int N, int K, hipStream_t s, int ldc = 0, int res_row_mod = 0) {
+           float* y, int M, int N, int K, hipStream_t s, int ldc = 0, int res_row_mod = 0, int ldr = 0) {
   GemmParams p = base_params();
   p.M = M; p.N = N; p.K = K;
   p.A = x; p.lda = K;
   p.A2 = x2; p.lda2 = K; p.a2_row_mod = x2_row_mod; p.a2_period = a2_period; p.a2_width = a2_width;
   p.W = w; p.C = y; p.ldc = ldc ? ldc : N;
-  p.bias = bias; p.residual = residual; p.ldr = N; p.res_row_mod = res_row_mod; p.relu = relu;
+  p.bias = bias; p.residual = residual; p.ldr = ldr ? ldr : N; p.res_row_mod = res_row_mod; p.relu = relu;
   p.colscale = colscale; p.colscale_n = colscale_n;
   KCHK(h, launch_gemm(GEMM_DENSE, p, s), "linear");
   if (h->prof >= 2) { char nm[96]; snprintf(nm, sizeof nm, "linear %dx%dx%d cfg%d", M, N, K, gemm_pick_config(GEMM_DENSE, p)); prof_mark(h, nm, s, 2); }
@@ -311,7 +324,7 @@ int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float
 bool ffn_rows_applies(int M) {
   if (M < knob(KN_FFN_ROWS_MIN_ROWS) || M <= knob(KN_FFN_FUSION_MAX_ROWS)) return false;
   const long tiles = (M + 63) / 64, rounds = (tiles + 255) / 256;
-  return tiles * 4 >= rounds * 256 * 3;
+  return tiles * 100 >= rounds * 256 * knob(KN_ROWS_MIN_FILL);
 }
 
 // The attention sub-layer as ONE launch (att_rows.hip): from knob att_rows_min_rows query rows on, where its 64-query tiles (per
@@ -320,7 +333,7 @@ bool att_rows_applies(int nb, int nq) {
   const long R = (long)nb * nq;
   if (R < knob(KN_ATT_ROWS_MIN_ROWS) || R <= knob(KN_ATTENTION_FUSION_MAX_ROWS)) return false;
   const long tpp = (nq + 63) / 64, tiles = tpp * nb, rounds = (tiles + 255) / 256;
-  return tiles * 4 >= rounds * 256 * 3 && (long)nq * 8 >= tpp * 64 * 7;
+  return tiles * 100 >= rounds * 256 * knob(KN_ROWS_MIN_FILL) && (long)nq * 8 >= tpp * 64 * 7;
 }
 
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
@@ -463,6 +476,9 @@ void cotr_destroy(cotr_handle h) {
   prof_reset(h);
   if (h->wbuf) (void)hipFree(h->wbuf);
   if (h->pos) (void)hipFree(h->pos);
+  for (hipEvent_t ev : {h->ev_fork, h->ev_q, h->ev_mem, h->ev_kv})
+    if (ev) (void)hipEventDestroy(ev);
+  if (h->side) (void)hipStreamDestroy(h->side);
   for (Arena* a : {&h->memkv, &h->enc_scr, &h->dec_scr})
     if (a->ptr && !a->external) (void)hipFree(a->ptr);
   for (auto& kv : h->tap_store)
@@ -864,7 +880,17 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
     float* kv_c = kv + (size_t)b0 * TOK * KVLD;
     // (the hoisted K/V projection takes the table at any row count: 3072 columns fill the chip with large tiles even at one pair -
     // 18 -> 14 us there; the encoder in-projections only from knob pos_table_min_rows on)
-    if (knob(KN_POS_TABLE_MIN_ROWS) < (1 << 30)) {
+    if ((h->side_mode & 2) && B <= ENC_CHUNK && knob(KN_POS_TABLE_MIN_ROWS) < (1 << 30)) {
+      // cotr_forward with few rows (knob side_stream bit 1): decoder layer 0 needs its own K / V columns only - the other layers'
+      // 5/6 of this product run on the handle's second stream beside decoder layer 0 (decode_chunk waits for them before layer 1)
+      const int n0 = 2 * D, n1 = (int)KVLD - n0;
+      if ((r = linear(h, mem_c, nullptr, 0, 1, 0, h->kv_w, h->kv_b, h->tab_kv, 0, 1.f, 0, kv_c, M, n0, D, s, (int)KVLD, TOK, (int)KVLD))) return r;
+      HIPCHK(h, hipEventRecord(h->ev_mem, s));
+      HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_mem, 0));
+      if ((r = linear(h, mem_c, nullptr, 0, 1, 0, h->kv_w + (size_t)n0 * D, h->kv_b + n0, h->tab_kv + n0, 0, 1.f, 0, kv_c + n0, M, n1, D, h->side,
+                      (int)KVLD, TOK, (int)KVLD))) return r;
+      HIPCHK(h, hipEventRecord(h->ev_kv, h->side));
+    } else if (knob(KN_POS_TABLE_MIN_ROWS) < (1 << 30)) {
       if ((r = linear(h, mem_c, nullptr, 0, 1, 0, h->kv_w, h->kv_b, h->tab_kv, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s, 0, TOK))) return r;
     } else if ((r = linear(h, mem_c, h->pos, TOK, 2 * D, D, h->kv_w, h->kv_b, nullptr, 0, 1.f, 0, kv_c, M, (int)KVLD, D, s))) return r;
     prof_mark(h, "dec_kv", s);
@@ -927,8 +953,13 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
 // query-side prologue of one chunk: lin_sine encoding of the queries (cotr_model.py:34-36) and layer 0's
 // q = Wq(0 + query_pos) * 32^-0.5 (tgt == 0 at layer 0, transformer.py:54).  Depends on the queries only.
 int dec_prologue(cotr_ctx* h, const DecPlan& d, const float* qsrc, int nb, int nq, int Q, hipStream_t s, bool fused) {
-  KCHK(h, launch_posenc(qsrc, d.qpos, nb, nq, Q, s), "posenc");
-  prof_mark(h, "posenc", s, 2);
+  if (h->side_mode & 1) {
+    // (knob side_stream bit 0) cotr_forward already ran the query encoding on the second stream, beside the backbone
+    HIPCHK(h, hipStreamWaitEvent(s, h->ev_q, 0));
+  } else {
+    KCHK(h, launch_posenc(qsrc, d.qpos, nb, nq, Q, s), "posenc");
+    prof_mark(h, "posenc", s, 2);
+  }
   if (fused) return COTR_OK;   // the attention kernel projects its own queries
   const DecW& w = h->dec[0];
   return linear(h, d.qpos, nullptr, 0, 1, 0, w.q_w, w.q_b, nullptr, 0, QSCALE, D, d.q, nb * nq, D, D, s);
@@ -953,6 +984,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
     const DecW& w = h->dec[li];
     const float* kl = kv_c + (size_t)li * 2 * D;          // this layer's K (then V) columns of the hoisted projection
     const float* tgt_in = li == 0 ? nullptr : d.tgt;      // tgt == 0 at layer 0 (transformer.py:54)
+    if (li == 1 && (h->side_mode & 2)) HIPCHK(h, hipStreamWaitEvent(s, h->ev_kv, 0));   // K / V of layers 1-5 from the second stream
     if (fused) {
       // few rows: q = Wq(tgt + query_pos) * 32^-0.5 in the attention kernel's prologue, out_proj in its epilogue (8 per-head
       // partials), then ln_reduce: sum + bias + residual + norm2; FFN block; 4 launches per layer.  Last layer: decoder.norm rides
@@ -1043,17 +1075,45 @@ int cotr_decode(cotr_handle h, const float* queries, int B, int Q, float* out, c
   return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
 }
 
+// cotr_forward after its argument checks (the research library wraps this call; keep the entry point itself a one-liner)
+static int forward_impl(cotr_ctx* h, const float* img, const float* queries, int B, int Q, float* out, hipStream_t s) {
+  int side = 0;
+  if (Q > 0) {
+    // Few rows (one chunk of pairs, one chunk of queries, the fused small-row kernels): the chain is bound by its ~94 dependent
+    // launches, not by the chip - work that depends on the queries only (their lin_sine encoding, cotr_model.py:34-36) or on the memory
+    // only (K / V of decoder layers 1-5, transformer.py:192-195) leaves the chain for a second stream.  Both streams join before
+    // cotr_forward returns: the caller sees one stream.
+    side = knob(KN_SIDE_STREAM);
+    if (h->dec.size() < 2) side &= ~2;
+    if (h->prof || h->keep_taps || B > knob(KN_ENCODE_CHUNK) || (long)B * Q > 8192) side = 0;
+    if (side) {
+      if (!h->side) {   // the handle's second stream and its events, created at first use
+        HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        for (hipEvent_t* ev : {&h->ev_fork, &h->ev_q, &h->ev_mem, &h->ev_kv}) HIPCHK(h, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+      }
+      if (side & 1) HIPCHK(h, hipEventRecord(h->ev_fork, s));   // the previous call on `s` may still read the query encodings
+    }
+  }
+  h->side_mode = side;
+  struct Reset { cotr_ctx* h; ~Reset() { h->side_mode = 0; } } reset{h};
+  int r = encode_impl(h, img, B, s, nullptr);
+  if (r || Q == 0) return r;
+  DecPlan d;
+  if ((r = dec_plan(h, B, Q, d))) return r;
+  if (side & 1) {
+    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    KCHK(h, launch_posenc(queries, d.qpos, B, Q, Q, h->side), "posenc");
+    HIPCHK(h, hipEventRecord(h->ev_q, h->side));
+  }
+  return decode_impl(h, queries, B, Q, out, s, d);
+}
+
 int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, int Q, float* out,
                  cotr_stream stream) {
   if (!h) return COTR_ERR_ARG;
   if (int r = decode_check(h, queries, B, Q, out)) return r;
-  int r = cotr_encode(h, img, B, stream);
-  if (r) return r;
-  if (Q == 0) return COTR_OK;
   DEVICE_SCOPE(h);
-  DecPlan d;
-  if ((r = dec_plan(h, B, Q, d))) return r;
-  return decode_impl(h, queries, B, Q, out, static_cast<hipStream_t>(stream), d);
+  return forward_impl(h, img, queries, B, Q, out, static_cast<hipStream_t>(stream));
 }
 
 // bytes of the three arenas a call of that size carves (each rounded up to 256 B): what cotr_set_workspace must be given

@@ -63,6 +63,8 @@ struct AttRowsParams {
   float* Y;              // [pairs*nq][256]
   const float* zeros;
   int nq;                // query rows per pair
+  int nb, tpp;           // pairs; 64-row tiles per pair
+  int by_xcd;            // 1: 1-D grid, all tiles of a pair on ONE XCD (see att_rows_kernel); 0: grid (tiles per pair, pairs)
   float* dbg;            // debug instantiation only (tools/micro/att_rows_probe.hip): stage dumps of workgroup 0
 };
 
@@ -376,8 +378,23 @@ __global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
-  const int pair = blockIdx.y;
-  const int q0 = blockIdx.x * AR_BM;                       // first query of this tile inside its pair
+  // Workgroup -> (pair, tile).  Workgroups are dealt to the 8 XCDs round-robin by their linear id and every XCD has its own L2, so
+  // with the plain (tile, pair) grid the 8 / 16 tiles of a pair land on 8 different XCDs and the pair's K_h / V_h (1 MB per layer) are
+  // pulled into all eight L2s (profiles/r5_final_mfma_util_and_traffic_b32_q1000.txt: 1.9 / 2.4 GB per forward).  by_xcd: a 1-D grid
+  // of 8 * tpp * ceil(nb / 8) workgroups; linear id b runs on XCD b & 7 and is the (b >> 3)-th workgroup there; XCD x owns pairs
+  // x, x + 8, x + 16, ... and walks them tile by tile, so the tiles of a pair that are resident together share one L2 (4 pairs x 1 MB
+  // per XCD at one workgroup per CU).  Placement is for speed only: any mapping gives the same results.
+  int pair, tile;
+  if (p.by_xcd) {
+    const int j = blockIdx.x >> 3;
+    pair = (blockIdx.x & 7) + 8 * (j / p.tpp);
+    tile = j % p.tpp;
+    if (pair >= p.nb) return;
+  } else {
+    pair = blockIdx.y;
+    tile = blockIdx.x;
+  }
+  const int q0 = tile * AR_BM;                             // first query of this tile inside its pair
   const size_t row0 = (size_t)pair * p.nq + q0;            // ... its global row
   const size_t key0 = (size_t)pair * AR_KEYS;
   const int nvalid = p.nq - q0 < AR_BM ? p.nq - q0 : AR_BM;
@@ -386,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p)
   do {                                                                                                                    \
     if constexpr (DBG) {                                                                                                  \
       if (t == 0) {                                                                                                       \
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(p.dbg + 131072) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)) * 2; \
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(p.dbg + 131072) + ((size_t)(pair * p.tpp + tile) * 8 + (slot)) * 2; \
         st[0] = __builtin_readcyclecounter();                                                                             \
         st[1] = wall_clock64();                                                                                           \
       }                                                                                                                   \
@@ -443,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p)
   __syncthreads();
 
   if constexpr (DBG) {   // [57344 .. 54096): wavefront 0's ring right after the prologue
-    if (blockIdx.x == 0 && blockIdx.y == 0 && wave == 0)
+    if (pair == 0 && tile == 0 && wave == 0)
       for (int i = lane; i < AR_RING; i += 64) p.dbg[57344 + i] = L.ring[i];
   }
   AR_STAMP(1);
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p)
   }
 
   if constexpr (DBG) {   // [0 .. 16384): q16 as [wave][hd][u][r][lane]
-    if (blockIdx.x == 0 && blockIdx.y == 0)
+    if (pair == 0 && tile == 0)
       for (int u = 0; u < 2; ++u)
         for (int r = 0; r < 16; ++r) p.dbg[((wave * 2 + u) * 16 + r) * 64 + lane] = q16[u][r];
   }
@@ -505,7 +522,7 @@ __global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p)
       for (int r = 0; r < 16; ++r) o[u][r] = 0.f;
     for (int kb2 = 0; kb2 < 8; ++kb2) {
       ar_kv_block<QP, 0, DBG, ABL>(p, L, wave, key0, it, false, kf, q16, o, m_run, l_run,
-                              DBG && kb2 == 0 && wave == 0 && blockIdx.x == 0 && blockIdx.y == 0);
+                              DBG && kb2 == 0 && wave == 0 && pair == 0 && tile == 0);
       ar_kv_block<QP, 1, DBG, ABL>(p, L, wave, key0, it, kb2 == 7, kf, q16, o, m_run, l_run);
     }
 #pragma unroll
@@ -514,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) onorm[u][r] = o[u][r] * inv;
       if constexpr (DBG) {   // [16384 .. 32768): onorm as [wave][u][r][lane]; [32768 .. ): l, m per [wave][u][lane]
-        if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (pair == 0 && tile == 0) {
           for (int r = 0; r < 16; ++r) p.dbg[16384 + ((wave * 2 + u) * 16 + r) * 64 + lane] = onorm[u][r];
           p.dbg[32768 + (wave * 2 + u) * 64 + lane] = l_run[u];
           p.dbg[32768 + 1024 + (wave * 2 + u) * 64 + lane] = m_run[u];
@@ -548,7 +565,7 @@ __global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p)
   }
 
   if constexpr (DBG) {   // [36864 .. ): yacc as [wave][mb][r][lane]
-    if (blockIdx.x == 0 && blockIdx.y == 0)
+    if (pair == 0 && tile == 0)
       for (int mb = 0; mb < 2; ++mb)
         for (int r = 0; r < 16; ++r) p.dbg[36864 + ((wave * 2 + mb) * 16 + r) * 64 + lane] = yacc[mb][r];
   }
@@ -635,7 +652,9 @@ int launch_att_rows(const float* q, int ldq, const float* x, const float* x2, co
   p.q = q; p.ldq = ldq; p.x = x; p.x2 = x2; p.wq = wq; p.bq = bq; p.qscale = qscale; p.k = k; p.v = v; p.ldkv = ldkv;
   p.wo = wo; p.bo = bo; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y; p.zeros = gemm_zero_buffer(); p.nq = nq;
   p.dbg = nullptr;
-  const dim3 grid((nq + AR_BM - 1) / AR_BM, nb);
+  p.nb = nb; p.tpp = (nq + AR_BM - 1) / AR_BM;
+  p.by_xcd = !(knob(KN_XCD_MAPPING) & 32);
+  const dim3 grid = p.by_xcd ? dim3(8 * p.tpp * ((nb + 7) / 8)) : dim3(p.tpp, nb);
   if (qp) hipLaunchKernelGGL(att_rows_kernel<true>, grid, dim3(64 * AR_NW), kAttRowsSmem, s, p);
   else hipLaunchKernelGGL(att_rows_kernel<false>, grid, dim3(64 * AR_NW), kAttRowsSmem, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;

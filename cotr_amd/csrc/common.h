@@ -1,11 +1,11 @@
 // Shared declarations of the gfx950 kernels behind libcotr_hip.so.
 #pragma once
-// The research library (libcotr_hip_exp.so, -DCOTR_EXPERIMENTAL: split-f16 products and the measured dead ends) is built from its OWN
-// copies of the translation units it changes (csrc/experimental/: api.hip, attention.hip, ffn.hip, gemm.hip, gemm_big.hip,
-// pointwise.hip and this header as common_exp.h) plus the untouched product ones, which find its declarations through this redirect -
-// the only mention of it in the product sources.
+// The research library (libcotr_hip_exp.so, -DCOTR_EXPERIMENTAL: split-f16 products and the measured dead ends) is built from PATCHED
+// copies of the translation units it changes (csrc/experimental/patches/*.patch applied to api.hip, attention.hip, ffn.hip, gemm.hip,
+// gemm_big.hip, pointwise.hip and to this header at build time -> csrc/experimental/gen/, cotr_amd/build.py) plus the untouched
+// product ones, which find its declarations through this redirect - the only mention of it in the product sources.
 #ifdef COTR_EXPERIMENTAL
-#include "experimental/common_exp.h"
+#include "experimental/gen/common_exp.h"
 #else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -62,7 +62,8 @@ enum KnobId {
   KN_DUAL_CONV,                  // downsample + conv1 of a stage's entry block as one launch (few pairs)
   KN_FUSED_STEM,                 // conv1 7x7 + bn + relu + maxpool in one launch
   KN_XCD_MAPPING,                // bits 0-1: GEMM tiles over XCDs (0 columns, 1 by operand size, 2 rows); bit 2: FFN chunks over XCDs;
-                                 // bit 3: attention heads over XCDs; bit 4: plain (not write-through) stores for the FFN partials
+                                 // bit 3: attention heads over XCDs; bit 4: plain (not write-through) stores for the FFN partials;
+                                 // bit 5: att_rows on the plain (tile, pair) grid instead of all tiles of a pair on one XCD
   KN_ATTENTION_FUSED_SPLITS,     // key splits of the fused attention: 0 (= 4), 4, 8, 48 / 84 (encoder / decoder separately)
   KN_CONV_PATCH,                 // layer3's 3x3 convolutions load their input patch once (config 31)
   KN_POS_TABLE_MIN_ROWS,         // token rows from which the encoder in-projections take pos . W^T from the tables
@@ -79,6 +80,9 @@ enum KnobId {
   KN_CONV23_MIN_PAIRS,           // layer1: conv2 (3x3) -> conv3 (1x1 expansion) + identity + ReLU as ONE launch (conv23.hip) from this many pairs per pass
   KN_CONV23M_MIN_PAIRS,          // layer2: conv2 (3x3) -> conv3 (1x1 expansion) + identity + ReLU as ONE launch (conv23m.hip) from this many pairs per pass
   KN_EXPAND_MIN_ROWS,            // layer1 block 0's downsample + conv1 as one launch (expand.hip) from this many rows
+  KN_ROWS_MIN_FILL,              // att_rows / ffn_rows: least fill (percent) of their 64-row tiles' last round over the CUs for the one-launch form to be taken
+  KN_SIDE_STREAM,                // cotr_forward, few rows: query-only / memory-only work on a second stream of the handle, beside the chain
+                                 // (bit 0: the query encoding beside the backbone; bit 1: the K/V projections of decoder layers 1-5 beside decoder layer 0)
   KN_COUNT
 };
 struct KnobSet {

@@ -368,7 +368,8 @@ int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd,
  *   fused_stem                 1 (default): conv1 + bn1 + relu + maxpool as one launch (stem_pool.hip)
  *   xcd_mapping                workgroup -> XCD mapping, a bit field (default 1): bits 0-1 GEMM / conv tiles (0 = column tiles over the
  *                              8 XCDs, 2 = row tiles, 1 = per launch by operand size); bit 2 fused FFN: hidden-unit chunks over XCDs;
- *                              bit 3 attention: heads over XCDs; bit 4 fused FFN: plain instead of write-through partial stores
+ *                              bit 3 attention: heads over XCDs; bit 4 fused FFN: plain instead of write-through partial stores;
+ *                              bit 5 att_rows: the plain (tile, pair) grid instead of all tiles of a pair on ONE XCD (round 6)
  *   attention_fused_splits     key splits of the fused attention: 0 (default = 4), 4, 8, 48 / 84 (encoder / decoder separately)
  *   conv_patch                 1 (default): layer3's 3x3 convolutions at few pairs load their input patch once
  *   pos_table_min_rows         token rows from which the encoder in-projections take pos . W^T from tables built at cotr_load_weights
@@ -382,6 +383,14 @@ int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd,
  *                              bit 1 (default) for the loaders
  *   bottleneck_max_pairs       layer1's bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass (default 4)
  *   train_attention_form       training attention backward: 0 (default) = by shape, 1-3 = force the first / second / one-pass form
+ *   att_rows_min_rows, ffn_rows_min_rows   query rows / rows from which the attention sub-layer / the FFN block run as ONE launch
+ *                              (att_rows.hip / ffn_rows.hip; default 8192), and
+ *   rows_min_fill              the least fill, in percent, of the last round of their 64-row tiles over the CUs (default 75)
+ *   conv23_min_pairs, conv23m_min_pairs, expand_min_rows   layer1 / layer2 conv2 -> conv3 and layer1.0's downsample + conv1 as one
+ *                              launch from this many pairs per pass / rows (defaults 5 / 16 / 65536)
+ *   side_stream                cotr_forward with few rows (B * Q <= 8192, one pass): bit 0 the query encoding, bit 1 the K/V projections of
+ *                              decoder layers 1-5 run on a second stream owned by the handle, beside the chain; joined before the
+ *                              call returns (default 0: measured, profiles/r6_ab_side_stream_*.txt)
  * libcotr_hip_exp.so (the experimental build, -DCOTR_EXPERIMENTAL) adds the knobs of the measured dead ends, all off by default:
  *   head_fusion_max_rows, ffn_preln, ffn_tail, coop_tail, coop_tail_spin, gemm_ln_min_rows, l2_warm  (cotr_amd/csrc/experimental/experimental.h)
  * and the RESEARCH path of docs/LABNOTES.md 3e (not a dead end; off by default, results as close to fp64 as the fp32 path but not its bits):

@@ -125,7 +125,7 @@ def test_knob_registry_round_trip_without_a_gpu():
     op-level entry points read.  count / name / get / set / reset need no device; the model object remembers knobs set before
     its handle exists.  The product library does not know the knobs of the measured dead ends."""
     k0 = _lib.knobs()
-    assert len(k0) == 23 and all(cur == dflt for cur, dflt in k0.values())
+    assert len(k0) == 25 and all(cur == dflt for cur, dflt in k0.values())
     assert k0['attention_fusion_max_rows'] == (1024, 1024) and k0['encode_chunk'] == (64, 64)
     for exp_only in ('head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail', 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs'):
         assert exp_only not in k0
@@ -138,7 +138,7 @@ def test_knob_registry_round_trip_without_a_gpu():
             _lib.set_knob('no_such_knob', 1)
         with pytest.raises(_lib.CotrHipError):
             _lib.set_knob('coop_tail', 1)
-        for name, bad in (('xcd_mapping', 3), ('xcd_mapping', 32), ('encode_chunk', 0), ('encode_chunk', 129), ('attention_splits', 3),
+        for name, bad in (('xcd_mapping', 3), ('xcd_mapping', 64), ('encode_chunk', 0), ('encode_chunk', 129), ('attention_splits', 3),
                           ('attention_fused_splits', 5), ('ks3', 2), ('attention_wide_occupancy', 4), ('ffn_fusion_max_rows', -1)):
             assert _lib.load_library().cotr_set_knob(None, name.encode(), bad) != 0, (name, bad)
         assert _lib.knobs() == k1                           # a refused value changes nothing
@@ -161,13 +161,31 @@ def test_experimental_library_has_the_dead_ends_and_their_knobs():
     assert _lib.load_library().cotr_is_experimental() == 0
     lib.cotr_knob_name.restype = ctypes.c_char_p
     names = [lib.cotr_knob_name(i).decode() for i in range(lib.cotr_knob_count())]
-    assert names[:23] == list(_lib.knobs()) and names[23:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
+    assert names[:25] == list(_lib.knobs()) and names[25:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
                                                                  'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs',
                                                                  'linear_rows_min_rows']
     for n, want in (('head_fusion_max_rows', 0), ('ffn_preln', 0), ('ffn_tail', 0), ('coop_tail', 0), ('gemm_ln_min_rows', 1 << 30),
                     ('l2_warm', 0), ('split_f16', 0), ('split_f16_min_pairs', 8)):
         cur, dflt = ctypes.c_int(), ctypes.c_int()
         assert lib.cotr_get_knob(None, n.encode(), ctypes.byref(cur), ctypes.byref(dflt)) == 0 and cur.value == dflt.value == want
+
+
+def test_research_sources_are_derived_from_the_current_product_sources(tmp_path):
+    """The research library has no forks of product files in the repository: csrc/experimental/patches/*.patch are applied to the CURRENT
+    product sources at build time (cotr_amd/build.py generate_forks).  Every patch must fit (a product edit that breaks one fails here,
+    before a stale research library can be compared against), the derived files keep every product line the patch does not touch, and no
+    full copy of a product translation unit is tracked under csrc/experimental/."""
+    import difflib
+    from cotr_amd import build as b
+    out = b.generate_forks(dest=str(tmp_path))
+    for name, (src, _) in b.GENERATED.items():
+        prod = open(os.path.join(b.CSRC, src)).read().splitlines()
+        gen = open(os.path.join(out, name)).read().splitlines()
+        sm = difflib.SequenceMatcher(None, prod, gen, autojunk=False)
+        kept = sum(m.size for m in sm.get_matching_blocks())
+        assert kept >= 0.9 * len(prod), f'{name}: only {kept} of {len(prod)} product lines survive the patch'
+    tracked = os.listdir(os.path.join(b.CSRC, 'experimental'))
+    assert not [f for f in b.GENERATED if f in tracked], 'a generated source is checked in next to its patch'
 
 
 def test_first_run_kit_applies_the_one_line_switch(tmp_path):

@@ -33,7 +33,7 @@ int main() {
   CK(hipMemcpy(lwd, lw.data(), 1024, hipMemcpyHostToDevice)); CK(hipMemcpy(lbd, lb.data(), 1024, hipMemcpyHostToDevice));
   AttRowsParams p = {};
   p.q = qd; p.ldq = ldq; p.k = kvd + 256; p.v = kvd + 512; p.ldkv = ldkv; p.wo = wod; p.bo = bod; p.ln_w = lwd; p.ln_b = lbd; p.Y = yd;
-  p.zeros = g_zero; p.nq = nq; p.dbg = dbg;
+  p.zeros = g_zero; p.nq = nq; p.dbg = dbg; p.nb = 1; p.tpp = 1; p.by_xcd = 0;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(att_rows_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttRowsSmem));
   hipLaunchKernelGGL((att_rows_kernel<false, true>), dim3(1, 1), dim3(512), kAttRowsSmem, 0, p);
   CK(hipDeviceSynchronize());
@@ -156,7 +156,7 @@ int main() {
     CK(hipMemcpy(wqb, h.data(), 65536 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(bqb, h.data() + 70000, 1024, hipMemcpyHostToDevice));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(att_rows_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttRowsSmem));
     AttRowsParams pb = p;
-    pb.q = qb; pb.ldq = 768; pb.k = kvb; pb.v = kvb + 256; pb.ldkv = 3072; pb.Y = yb; pb.nq = 512; pb.residual = x2b;
+    pb.q = qb; pb.ldq = 768; pb.k = kvb; pb.v = kvb + 256; pb.ldkv = 3072; pb.Y = yb; pb.nq = 512; pb.tpp = 8; pb.residual = x2b;
     pb.x = nullptr; pb.x2 = x2b; pb.wq = wqb; pb.bq = bqb; pb.qscale = 0.17677669f;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(att_rows_kernel<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttRowsSmem));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(att_rows_kernel<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAttRowsSmem));
