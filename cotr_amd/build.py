@@ -77,7 +77,7 @@ def generate_forks(dest=None, verbose=False):
         raise RuntimeError('patch(1) not found (needed to derive the research library\'s sources from the product sources)')
     for name, (src, pt) in GENERATED.items():
         out = os.path.join(dest, name)
-        r = subprocess.run([exe, '--no-backup-if-mismatch', '-s', '-F', '3', '-o', out, os.path.join(CSRC, src), os.path.join(PATCH_DIR, pt)],
+        r = subprocess.run([exe, '--no-backup-if-mismatch', '-s', '-F', '1', '-o', out, os.path.join(CSRC, src), os.path.join(PATCH_DIR, pt)],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0 or os.path.exists(out + '.rej'):
             raise RuntimeError(f'experimental/patches/{pt} no longer applies to csrc/{src} (edit the patch, or regenerate it with '

@@ -70,8 +70,8 @@ struct KnobDesc {
 };
 constexpr KnobDesc kKnobs[] = {
     {KN_ENCODE_CHUNK, "encode_chunk", 64, 1, ENC_CHUNK_MAX},
-    {KN_ATTENTION_FUSION_MAX_ROWS, "attention_fusion_max_rows", 1024, 0, INT_MAX},
-    {KN_FFN_FUSION_MAX_ROWS, "ffn_fusion_max_rows", 1024, 0, INT_MAX},
+    {KN_ATTENTION_FUSION_MAX_ROWS, "attention_fusion_max_rows", 4096, 0, INT_MAX},
+    {KN_FFN_FUSION_MAX_ROWS, "ffn_fusion_max_rows", 4096, 0, INT_MAX},
     {KN_KS3, "ks3", 1, 0, 1},
     {KN_DUAL_CONV, "dual_conv", 1, 0, 1},
     {KN_FUSED_STEM, "fused_stem", 1, 0, 1},
@@ -318,30 +318,49 @@ int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float
 }
 
 
+// The small-row fused kernels (attention + out-projection partials, fused FFN: attention.hip / ffn.hip, each followed by ln_reduce):
+// always up to 1024 rows - the one-pair regime they were built for; above, up to their knob (4096 rows), only where their grid of
+// 32-row tiles x 8 heads / x hidden chunks fills whole rounds of the 256 CUs to >= 90 % (2048 and 4096 encoder rows = 4 and 8 pairs,
+// 2000 and 4000 query rows: -2.5 ... -4 % per forward there; 1536 / 3072 rows = 1.5 rounds: +2 ... +4 %, left to the unfused
+// launches; profiles/r6_frac_by_batch_sweep.txt)
+bool fused_fill_ok(long wgs) {
+  const long rounds = (wgs + 255) / 256;
+  return wgs * 10 >= rounds * 256 * 9;
+}
+bool att_fused_applies(long rows) {
+  if (rows > knob(KN_ATTENTION_FUSION_MAX_ROWS)) return false;
+  return rows <= 1024 || fused_fill_ok((rows + 31) / 32 * 8);
+}
+bool ffn_fused_applies(long rows) {
+  if (rows > knob(KN_FFN_FUSION_MAX_ROWS)) return false;
+  return rows <= 1024 || fused_fill_ok((rows + 31) / 32 * ffn_fused_chunks((int)rows));
+}
+
 // The FFN block as ONE launch (ffn_rows.hip): from knob ffn_rows_min_rows rows on, where its 64-row tiles - one workgroup per CU,
-// 256 CUs - fill their last round of the chip to at least 3/4 (500 tiles of 32 x 1000 rows: 0.98; 313 tiles of 20 000 rows: 0.61 ->
-// the three launches, whose tiles are finer)
+// 256 CUs - fill their last round of the chip to at least knob rows_min_fill percent (75: 500 tiles of 32 x 1000 rows: 0.98; 313
+// tiles of 20 000 rows: 0.61 -> the three launches, whose tiles are finer)
 bool ffn_rows_applies(int M) {
-  if (M < knob(KN_FFN_ROWS_MIN_ROWS) || M <= knob(KN_FFN_FUSION_MAX_ROWS)) return false;
+  if (M < knob(KN_FFN_ROWS_MIN_ROWS) || ffn_fused_applies(M)) return false;
   const long tiles = (M + 63) / 64, rounds = (tiles + 255) / 256;
   return tiles * 100 >= rounds * 256 * knob(KN_ROWS_MIN_FILL);
 }
 
 // The attention sub-layer as ONE launch (att_rows.hip): from knob att_rows_min_rows query rows on, where its 64-query tiles (per
-// pair) fill the last round of the 256 CUs to at least 3/4 and a pair's last tile is not mostly padding
+// pair) fill the last round of the 256 CUs to at least rows_min_fill percent and a pair's last tile is not mostly padding
 bool att_rows_applies(int nb, int nq) {
   const long R = (long)nb * nq;
-  if (R < knob(KN_ATT_ROWS_MIN_ROWS) || R <= knob(KN_ATTENTION_FUSION_MAX_ROWS)) return false;
+  if (R < knob(KN_ATT_ROWS_MIN_ROWS)) return false;
   const long tpp = (nq + 63) / 64, tiles = tpp * nb, rounds = (tiles + 255) / 256;
   return tiles * 100 >= rounds * 256 * knob(KN_ROWS_MIN_FILL) && (long)nq * 8 >= tpp * 64 * 7;
 }
 
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
-// Up to knob ffn_fusion_max_rows rows: ONE fused launch that keeps the hidden activations on the CU and writes per-chunk
+// Where ffn_fused_applies: ONE fused launch that keeps the hidden activations on the CU and writes per-chunk
 // partial outputs + ln_reduce (sum, bias, residual, norm [, a second norm: decoder.norm after the last layer]); above: linear1,
-// linear2 (+residual), layernorm.  `hid` holds max(M*1024, chunks*M*256) floats, `tmp` M*256.  post_w only with M <= the threshold.
+// linear2 (+residual), layernorm.  `hid` holds hid_cap >= M*1024 floats (the fused form needs chunks*M*256), `tmp` M*256.
+// post_w only where the caller knows the fused form (or ffn_rows) applies.
 int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, const float* l2w, const float* l2b,
-              const float* nw, const float* nb, float* hid, float* tmp, float* y, int M, hipStream_t s,
+              const float* nw, const float* nb, float* hid, size_t hid_cap, float* tmp, float* y, int M, hipStream_t s,
               const float* post_w = nullptr, const float* post_b = nullptr) {
   if (ffn_rows_applies(M) && y != x) {
     // many rows: the whole block - linear1, ReLU, linear2, bias, residual, norm [, decoder.norm] - in one launch (ffn_rows.hip)
@@ -349,8 +368,9 @@ int ffn_block(cotr_ctx* h, const float* x, const float* l1w, const float* l1b, c
     if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_rows %d rows", M); prof_mark(h, nm, s, 2); }
     return COTR_OK;
   }
-  if (post_w != nullptr || M <= knob(KN_FFN_FUSION_MAX_ROWS)) {
+  if (post_w != nullptr || (ffn_fused_applies(M) && (size_t)ffn_fused_chunks(M) * M * D <= hid_cap)) {
     const int nch = ffn_fused_chunks(M);
+    if ((size_t)nch * M * D > hid_cap) { h->err = "ffn_block: partial-output scratch too small"; return COTR_ERR_STATE; }
     KCHK(h, launch_ffn_fused(x, l1w, l1b, l2w, hid, M, nch, s), "ffn_fused");
     if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "ffn_fused %d rows x%d", M, nch); prof_mark(h, nm, s, 2); }
     KCHK(h, launch_ln_reduce_post(hid, nch, l2b, x, nw, nb, post_w, post_b, y, M, s), "ln_reduce");
@@ -853,7 +873,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
           return r;
       } else if ((r = linear(h, xin, h->pos, TOK, 3 * D, 2 * D, e.in_w, e.in_b, nullptr, 0, QSCALE, D, t_qkv, M, 3 * D, D, s))) return r;
       float* y = (li + 1 == h->enc.size()) ? mem_c : (xin == t_alt ? t_pre2 : t_alt);
-      bool fused = n_part != 0 && M <= knob(KN_ATTENTION_FUSION_MAX_ROWS) && M <= knob(KN_FFN_FUSION_MAX_ROWS);
+      bool fused = n_part != 0 && att_fused_applies(M);   // (the FFN block decides for itself: ffn_block)
       if (fused) {
         // few rows: out_proj inside the attention kernel (8 per-head partial outputs), summed + bias + residual + norm1 by ln_reduce
         KCHK(h, launch_attention_fused(t_qkv, 3 * D, nullptr, nullptr, nullptr, nullptr, 0.f, t_qkv + D, t_qkv + 2 * D, 3 * D,
@@ -872,7 +892,8 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
         if ((r = linear(h, t_ao, nullptr, 0, 1, 0, e.out_w, e.out_b, xin, 0, 1.f, 0, t_tmp, M, D, D, s))) return r;
         if ((r = layernorm(h, t_tmp, e.n1w, e.n1b, t_x1, M, s))) return r;
       }
-      if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, fused ? t_tmp : t_ao, y, M, s))) return r;
+      if ((r = ffn_block(h, t_x1, e.l1w, e.l1b, e.l2w, e.l2b, e.n2w, e.n2b, t_hid, (size_t)TOK * 4 * FFN * Bc_max, fused ? t_tmp : t_ao, y, M, s)))
+        return r;
       xin = y;
     }
     prof_mark(h, "encoder", s);
@@ -921,7 +942,7 @@ namespace {
 
 struct DecPlan {
   int q_chunk = 0, nb_max = 0;
-  size_t Rmax = 0;
+  size_t Rmax = 0, hid_per_row = 0;
   float *qpos = nullptr, *tgt = nullptr, *q = nullptr, *ao = nullptr, *pre2 = nullptr, *t2 = nullptr, *pre3 = nullptr,
         *hid = nullptr, *part = nullptr;
   bool single_chunk = false;
@@ -935,6 +956,7 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
   d.single_chunk = d.nb_max >= B && d.q_chunk >= Q;
   const size_t hid_per_row = d.Rmax <= (size_t)knob(KN_FFN_FUSION_MAX_ROWS) ? 4 * FFN : FFN;  // fused FFN: up to 16 partial outputs
   const size_t part_per_row = d.Rmax <= (size_t)knob(KN_ATTENTION_FUSION_MAX_ROWS) ? 8 * D : 0;  // per-head partials of attention + out_proj
+  d.hid_per_row = hid_per_row;
   int r = ensure(h, h->dec_scr, d.Rmax * (7 * D + hid_per_row + part_per_row));
   if (r) return r;
   float* p = h->dec_scr.ptr;
@@ -975,7 +997,8 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   const int KVLD = L * 2 * D;
   const int R = nb * nq;
   int r;
-  bool fused = d.part != nullptr && R <= knob(KN_ATTENTION_FUSION_MAX_ROWS) && R <= knob(KN_FFN_FUSION_MAX_ROWS);
+  const size_t hid_cap = d0.Rmax * d0.hid_per_row;
+  bool fused = d.part != nullptr && att_fused_applies(R) && ffn_fused_applies(R) && (size_t)ffn_fused_chunks(R) * R * D <= hid_cap;
   bool hs_normed = false;
   const bool rows = !fused && att_rows_applies(nb, nq);   // many rows: q projection, attention, out_proj, residual, norm2 in one launch
   if ((r = dec_prologue(h, d, qsrc, nb, nq, Q, s, fused || rows))) return r;
@@ -995,7 +1018,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       KCHK(h, launch_ln_reduce(d.part, 8, w.out_b, tgt_in, w.n2w, w.n2b, d.t2, R, s), "ln_reduce");
       prof_mark(h, "ln_reduce heads", s, 2);
       const bool post = li + 1 == L;
-      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
+      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, hid_cap, d.pre3, post ? d.pre2 : d.tgt, R, s,
                          post ? h->dn_w : nullptr, post ? h->dn_b : nullptr))) return r;
       hs_normed = post;
     } else {
@@ -1013,7 +1036,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
       }
       // (many rows, last layer: decoder.norm rides in the one-launch FFN block's epilogue; pre2 = the normed 'hs')
       const bool post = li + 1 == L && ffn_rows_applies(R);
-      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, d.pre3, post ? d.pre2 : d.tgt, R, s,
+      if ((r = ffn_block(h, d.t2, w.l1w, w.l1b, w.l2w, w.l2b, w.n3w, w.n3b, d.hid, hid_cap, d.pre3, post ? d.pre2 : d.tgt, R, s,
                          post ? h->dn_w : nullptr, post ? h->dn_b : nullptr))) return r;
       hs_normed = post;
     }

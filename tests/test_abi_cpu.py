@@ -126,14 +126,14 @@ def test_knob_registry_round_trip_without_a_gpu():
     its handle exists.  The product library does not know the knobs of the measured dead ends."""
     k0 = _lib.knobs()
     assert len(k0) == 25 and all(cur == dflt for cur, dflt in k0.values())
-    assert k0['attention_fusion_max_rows'] == (1024, 1024) and k0['encode_chunk'] == (64, 64)
+    assert k0['attention_fusion_max_rows'] == (4096, 4096) and k0['encode_chunk'] == (64, 64)
     for exp_only in ('head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail', 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs'):
         assert exp_only not in k0
     try:
         _lib.set_knob('conv1x1_dense', 0)
         _lib.set_knob('ffn_fusion_max_rows', 0)
         k1 = _lib.knobs()
-        assert k1['conv1x1_dense'] == (0, 1) and k1['ffn_fusion_max_rows'] == (0, 1024)
+        assert k1['conv1x1_dense'] == (0, 1) and k1['ffn_fusion_max_rows'] == (0, 4096)
         with pytest.raises(_lib.CotrHipError):
             _lib.set_knob('no_such_knob', 1)
         with pytest.raises(_lib.CotrHipError):

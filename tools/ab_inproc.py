@@ -23,7 +23,7 @@ ap.add_argument('settings', nargs='*')
 ap.add_argument('--rounds', type=int, default=5)
 ap.add_argument('--iters', type=int, default=0)
 ap.add_argument('--check', action='store_true')
-a = ap.parse_args()
+a = ap.parse_intermixed_args()
 m = build_model(cotr_amd.default_args()).cuda().eval()
 m.load_state_dict(synth_state_dict(0))
 img, qs = synth_inputs(a.B, a.Q, seed=1)

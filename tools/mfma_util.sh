@@ -1,15 +1,16 @@
 #!/bin/bash
 # Per kernel of one forward at (B, Q): duration, MFMA pipe utilisation, L2<->fabric bytes and GB/s.  Separate rocprofv3 passes
-# (kernel trace + one counter group each).  usage: tools/mfma_util.sh B Q out.txt
+# (kernel trace + one counter group each).  usage: tools/mfma_util.sh B Q out.txt [KNOB=INT ...]
 B=${1:-32}; Q=${2:-1000}; out=${3:-gpurun_out/mfma_util.txt}
 export TMPDIR=/tmp
 root=$PWD
+knobs="${@:4}"
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
   d=$root/gpurun_out/mfma_util_$i
   rm -rf $d; mkdir -p $d
   cd /tmp
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o u -- python $root/tools/run_forwards.py $B $Q 4 > $d/run.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $d -o u -- python $root/tools/run_forwards.py $B $Q 4 $knobs > $d/run.log 2>&1
   cd $root
   i=$((i+1))
 done
