@@ -380,12 +380,14 @@ __global__ __launch_bounds__(512, 2) void att_rows_kernel(const AttRowsParams p)
   const int l31 = lane & 31, hh = lane >> 5;
   // Workgroup -> (pair, tile).  Workgroups are dealt to the 8 XCDs round-robin by their linear id and every XCD has its own L2, so
   // with the plain (tile, pair) grid the 8 / 16 tiles of a pair land on 8 different XCDs and the pair's K_h / V_h (1 MB per layer) are
-  // pulled into all eight L2s (profiles/r5_final_mfma_util_and_traffic_b32_q1000.txt: 1.9 / 2.4 GB per forward).  by_xcd (knob
-  // xcd_mapping bit 5, pairs a multiple of 8): a 1-D grid; linear id b runs on XCD b & 7 and is the (b >> 3)-th workgroup there; XCD x
-  // owns pairs x, x + 8, x + 16, ... and walks them tile by tile, so the tiles of a pair that are resident together share one L2.
-  // Measured in round 6 (profiles/r6_ab_att_rows_xcd_*.txt): the forward's time does not move (10.11 vs 10.13 ms at 32 pairs x 1000
-  // queries - the kernel is bound by its softmax VALU + matrix pipe, not by the fabric), so the plain grid stays the default.
-  // Placement is for speed only: any mapping gives the same results.
+  // pulled into all eight L2s (profiles/r5_final_mfma_util_and_traffic_b32_q1000.txt: 1.9 / 2.4 GB per forward).  by_xcd (pairs a
+  // multiple of 8; knob xcd_mapping bit 5 turns it off): a 1-D grid; linear id b runs on XCD b & 7 and is the (b >> 3)-th workgroup
+  // there; XCD x owns pairs x, x + 8, x + 16, ... and walks them tile by tile, so the tiles of a pair that are resident together
+  // share one L2.  Measured (profiles/r6_mfma_util_b32_q1000_{plain_grid,pair_per_xcd}.txt, 32 pairs x 1000 queries): L2 <-> fabric
+  // bytes of the encoder form 1927 -> 518 MB, of the decoder form 2385 -> 955 MB per forward (the whole forward 15.6 -> 12.8 GB);
+  // time: encoder form 641 -> 622 us (matrix pipes 0.644 -> 0.664 busy), decoder form unchanged (1394 -> 1399 us) - the kernel is
+  // bound by its softmax VALU + matrix pipe, not by the fabric.  Other pair counts keep the plain grid (a padded 1-D grid leaves
+  // XCDs idle: 4 pairs on 4 of the 8 XCDs ran the dense pass 4 x slower).  Placement is for speed only: any mapping gives the same results.
   int pair, tile;
   if (p.by_xcd) {
     const int j = blockIdx.x >> 3;
@@ -655,7 +657,7 @@ int launch_att_rows(const float* q, int ldq, const float* x, const float* x2, co
   p.wo = wo; p.bo = bo; p.residual = residual; p.ln_w = ln_w; p.ln_b = ln_b; p.Y = Y; p.zeros = gemm_zero_buffer(); p.nq = nq;
   p.dbg = nullptr;
   p.nb = nb; p.tpp = (nq + AR_BM - 1) / AR_BM;
-  p.by_xcd = (knob(KN_XCD_MAPPING) & 32) != 0 && nb % 8 == 0;
+  p.by_xcd = (knob(KN_XCD_MAPPING) & 32) == 0 && nb % 8 == 0;
   const dim3 grid = p.by_xcd ? dim3(p.tpp * nb) : dim3(p.tpp, nb);
   if (qp) hipLaunchKernelGGL(att_rows_kernel<true>, grid, dim3(64 * AR_NW), kAttRowsSmem, s, p);
   else hipLaunchKernelGGL(att_rows_kernel<false>, grid, dim3(64 * AR_NW), kAttRowsSmem, s, p);

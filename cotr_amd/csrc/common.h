@@ -63,7 +63,7 @@ enum KnobId {
   KN_FUSED_STEM,                 // conv1 7x7 + bn + relu + maxpool in one launch
   KN_XCD_MAPPING,                // bits 0-1: GEMM tiles over XCDs (0 columns, 1 by operand size, 2 rows); bit 2: FFN chunks over XCDs;
                                  // bit 3: attention heads over XCDs; bit 4: plain (not write-through) stores for the FFN partials;
-                                 // bit 5: att_rows with all tiles of a pair on ONE XCD (pairs a multiple of 8) instead of the plain (tile, pair) grid
+                                 // bit 5: att_rows on the plain (tile, pair) grid also where the pairs are a multiple of 8 (default: all tiles of a pair on ONE XCD there)
   KN_ATTENTION_FUSED_SPLITS,     // key splits of the fused attention: 0 (= 4), 4, 8, 48 / 84 (encoder / decoder separately)
   KN_CONV_PATCH,                 // layer3's 3x3 convolutions load their input patch once (config 31)
   KN_POS_TABLE_MIN_ROWS,         // token rows from which the encoder in-projections take pos . W^T from the tables

@@ -61,7 +61,8 @@ class _DeviceDensePost:
         self.lib = _lib.load_library()
         self.device = device
 
-    def __call__(self, pred, pairs, shape_a, shape_b):
+    def device_maps(self, pred, pairs, shape_a, shape_b):
+        """-> (corr_a [Ha,Wa,2], con_a [Ha,Wa], corr_b, con_b) float32 tensors ON THE DEVICE (nothing is copied back)."""
         lib, dev = self.lib, self.device
         n = len(pairs)
         pred = pred.detach().to(dev, torch.float32).contiguous()
@@ -75,17 +76,37 @@ class _DeviceDensePost:
             rc = lib.cotr_dense_cycle(pred.data_ptr(), n, aff_d.data_ptr(), maps.data_ptr(), stream)
             if rc != 0:
                 raise self._lib.CotrHipError(f'cotr_dense_cycle failed (code {rc})')
+            boxes = torch.tensor([list(p[0]) + list(p[1]) for p in pairs], dtype=torch.int32).to(dev)   # one upload for both sides
             for side, shape in ((0, shape_a), (1, shape_b)):
-                boxes = torch.tensor([list(p[side]) for p in pairs], dtype=torch.int32).to(dev)
+                bx = boxes[:, 3 * side:3 * side + 3].contiguous()
                 flow = torch.empty((shape[0], shape[1], 2), dtype=torch.float32, device=dev)
                 conf = torch.empty((shape[0], shape[1]), dtype=torch.float32, device=dev)
-                rc = lib.cotr_dense_merge(maps.data_ptr(), boxes.data_ptr(), n, side, shape[0], shape[1], flow.data_ptr(),
+                rc = lib.cotr_dense_merge(maps.data_ptr(), bx.data_ptr(), n, side, shape[0], shape[1], flow.data_ptr(),
                                           conf.data_ptr(), stream)
                 if rc != 0:
                     raise self._lib.CotrHipError(f'cotr_dense_merge failed (code {rc})')
                 out += [flow, conf]
-        # the reference's maps are float64 numpy arrays holding float32 values
-        return tuple(t.cpu().numpy().astype(np.float64) for t in out)
+        return tuple(out)
+
+    def to_host(self, tensors):
+        """Device float32 maps -> float64 numpy arrays (the reference's maps are float64 arrays holding float32 values): widened on the
+        device, copied through ONE pinned staging buffer with ONE synchronisation (pageable D2H of the four 5-10 MB maps + four host
+        astype passes were a third of the dense pass at engine level)."""
+        wide = [t.double().contiguous() for t in tensors]
+        total = sum(w.numel() for w in wide)
+        stage = torch.empty(total, dtype=torch.float64, pin_memory=True)
+        off = 0
+        views = []
+        for w in wide:
+            v = stage[off:off + w.numel()].view(w.shape)
+            v.copy_(w, non_blocking=True)
+            views.append(v)
+            off += w.numel()
+        torch.cuda.current_stream(self.device).synchronize()
+        return tuple(v.numpy().copy() for v in views)
+
+    def __call__(self, pred, pairs, shape_a, shape_b):
+        return self.to_host(self.device_maps(pred, pairs, shape_a, shape_b))
 
     def resize(self, arr, shape):
         """``utils.float_image_resize`` (utils.py:69-83) of a [H,W] or [H,W,C] map to ``shape`` = (H', W'): float32 result,
@@ -397,6 +418,22 @@ class ZoomEngine:
         return RefineResult(loc_from, cur.copy(), good, hist, calls0, self.total_tasks - crops0, steps, last_iters)
 
     # ------------------------------------------------------------------------------------------------
+    _grids = {}
+
+    @classmethod
+    def _query_grid(cls, device):
+        """The dense pass's constant queries (inference_helper.py:116-120): (j / 512, i / 256) for the 256 x 512 pixels of the network
+        frame, [1, 131072, 2] float32, built ON THE DEVICE once per device (every value is k / 2^n: exact in float32, the same bits as
+        the reference's float64 grid cast with .float()); the per-call numpy meshgrid + 1 MB upload is gone."""
+        key = str(device)
+        g = cls._grids.get(key)
+        if g is None:
+            jj = torch.arange(MAX_SIZE * 2, dtype=torch.float32, device=device) / (MAX_SIZE * 2)
+            ii = torch.arange(MAX_SIZE, dtype=torch.float32, device=device) / MAX_SIZE
+            g = torch.stack([jj[None, :].expand(MAX_SIZE, -1), ii[:, None].expand(-1, MAX_SIZE * 2)], dim=-1).reshape(1, -1, 2).contiguous()
+            cls._grids[key] = g
+        return g
+
     @staticmethod
     def _square_patches(img):
         """``to_square_patches`` (inference_helper.py:41-58) as boxes: [(x, y, size)], one or two per image."""
@@ -474,14 +511,28 @@ class ZoomEngine:
         cropper = self.make_cropper(img_a, img_b, device)
         buf = torch.empty((len(pairs), 3, 256, 512), dtype=torch.float32, device=device)
         img = cropper(boxes, buf)
-        jj, ii = np.meshgrid(np.arange(MAX_SIZE * 2), np.arange(MAX_SIZE))
-        q_grid = np.stack([jj / (MAX_SIZE * 2), ii / MAX_SIZE], axis=-1)               # [256,512,2] float64
-        q = torch.from_numpy(q_grid.reshape(1, -1, 2)).float().to(device).expand(len(pairs), -1, -1).contiguous()
+        q = self._query_grid(device).expand(len(pairs), -1, -1).contiguous()
         # (cotr_amd.dist.sharded_zoom_engine routes this one call through a PairShardedModel: pairs / queries over the ranks)
         pred = getattr(self, '_dense_model', self.model)(img, q)['pred_corrs']
         self.total_tasks += len(pairs)
-        corr_a, con_a, corr_b, con_b = self.make_dense_post(device)(pred, pairs, img_a.shape, img_b.shape)
+        post = self.make_dense_post(device)
         res_a = res_b = None
+        if hasattr(post, 'device_maps') and hasattr(cropper, 'a'):
+            # device post-processing: the merged maps stay on the device until here; the visualisation warps (:178-181) read them and
+            # the cropper's device copies of the images in place; everything the caller gets comes back in one pinned copy
+            maps = post.device_maps(pred, pairs, img_a.shape, img_b.shape)
+            outs = list(maps)
+            if resample:
+                def warp_d(img_dev, corr_dev):
+                    t = img_dev.permute(2, 0, 1)[None].float()
+                    return torch.nn.functional.grid_sample(t, corr_dev[None], align_corners=False)[0].permute(1, 2, 0)
+                outs += [warp_d(cropper.b, maps[0]), warp_d(cropper.a, maps[2])]
+            host = post.to_host(outs)
+            corr_a, con_a, corr_b, con_b = host[:4]
+            if resample:
+                res_a, res_b = (np.ascontiguousarray(r, dtype=np.float32) for r in host[4:])
+            return corr_a, con_a, res_a, corr_b, con_b, res_b
+        corr_a, con_a, corr_b, con_b = post(pred, pairs, img_a.shape, img_b.shape)
         if resample:                                                                    # :178-181
             def warp(img_src, corr):
                 t = torch.from_numpy(np.transpose(img_src, (2, 0, 1)))[None].float().to(device)

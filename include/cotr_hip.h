@@ -369,7 +369,8 @@ int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd,
  *   xcd_mapping                workgroup -> XCD mapping, a bit field (default 1): bits 0-1 GEMM / conv tiles (0 = column tiles over the
  *                              8 XCDs, 2 = row tiles, 1 = per launch by operand size); bit 2 fused FFN: hidden-unit chunks over XCDs;
  *                              bit 3 attention: heads over XCDs; bit 4 fused FFN: plain instead of write-through partial stores;
- *                              bit 5 att_rows: all tiles of a pair on ONE XCD (pairs a multiple of 8; round 6: fabric traffic down, time unchanged)
+ *                              bit 5 att_rows: the plain (tile, pair) grid also where the pairs are a multiple of 8 (default there: all tiles of a
+ *                              pair on ONE XCD - round 6: fabric traffic of the kernel / 2.5-3.7, its time -0 ... -3 %)
  *   attention_fused_splits     key splits of the fused attention: 0 (default = 4), 4, 8, 48 / 84 (encoder / decoder separately)
  *   conv_patch                 1 (default): layer3's 3x3 convolutions at few pairs load their input patch once
  *   pos_table_min_rows         token rows from which the encoder in-projections take pos . W^T from tables built at cotr_load_weights

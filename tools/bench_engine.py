@@ -46,12 +46,17 @@ print(f'reference loop shape (32 per call, PIL crops on the host, same HIP model
 # dense initial pass (cotr_flow): 4 patch pairs x 131072 queries in one model call + device post-processing
 eng = ZoomEngine(m)
 eng.flow(img_a[:300, :420], img_b[:350, :330])                   # warm-up (also the big-Q decode scratch)
+eng.flow(img_a, img_b)                                           # ... and torch's allocator for this pair's map sizes
 for tag, (ia, ib) in (('2x2 patch pairs (cathedral sizes)', (img_a, img_b)),):
     torch.cuda.synchronize()
     t = time.perf_counter()
     out = eng.flow(ia, ib)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t
+    t = time.perf_counter()
+    eng.flow(ia, ib, resample=False)
+    torch.cuda.synchronize()
+    dt_nr = time.perf_counter() - t
     pa, pb = eng._square_patches(ia), eng._square_patches(ib)
     boxes = np.array([[i[0], i[1], i[2], j[0], j[1], j[2]] for i in pa for j in pb], dtype=np.int32)
     crop = eng.make_cropper(ia, ib, torch.device('cuda'))
@@ -64,7 +69,7 @@ for tag, (ia, ib) in (('2x2 patch pairs (cathedral sizes)', (img_a, img_b)),):
     m(imgs, q)
     torch.cuda.synchronize()
     dm = time.perf_counter() - t
-    print(f'dense pass, {tag}: {dt:.3f} s total, of which the model call ({len(boxes)} x 131072 queries) {dm:.3f} s = '
+    print(f'dense pass, {tag}: {dt:.3f} s total ({dt_nr:.3f} s without the two visualisation warps, as gen_tasks calls it), of which the model call ({len(boxes)} x 131072 queries) {dm:.3f} s = '
           f'{len(boxes) * 131072 / dm:.0f} query-corr/s; the rest: crop launch, query grid upload, cotr_dense_cycle + '
           f'2 x cotr_dense_merge, D2H of the merged maps, the two visualisation warps', flush=True)
 # dense pass + zoom, 10 k forced queries, converge_iters = 3, on a 512x512 synthetic pair
