@@ -467,9 +467,9 @@ def run_train(args, dev, world, rank):
             **ident,
             'roofline': {'bound': 'mfma', 'achieved': world * flop_step / ms / 1e9, 'peak': 157.3 * world, 'unit': 'TFLOP/s', 'frac': flop_step / ms / 1e9 / 157.3,
                          'flop_per_step_per_gpu': flop_step,
-                         'flop_note': ('forward %.0f GFLOP (backbone once, input_proj / encoder / decoder K/V on 2 x 16 pairs, two decodes of 16 x 200 queries) + backward %.0f GFLOP '
+                         'flop_note': ('forward %.0f GFLOP (backbone once, input_proj / encoder / decoder K/V on 2 x %d pairs, two decodes of %d x %d queries) + backward %.0f GFLOP '
                                        '(dX and dW = 2 x the forward FLOP of every trainable contraction%s); traffic not measured for this workload'
-                                       % (fwd / G, bwd / G, ', layer2 / layer3 of the backbone included' if args.stage == 2 else '; backbone frozen')),
+                                       % (fwd / G, pairs, pairs, nq, bwd / G, ', layer2 / layer3 of the backbone included' if args.stage == 2 else '; backbone frozen')),
                          'traffic': None},
             'metric': 'training pairs/sec (COTRTrainer.train_batch step, cycle + bidirectional)', 'value': world * pairs * args.steps / elapsed,
             'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

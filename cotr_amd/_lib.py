@@ -113,6 +113,7 @@ _PROTOS = {
     'cotr_knob_name': (ctypes.c_char_p, [ctypes.c_int]),
     'cotr_get_knob': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     'cotr_set_knob': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]),
+    'cotr_check_knob': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'cotr_reset_knobs': (ctypes.c_int, [ctypes.c_void_p]),
     'cotr_is_experimental': (ctypes.c_int, []),
     'cotr_bench_linear': (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int,
@@ -229,13 +230,10 @@ def set_knob(name, value, handle=None):
 
 
 def validate_knob(name, value):
-    """Raise CotrHipError unless the library's registry has the knob and accepts the value (tried on the process-wide set, which is put
-    back): what a model does with a knob set before its handle exists."""
-    lib = load_library()
-    cur, dflt = ctypes.c_int(), ctypes.c_int()
-    check(lib.cotr_get_knob(None, name.encode(), ctypes.byref(cur), ctypes.byref(dflt)), None, f'cotr_get_knob({name})')
-    check(lib.cotr_set_knob(None, name.encode(), int(value)), None, f'cotr_set_knob({name}, {value})')
-    check(lib.cotr_set_knob(None, name.encode(), cur.value), None, f'cotr_set_knob({name}, {cur.value})')
+    """Raise CotrHipError unless the library's registry has the knob and accepts the value (cotr_check_knob: no knob set is touched):
+    what a model does with a knob set before its handle exists."""
+    if load_library().cotr_check_knob(name.encode(), int(value)) != 0:
+        raise CotrHipError(f'cotr_set_knob({name}, {value}): no such knob in this library, or the value is outside its range')
 
 
 def reset_knobs(handle=None):

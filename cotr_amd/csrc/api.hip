@@ -324,8 +324,8 @@ int layernorm(cotr_ctx* h, const float* x, const float* w, const float* b, float
 // 2000 and 4000 query rows: -2.5 ... -4 % per forward there; 1536 / 3072 rows = 1.5 rounds: +2 ... +4 %, left to the unfused
 // launches; profiles/r6_frac_by_batch_sweep.txt)
 bool fused_fill_ok(long wgs) {
-  const long rounds = (wgs + 255) / 256;
-  return wgs * 10 >= rounds * 256 * 9;
+  const long cus = cotr_num_cus(), rounds = (wgs + cus - 1) / cus;
+  return wgs * 10 >= rounds * cus * 9;
 }
 bool att_fused_applies(long rows) {
   if (rows > knob(KN_ATTENTION_FUSION_MAX_ROWS)) return false;
@@ -341,8 +341,8 @@ bool ffn_fused_applies(long rows) {
 // tiles of 20 000 rows: 0.61 -> the three launches, whose tiles are finer)
 bool ffn_rows_applies(int M) {
   if (M < knob(KN_FFN_ROWS_MIN_ROWS) || ffn_fused_applies(M)) return false;
-  const long tiles = (M + 63) / 64, rounds = (tiles + 255) / 256;
-  return tiles * 100 >= rounds * 256 * knob(KN_ROWS_MIN_FILL);
+  const long cus = cotr_num_cus(), tiles = (M + 63) / 64, rounds = (tiles + cus - 1) / cus;
+  return tiles * 100 >= rounds * cus * knob(KN_ROWS_MIN_FILL);
 }
 
 // The attention sub-layer as ONE launch (att_rows.hip): from knob att_rows_min_rows query rows on, where its 64-query tiles (per
@@ -350,8 +350,8 @@ bool ffn_rows_applies(int M) {
 bool att_rows_applies(int nb, int nq) {
   const long R = (long)nb * nq;
   if (R < knob(KN_ATT_ROWS_MIN_ROWS)) return false;
-  const long tpp = (nq + 63) / 64, tiles = tpp * nb, rounds = (tiles + 255) / 256;
-  return tiles * 100 >= rounds * 256 * knob(KN_ROWS_MIN_FILL) && (long)nq * 8 >= tpp * 64 * 7;
+  const long cus = cotr_num_cus(), tpp = (nq + 63) / 64, tiles = tpp * nb, rounds = (tiles + cus - 1) / cus;
+  return tiles * 100 >= rounds * cus * knob(KN_ROWS_MIN_FILL) && (long)nq * 8 >= tpp * 64 * 7;
 }
 
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
@@ -1443,6 +1443,12 @@ int cotr_set_knob(cotr_handle h, const char* name, int value) {
   }
   (h ? h->knobs : g_process_knobs).v[i] = value;
   return COTR_OK;
+}
+// would cotr_set_knob accept this?  Changes nothing (a binding that remembers knobs before its handle exists asks this instead of trying
+// the value on the process-wide set, which a concurrent handle-less call of another thread would see)
+int cotr_check_knob(const char* name, int value) {
+  const int i = knob_index(name);
+  return (i >= 0 && knob_value_ok(i, value)) ? COTR_OK : COTR_ERR_ARG;
 }
 int cotr_reset_knobs(cotr_handle h) {
   (h ? h->knobs : g_process_knobs) = default_knobs();

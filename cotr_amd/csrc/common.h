@@ -41,6 +41,19 @@ static inline int cotr_current_device() {
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= COTR_MAX_DEVICES) d = 0;
   return d;
 }
+// Compute units of the current device, asked once per device.  The dispatch rules that count "rounds of the chip" (api.hip) and the
+// first-round stagger of conv23 / conv23m / expand (CU slot = blockIdx >> 8) are written for the MI355X's 256 CUs in one partition:
+// on another count (CPX / NPS partition modes) the rules use the real number and the stagger is skipped.
+static inline int cotr_num_cus() {
+  static int cus[COTR_MAX_DEVICES] = {};
+  const int d = cotr_current_device();
+  if (cus[d] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    cus[d] = n;
+  }
+  return cus[d];
+}
 struct PerDeviceFlag {
   bool done[COTR_MAX_DEVICES] = {};
   bool get() const { return done[cotr_current_device()]; }

@@ -24,8 +24,10 @@
 //            a store's acknowledgement takes microseconds): every W3 request is issued before the stores of the piece in hand.
 //            Epilogue straight from the accumulators: a lane = one output channel, 32 lanes = 128 contiguous bytes of a pixel
 //            row, for the identity read and the y write alike.
-// Same arithmetic per output as the two-launch path except the order of the partial sums of conv3 (k runs 0..63 in the
-// permuted order above): results agree to fp32 rounding, not bit for bit (tests/test_ops_gpu.py::test_conv23_one_launch).
+// Same arithmetic per output as the two-launch path, and the same ORDER of the partial sums as the large-tile GEMM configurations
+// (26 / 27) those launches run from 5 pairs on: phase 2's k order 8g + 4 * half + e is theirs, so the results are their bits
+// (tests/test_parity_gpu.py::test_backbone_fusions_are_bit_identical_to_the_launches_they_replace; op level from 16 pairs on:
+// tests/test_ops_gpu.py::test_conv23_one_launch); against the small-tile configurations of fewer pairs: fp32 rounding.
 #include "common.h"
 
 struct Conv23Params {
@@ -311,7 +313,7 @@ int launch_conv23(const float* t1, const float* w2, const float* s2, const float
   p.zeros = gemm_zero_buffer();
   if (p.zeros == nullptr) return -2;
   p.tiles = B * 64;
-  p.stagger = 5;   // x 3.6 us per CU slot: 295 -> 247 us at 32 pairs, flat from 2 to 6 (profiles/r5_conv23_probe.txt)
+  p.stagger = cotr_num_cus() == 256 ? 5 : 0;   // x 3.6 us per CU slot: 295 -> 247 us at 32 pairs, flat from 2 to 6 (profiles/r5_conv23_probe.txt)
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv23_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, C23_SMEM) != hipSuccess)

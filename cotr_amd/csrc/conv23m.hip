@@ -240,7 +240,7 @@ int launch_conv23m(const float* t1, const float* w2, const float* s2, const floa
   p.zeros = gemm_zero_buffer();
   if (p.zeros == nullptr) return -2;
   p.tiles = B * 16;
-  p.stagger = 5;
+  p.stagger = cotr_num_cus() == 256 ? 5 : 0;
   static PerDeviceFlag attr_set;
   if (!attr_set.get()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv23m_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, C23M_SMEM) != hipSuccess ||

@@ -202,7 +202,7 @@ int launch_expand(const float* x, int M, const float* w0, const float* s0, const
   p.seg[0] = {w0, s0, b0, y0, n0, relu0, n0 / 32};
   p.seg[1] = {w1, s1, b1, y1, n1 > 0 ? n1 : 1, relu1, n1 / 32};
   p.tiles = M / 128;
-  p.stagger = 5;
+  p.stagger = cotr_num_cus() == 256 ? 5 : 0;
   hipLaunchKernelGGL(expand64_kernel<0>, dim3(p.tiles), dim3(256), EX_SMEM, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

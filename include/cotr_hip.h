@@ -403,6 +403,8 @@ int cotr_knob_count(void);
 const char* cotr_knob_name(int i);
 int cotr_get_knob(cotr_handle h, const char* name, int* value, int* default_value);
 int cotr_set_knob(cotr_handle h, const char* name, int value);
+/* COTR_OK if cotr_set_knob would accept (name, value), COTR_ERR_ARG otherwise; changes no knob set */
+int cotr_check_knob(const char* name, int value);
 int cotr_reset_knobs(cotr_handle h);
 /* 1 in libcotr_hip_exp.so, 0 in the product library */
 int cotr_is_experimental(void);

@@ -657,12 +657,14 @@ def test_fused_layer1_bottleneck(B, cin):
     assert lib.cotr_op_bottleneck(G.P(xd), G.P(y), B, 128, *[G.P(a) for a in args], G.sptr()) != 0
 
 
-@pytest.mark.parametrize('B', [1, 3, 8])
+@pytest.mark.parametrize('B', [1, 3, 8, 17])
 def test_conv23_one_launch(B):
     """conv23.hip: conv2 3x3 (+ FrozenBN + ReLU) -> conv3 1x1 (+ FrozenBN + identity + ReLU) of a layer1 bottleneck in ONE launch,
     against torchvision's Bottleneck.forward per 64-wide half (COTR/models/backbone.py:46-56,79-92): the zero padding of every half's
     border rows / columns (also at the seam), the transposed first product handing its registers to the second, the W3 ring.  Also
-    against the two launches it replaces (same contract; equal to fp32 rounding)."""
+    against the two launches it replaces (same contract; equal to fp32 rounding whatever configuration the table picks for them, and
+    BIT for bit from 16 pairs on, where they run the large-tile configurations whose k order the kernel follows).  17 pairs: 2176
+    workgroups = the staggered first round (blockIdx >> 8, three per CU) plus a ragged last one."""
     from cotr_amd import _lib
     lib = _lib.load_library()
     g = _g(B * 13 + 5)
@@ -688,6 +690,8 @@ def test_conv23_one_launch(B):
     t2 = G.op_conv(t1d, w2d, s2d, b2d, None, True, 64, 3, 1)
     y2 = G.op_conv(t2, w3d, s3d, b3d, idtd, True, 256, 1, 1)
     assert G.rel_err(y, y2) < 1e-5
+    if B >= 16:
+        assert torch.equal(y, y2)
     # NaN in, NaN out - where the reference has them (one pixel of t1 reaches its 3 x 3 neighbourhood of one half, every channel)
     t1n = t1d.clone()
     t1n[0, 10, 20, 3] = float('nan')
@@ -739,7 +743,7 @@ def test_expand_one_launch(M, n0, n1):
     assert lib.cotr_op_expand(G.P(xd), M - 1, *flat, G.sptr()) != 0
 
 
-@pytest.mark.parametrize('B,stride', [(1, 1), (3, 1), (2, 2)])
+@pytest.mark.parametrize('B,stride', [(1, 1), (3, 1), (2, 2), (16, 1), (17, 2)])
 def test_conv23m_one_launch(B, stride):
     """conv23m.hip: conv2 3x3 (stride 1 / 2, + FrozenBN + ReLU) -> conv3 1x1 (+ FrozenBN + identity + ReLU) of a layer2 bottleneck in ONE
     launch, against torchvision's Bottleneck.forward per half (COTR/models/backbone.py:46-56,79-92) and against the two launches it
@@ -770,6 +774,8 @@ def test_conv23m_one_launch(B, stride):
     t2 = G.op_conv(t1d, w2d, s2d, b2d, None, True, 128, 3, stride)
     y2 = G.op_conv(t2, w3d, s3d, b3d, idtd, True, 512, 1, 1)
     assert G.rel_err(y, y2) < 1e-5
+    if B >= 16:        # the staggered first round (two workgroups per CU, blockIdx >> 8) and the large-tile k order: the launches' bits
+        assert torch.equal(y, y2)
     assert lib.cotr_op_conv23m(G.P(t1d), G.P(w2d), G.P(s2d), G.P(b2d), G.P(w3d), G.P(s3d), G.P(b3d), G.P(idtd), G.P(y), B, 3, G.sptr()) != 0
 
 

@@ -403,8 +403,8 @@ def test_knobs_are_per_handle():
     assert all(torch.equal(x, base) for x, _ in outs)
     assert all(not torch.equal(y, base) and torch.equal(y, outs[0][1]) for _, y in outs)
     assert cotr_oracle.px_err(outs[0][1].cpu(), base.cpu()) < SHAPE_NOISE_PX
-    assert a.knobs()['ffn_fusion_max_rows'] == (1024, 1024) and b.knobs()['ffn_fusion_max_rows'] == (0, 1024)
-    assert _lib.knobs()['ffn_fusion_max_rows'] == (1024, 1024)           # the process-wide set is a third, untouched one
+    assert a.knobs()['ffn_fusion_max_rows'] == (4096, 4096) and b.knobs()['ffn_fusion_max_rows'] == (0, 4096)
+    assert _lib.knobs()['ffn_fusion_max_rows'] == (4096, 4096)           # the process-wide set is a third, untouched one
     b.reset_knobs()
     assert torch.equal(b(img, qs)['pred_corrs'], base)
     with pytest.raises(_lib.CotrHipError):
