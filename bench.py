@@ -35,6 +35,7 @@ import argparse
 import csv
 import glob
 import json
+import math
 import os
 import shutil
 import subprocess
@@ -247,7 +248,33 @@ def other_regimes(sd, dev):
         dt = time_calls(lambda: m(img, qs), n)
         out[tag] = {'ms_per_call': dt * 1e3, 'query_corr_per_s': b * q / dt, 'pairs_per_s': b / dt,
                     'tflops': flop(b, q) / dt / 1e12, 'frac_of_fp32_mfma_peak': flop(b, q) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+    # the batch axis at the metric's query count (tools/frac_by_batch.py has the whole grid: profiles/r6_frac_by_batch.txt)
+    by_batch = []
+    for b in (1, 2, 4, 8, 16, 32):
+        img, qs = synth_inputs(b, QUERIES, seed=2)
+        img, qs = img.to(dev), qs.to(dev)
+        dt = time_calls(lambda: m(img, qs), max(5, 40 // b))
+        by_batch.append({'pairs': b, 'queries': QUERIES, 'ms_per_call': round(dt * 1e3, 4),
+                         'frac_of_fp32_mfma_peak': round(flop(b, QUERIES) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)})
+    out['by_batch'] = by_batch
     return out
+
+
+def committed_by_batch(pairs, queries):
+    """The measured point of profiles/r*_frac_by_batch.txt (1 GPU) nearest to (pairs, queries): what a rank of a multi-GPU run would run at."""
+    import glob
+    import re
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_frac_by_batch.txt'))):
+        for ln in open(path):
+            m = re.match(r'B=\s*(\d+) Q=\s*(\d+):\s*([\d.]+) ms\s+frac ([\d.]+)', ln)
+            if m:
+                b, q, ms, frac = int(m.group(1)), int(m.group(2)), float(m.group(3)), float(m.group(4))
+                d = abs(math.log(b / max(pairs, 1))) + abs(math.log(q / max(queries, 1)))
+                if best is None or d <= best[0]:
+                    best = (d, {'pairs': b, 'queries': q, 'ms_per_call_1gpu': ms, 'frac_of_fp32_mfma_peak_1gpu': frac,
+                                'source': os.path.relpath(path, ROOT)})
+    return best[1] if best else None
 
 
 # ---- research: split-f16 MFMAs (never the headline) ------------------------------------------------------------------
@@ -585,6 +612,10 @@ def dry_run(args, world, rank):
                 'data': 'synthetic', 'dry_run': True, 'gathered_rows': int(gathered.shape[0]),
                 'config': {'workload': f'dry run of --workload {args.workload}', 'pairs_per_gpu': pairs}}
         line.update(ident)
+        # what each rank of the REAL run would execute per step, and where that point sits on the measured 1-GPU batch curve
+        real_pairs = {'headline': 1, 'batch256': -(-256 // world), 'dense': 1, 'train': 16}[args.workload]
+        real_queries = -(-131072 // world) if dense else (200 if args.workload == 'train' else QUERIES)
+        line['real_run_per_gpu'] = {'pairs': real_pairs, 'queries': real_queries, 'by_batch_point': committed_by_batch(real_pairs, real_queries)}
         if dense:
             line['dense_check'] = {'equals_unsharded': bool(torch.equal(gathered, fake(img, qs)['pred_corrs'][0])),
                                    'queries_this_rank': calls[-1][1], 'queries_total': int(qs.shape[1])}
@@ -779,11 +810,13 @@ def main():
                          'algorithmic_gflop_per_launch': my_flop / 1e9,
                          'min_hbm_gbs': min_hbm_bytes(pairs, my_queries) / (kernel_ms * 1e-3) / 1e9,
                          'hbm_peak_gbs': HBM_PEAK_GBS,
-                         'peak_at_measured_clock': 155.9,
-                         'clock_note': ('shader clock under this workload measured by an un-instrumented probe wavefront (s_memtime vs the 100 MHz '
-                                        'wall clock, tools/clock_settle.py): 2.38-2.39 GHz for the 1-pair and the 32-pair forward and for back-to-back large-tile '
-                                        'GEMMs, amd-smi reads 2.38-2.40 GHz per XCD (profiles/r4_shader_clock_probe_and_smi.txt) - the chip does not throttle here, '
-                                        'so the nominal 157.3 TFLOP/s (2.4 GHz) is the peak to measure against; 155.9 = 65536 FLOP/clock x 2.379 GHz')},
+                         'peak_at_measured_clock': {'one_pair_2.38GHz': 155.9, 'all_cus_dense_mfma_2.15-2.25GHz': [140.9, 147.5]},
+                         'clock_note': ('the yardstick is the nominal 157.3 TFLOP/s (65536 FLOP/clock x 2.4 GHz).  What the chip clocks to depends on the load: an '
+                                        'un-instrumented probe wavefront (s_memtime vs the 100 MHz wall clock, tools/clock_settle.py) reads 2.38-2.39 GHz during '
+                                        'the 1-pair forward and during kernels whose matrix pipes are 58-66 % busy (profiles/r4_shader_clock_probe_and_smi.txt: '
+                                        '155.9 TFLOP/s); with all 256 CUs on dense matrix work (ffn_rows / att_rows, matrix pipes ~0.8 busy) the phase stamps of '
+                                        'round 5 read 2.15-2.25 GHz (docs/LABNOTES.md, round 5 lab record; profiles/r5_final_ffn_rows_probe.txt): the power-limited '
+                                        'ceiling of the batched regime is 0.90-0.94 of the nominal peak, so batched_frac 0.72 is ~0.78 of what the chip can clock')},
         }
         research = [f'{n}={v}' for n, v in KNOBS if n.startswith('split_f16') and v]
         if research:   # --set split_f16=N on the experimental library: the line is NOT a measurement of the fp32-MFMA product path - say so in it
@@ -820,6 +853,7 @@ def main():
             line['also_measured'] = other_regimes(synth_state_dict(0), dev)
             roof['batched_frac'] = line['also_measured']['batch_32_pairs_x_1000_queries']['frac_of_fp32_mfma_peak']
             roof['batched_frac_note'] = 'same path at 32 pairs x 1000 queries per call (throughput regime)'
+            roof['by_batch'] = line['also_measured'].pop('by_batch')
             if args.research:   # opt-in: the driver's run times the product only
                 line['also_measured']['RESEARCH_split_f16_opt_in_not_the_product_path'] = research_split_f16()
         if world == 1 and not args.no_cpu_baseline and not batch256 and not dense:

@@ -94,6 +94,7 @@ constexpr KnobDesc kKnobs[] = {
     {KN_EXPAND_MIN_ROWS, "expand_min_rows", 65536, 0, INT_MAX},
     {KN_ROWS_MIN_FILL, "rows_min_fill", 75, 0, 100},
     {KN_SIDE_STREAM, "side_stream", 0, 0, 3},
+    {KN_FFN_FUSED_MAX_CHUNKS, "ffn_fused_max_chunks", 16, 2, 16},
 };
 constexpr bool knobs_in_enum_order() {
   for (int i = 0; i < (int)(sizeof(kKnobs) / sizeof(kKnobs[0])); ++i)
@@ -106,6 +107,7 @@ bool knob_value_ok(int id, int v) {
   if (id == KN_XCD_MAPPING) return (v & 3) != 3;
   if (id == KN_ATTENTION_FUSED_SPLITS) return v == 0 || v == 4 || v == 8 || v == 48 || v == 84;
   if (id == KN_ATTENTION_SPLITS) return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16;
+  if (id == KN_FFN_FUSED_MAX_CHUNKS) return v == 2 || v == 4 || v == 8 || v == 16;
   return true;
 }
 KnobSet default_knobs() {

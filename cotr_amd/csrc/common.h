@@ -96,6 +96,8 @@ enum KnobId {
   KN_ROWS_MIN_FILL,              // att_rows / ffn_rows: least fill (percent) of their 64-row tiles' last round over the CUs for the one-launch form to be taken
   KN_SIDE_STREAM,                // cotr_forward, few rows: query-only / memory-only work on a second stream of the handle, beside the chain
                                  // (bit 0: the query encoding beside the backbone; bit 1: the K/V projections of decoder layers 1-5 beside decoder layer 0)
+  KN_FFN_FUSED_MAX_CHUNKS,       // fused FFN (ffn.hip): most hidden-unit chunks = partial output slabs per row tile (16; 8 = half as many, twice as large
+                                 // producers - round 6: measured with its ln_reduce, slower)
   KN_COUNT
 };
 struct KnobSet {

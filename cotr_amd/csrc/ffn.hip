@@ -172,11 +172,11 @@ void set_ffn_debug_times(unsigned long long* p) { g_ffn_dbg = p; }
 // knob KN_XCD_MAPPING bit 4 set = plain stores for the partials; bit 2 = hidden-unit chunks over XCDs (measured: -112 MB of fabric
 // traffic per forward but +2 % time -> off)
 
-// hidden-unit chunks per row tile: enough workgroups to cover the 256 CUs, at most 16 partial outputs
+// hidden-unit chunks per row tile: enough workgroups to cover the 256 CUs, at most 16 (knob ffn_fused_max_chunks) partial outputs
 int ffn_fused_chunks(int M) {
   const int tiles = (M + 31) / 32;
   int nch = 2;
-  while (nch < 16 && tiles * nch < 256) nch *= 2;
+  while (nch < knob(KN_FFN_FUSED_MAX_CHUNKS) && tiles * nch < 256) nch *= 2;
   return nch;
 }
 

@@ -359,10 +359,13 @@ int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd,
  *   encode_chunk               pairs per backbone / encoder pass inside cotr_encode (1..128, default 64; 64 is +2-3 % over 32 from 64
  *                              pairs up, 128 is -20 %).  Scratch of a pass is ~66 MB per pair: set BEFORE sizing a caller-supplied
  *                              workspace (cotr_scratch_bytes uses the handle's value)
- *   attention_fusion_max_rows  up to this many rows (default 1024; 0 = never) the attention kernel also does the output projection
+ *   attention_fusion_max_rows  up to this many rows (default 4096; 0 = never) the attention kernel also does the output projection
  *                              (per-head partials summed + bias + residual + LayerNorm by one ln_reduce launch) and, in the
- *                              decoder, the q projection of its own queries
- *   ffn_fusion_max_rows        the fused FFN block (ffn.hip) for at most this many rows (default 1024; 0 = never)
+ *                              decoder, the q projection of its own queries - above 1024 rows only where its grid of 32-row tiles x 8
+ *                              heads fills whole rounds of the CUs to >= 90 % (round 6)
+ *   ffn_fusion_max_rows        the fused FFN block (ffn.hip) for at most this many rows (default 4096; 0 = never; above 1024 rows
+ *                              under the same fill rule), with at most
+ *   ffn_fused_max_chunks       hidden-unit chunks = partial output slabs per row tile (2, 4, 8 or 16; default 16)
  *   ks3                        1 (default): K-deep small-M GEMMs the table gives to the two-stage LDS-DMA k-split run its three-stage form
  *   dual_conv                  1 (default): downsample + conv1 of a ResNet stage's entry block as one launch at few pairs
  *   fused_stem                 1 (default): conv1 + bn1 + relu + maxpool as one launch (stem_pool.hip)

@@ -190,7 +190,7 @@ def test_state_dict_round_trip_and_reload():
 
 
 def test_fused_and_unfused_ffn_paths_agree():
-    """The fused FFN block (default up to 1024 rows) and the three-launch path compute the same function."""
+    """The fused FFN block (always up to 1024 rows, up to 4096 where its grid fills whole rounds) and the three-launch path compute the same function."""
     sd = synth_state_dict(0)
     img, qs = synth_inputs(2, 300, seed=15)
     m = hip_model()
@@ -216,6 +216,30 @@ def test_fused_and_unfused_attention_paths_agree():
     assert cotr_oracle.px_err(fused, plain) < SHAPE_NOISE_PX
     ref = cotr_oracle.cotr_forward(sd, img, qs)
     assert cotr_oracle.px_err(plain, ref) < PX_BAR and cotr_oracle.px_err(fused, ref) < PX_BAR
+
+
+@pytest.mark.parametrize('b,q,mixes,what', [(4, 1000, True, 'encoder 2048 rows + decoder 4000 rows: both on the small-row fused kernels (2 / 4 whole rounds)'),
+                                      (8, 64, True, 'encoder 4096 rows fused (4 rounds), decoder 512 rows'),
+                                      (3, 333, True, 'encoder 1536 rows = 1.5 rounds: the unfused launches; decoder 999 rows fused'),
+                                      (6, 500, True, 'encoder 3072 rows: attention fused (3 rounds), FFN unfused (1.5); decoder 3000 rows'),
+                                      (12, 257, False, 'the grouped engine call in the middle of the batch axis: unfused layers, conv23'),
+                                      (24, 100, True, 'encoder 12288 rows: att_rows / ffn_rows at 3/4 fill, pair-per-XCD placement (24 = 3 x 8)')])
+def test_middle_of_the_batch_axis_against_the_oracle(b, q, mixes, what):
+    """Round 6: between 1024 and 8192 rows the dispatch picks per sub-layer - the small-row fused kernels where their grid fills whole
+    rounds of the 256 CUs (api.hip att_fused_applies / ffn_fused_applies), the unfused launches elsewhere, the one-launch rows kernels
+    from 8192 rows on - and FasterSparseEngine's grouped calls / every partial last batch land there (sparse_engine.py:339-369,
+    400-411).  Each mix: within the bar of the CPU oracle, bit-repeatable, and the same function as the all-unfused schedule."""
+    sd = synth_state_dict(0)
+    img, qs = synth_inputs(b, q, seed=100 + b)
+    m = hip_model()
+    outs = [m(img.cuda(), qs.cuda())['pred_corrs'].cpu() for _ in range(2)]
+    assert torch.equal(outs[0], outs[1]), what
+    ref = cotr_oracle.cotr_forward(sd, img, qs)
+    assert cotr_oracle.px_err(outs[0], ref) < PX_BAR, what
+    with G.model_knobs(m, ffn_fusion_max_rows=0, attention_fusion_max_rows=0, att_rows_min_rows=1 << 30, ffn_rows_min_rows=1 << 30):
+        plain = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+    assert cotr_oracle.px_err(outs[0], plain) < SHAPE_NOISE_PX, what
+    assert torch.equal(outs[0], plain) != mixes, 'the default dispatch is not the mix this case names: ' + what
 
 
 def test_dual_conv_launch_is_bit_identical_to_two_launches():
