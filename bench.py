@@ -409,7 +409,7 @@ def cpu_baseline(budget_s=12.0):
             fn()
             n += 1
             dt = time.perf_counter() - t0
-            if dt > budget or n >= 100:
+            if dt > budget or n >= 1000:
                 return n, dt
     n, dt = timed(lambda: cotr_oracle.cotr_forward(sd, img, qs, reference_cost=True), budget_s)
     out = {'value': QUERIES * n / dt, 'unit': 'query-correspondences/s', 'cores': cores, 'kind': 'port',

@@ -242,6 +242,37 @@ def test_middle_of_the_batch_axis_against_the_oracle(b, q, mixes, what):
     assert torch.equal(outs[0], plain) != mixes, 'the default dispatch is not the mix this case names: ' + what
 
 
+@pytest.mark.parametrize('side_stream', [0, 3])
+def test_eval_forward_replays_as_a_captured_hip_graph(side_stream):
+    """The whole forward captured in a HIP graph (torch.cuda.graph around model(img, q): the library only enqueues kernels on the
+    caller's stream - no allocation, no synchronisation once the workspace is sized) and replayed on new inputs: the eager call's bits.
+    With knob side_stream = 3 the handle's second stream is forked and joined inside the capture (hipEventRecord /
+    hipStreamWaitEvent are captured as graph edges): same bits again."""
+    m = hip_model()
+    img0, qs0 = synth_inputs(1, 200, seed=61)
+    simg, sqs = img0.cuda().clone(), qs0.cuda().clone()
+    with G.model_knobs(m, side_stream=side_stream):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                m(simg, sqs)                                   # sizes the workspace, creates the second stream, sets kernel attributes
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            sout = m(simg, sqs)['pred_corrs']
+        for seed in (62, 63):
+            img, qs = synth_inputs(1, 200, seed=seed)
+            simg.copy_(img.cuda())
+            sqs.copy_(qs.cuda())
+            g.replay()
+            torch.cuda.synchronize()
+            got = sout.clone()
+            assert torch.equal(got, m(img.cuda(), qs.cuda())['pred_corrs'])
+        del g
+    assert torch.equal(got, m(img.cuda(), qs.cuda())['pred_corrs'])       # knobs back at their defaults: side stream or not, the same bits
+
+
 def test_dual_conv_launch_is_bit_identical_to_two_launches():
     """The entry blocks' downsample + conv1 in one launch compute exactly what the two launches compute when the
     configuration is the same; end to end the two schedules agree to launch-configuration rounding."""
