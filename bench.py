@@ -253,7 +253,7 @@ def other_regimes(sd, dev):
     for b in (1, 2, 4, 8, 16, 32):
         img, qs = synth_inputs(b, QUERIES, seed=2)
         img, qs = img.to(dev), qs.to(dev)
-        dt = time_calls(lambda: m(img, qs), max(5, 40 // b))
+        dt = time_calls(lambda: m(img, qs), max(10, 120 // b), warm=3)
         by_batch.append({'pairs': b, 'queries': QUERIES, 'ms_per_call': round(dt * 1e3, 4),
                          'frac_of_fp32_mfma_peak': round(flop(b, QUERIES) / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)})
     out['by_batch'] = by_batch

@@ -29,6 +29,7 @@ _PROTOS = {
                                     ctypes.c_void_p]),
     'cotr_workspace_bytes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
     'cotr_scratch_bytes': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    'cotr_batch_chunks': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     'cotr_set_workspace': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]),
     'cotr_debug_tap': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, c_float_p, ctypes.c_size_t,
                                       ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]),

@@ -40,7 +40,7 @@ EXTRA_FLAGS = {'crop_resize.hip': ['-ffp-contract=off'], 'dense_post.hip': ['-ff
                # AccVGPRs the softmax of a key block ran entirely BEHIND its 64 matrix instructions (K/V phase 205 k cycles against 131 k of matrix
                # work, whatever the interleaving; profiles/r5_att_rows_probe.txt)
                'att_rows.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
-HEADERS = ['common.h', 'train.h', 'gemm_tuned.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
+HEADERS = ['common.h', 'train.h', 'gemm_tuned.inc', 'enc_split.inc', os.path.join('..', '..', 'include', 'cotr_hip.h')]
 EXP_HEADERS = [os.path.join('experimental', f) for f in ['coop_tail.h', 'experimental.h', 'api_exp.inc', 'gemm_h2.h']] + \
               [os.path.join('experimental', 'patches', pt) for _, pt in GENERATED.values()]
 # code-object v5: loadable by the ROCm 7.0 runtime torch bundles as well as by ROCm 7.2's

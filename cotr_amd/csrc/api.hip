@@ -84,7 +84,7 @@ constexpr KnobDesc kKnobs[] = {
     {KN_ATTENTION_SPLITS, "attention_splits", 0, 0, 16},
     {KN_CONV1X1_DENSE, "conv1x1_dense", 1, 0, 1},
     {KN_WS_FLAGS, "ws_flags", 2, 0, 3},
-    {KN_BOTTLENECK_MAX_PAIRS, "bottleneck_max_pairs", 4, 0, INT_MAX},
+    {KN_BOTTLENECK_MAX_PAIRS, "bottleneck_max_pairs", 5, 0, INT_MAX},
     {KN_TRAIN_ATTENTION_FORM, "train_attention_form", 0, 0, 3},
     {KN_ATTENTION_RESIDENT, "attention_resident", 1, 0, 1},
     {KN_ATT_ROWS_MIN_ROWS, "att_rows_min_rows", 8192, 0, INT_MAX},
@@ -95,6 +95,7 @@ constexpr KnobDesc kKnobs[] = {
     {KN_ROWS_MIN_FILL, "rows_min_fill", 75, 0, 100},
     {KN_SIDE_STREAM, "side_stream", 0, 0, 3},
     {KN_FFN_FUSED_MAX_CHUNKS, "ffn_fused_max_chunks", 16, 2, 16},
+    {KN_BATCH_SPLIT, "batch_split", 1, 0, 1},
 };
 constexpr bool knobs_in_enum_order() {
   for (int i = 0; i < (int)(sizeof(kKnobs) / sizeof(kKnobs[0])); ++i)
@@ -354,6 +355,41 @@ bool att_rows_applies(int nb, int nq) {
   if (R < knob(KN_ATT_ROWS_MIN_ROWS)) return false;
   const long cus = cotr_num_cus(), tpp = (nq + 63) / 64, tiles = tpp * nb, rounds = (tiles + cus - 1) / cus;
   return tiles * 100 >= rounds * cus * knob(KN_ROWS_MIN_FILL) && (long)nq * 8 >= tpp * 64 * 7;
+}
+
+// conv23m (layer2's conv2 -> conv3 in one launch) runs TWO workgroups per CU, 16 per pair: where its grid is a single round that fills
+// the chip unevenly - more than one workgroup per CU, fewer than 7/8 of two (17 ... 27 pairs on 256 CUs) - the CUs that hold two set the
+// time of the launch (the 32-pair time) and the two launches it replaces are faster: 20 pairs -2.9 ... -4.1 % per forward, 24 pairs
+// -1.0 ... -1.8 %; at 16 (one per CU), 28, 32, 40, 48, 64 pairs the one launch wins by 0.5 ... 2 % (profiles/r6_frac_by_batch_odd_pairs.txt)
+bool conv23m_fill_ok(int pairs) {
+  const long cus = cotr_num_cus(), wgs = 16L * pairs;
+  return wgs <= cus || wgs * 8 >= 2 * cus * 7;
+}
+
+// ---- how a batch is cut into passes (knob batch_split) -------------------------------------------------------------------------
+// The forward's time against the pair count is a staircase (profiles/r6_frac_by_batch_every_pair_count.txt: 16 pairs 4.16 ms, 17 pairs
+// 5.82; 32 pairs 7.23, 33 pairs 10.63 - tiles quantise to rounds of the 256 CUs, and the one-launch rows kernels need their last round
+// filled): a batch just above a step runs faster as the step + a small remainder.
+//  * encode (query-independent): kEncFirst[n] = the first pass of the cheapest partition of n pairs, from MEASURED encode times of
+//    1 ... 64 pairs (tools/batch_cost.py: dynamic programme over the table, a split must win at least 2 %; enc_split.inc).
+//  * decode: where the rows kernels do not take the whole pass but take a prefix of it, that prefix is a pass of its own (17 x 1000
+//    queries: 16 pairs on att_rows / ffn_rows + 1 pair on the small-row fused kernels: 1.7 against 2.7 ms) - from the dispatch
+//    predicates, so it follows the knobs and the query count.
+// Pairs are independent (no cross-pair arithmetic anywhere): any partition computes every pair exactly as a call on that pass alone would.
+#include "enc_split.inc"
+int enc_next_chunk(int remaining, int cap) {
+  const int n = remaining < cap ? remaining : cap;
+  if (!knob(KN_BATCH_SPLIT) || n > 64) return n;
+  const int c = kEncFirst[n];
+  return (c >= 1 && c <= n) ? c : n;
+}
+int dec_next_pairs(int remaining, int cap, int nq) {
+  const int n = remaining < cap ? remaining : cap;
+  if (!knob(KN_BATCH_SPLIT) || n < 2) return n;
+  if (att_rows_applies(n, nq) && ffn_rows_applies(n * nq)) return n;
+  for (int k = n - 1; k >= 1 && (long)k * nq >= 8192; --k)
+    if (att_rows_applies(k, nq) && ffn_rows_applies(k * nq)) return k;
+  return n;
 }
 
 // y = LayerNorm(x + linear2(relu(linear1(x))))  (transformer.py:156-158 / 199-201; x is already normalised).
@@ -747,7 +783,10 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
   const size_t per_pair = n_stem + n_pool + 5 * n_act + 6 * n_tok + (size_t)TOK * 3 * D + (size_t)TOK * 4 * FFN;
   // per-head partial outputs of the fused attention + out_proj launch (small-row regime only); a buffer of their own: the
   // fused FFN's partials (t_hid) are written with write-through stores right after these were read
-  const size_t n_part = (Bc_max * TOK <= knob(KN_ATTENTION_FUSION_MAX_ROWS)) ? (size_t)8 * Bc_max * n_tok : 0;
+  // (sized for the largest pass that can take that path: with batch_split a small remainder follows a large first pass)
+  const size_t part_rows_cap = knob(KN_ATTENTION_FUSION_MAX_ROWS) > 1024 ? knob(KN_ATTENTION_FUSION_MAX_ROWS) : 1024;
+  const size_t part_rows = (size_t)Bc_max * TOK < part_rows_cap ? (size_t)Bc_max * TOK : part_rows_cap;
+  const size_t n_part = (size_t)8 * part_rows * D;
   {
     int r = ensure(h, h->enc_scr, per_pair * Bc_max + n_part);
     if (r) return r;
@@ -772,8 +811,8 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
 
   if (h->prof) prof_reset(h);
   prof_mark(h, "begin", s);
-  for (int b0 = 0; b0 < B; b0 += ENC_CHUNK) {
-    const int Bc = (B - b0) < ENC_CHUNK ? (B - b0) : ENC_CHUNK;
+  for (int b0 = 0, Bc = 0; b0 < B; b0 += Bc) {
+    Bc = enc_next_chunk(B - b0, ENC_CHUNK);
     const float* img_c = img + (size_t)b0 * 3 * 256 * 512;
     // ---- backbone -------------------------------------------------------------------------
     int ci = 0;
@@ -836,7 +875,7 @@ static int encode_impl(cotr_handle h, const float* img, int B, cotr_stream strea
           // many pairs: conv2 -> conv3 + identity + ReLU in one launch, t2 never leaves the CU (conv23.hip)
           KCHK(h, launch_conv23(b_t1, c2.w, c2.scale, c2.bias, c3.w, c3.scale, c3.bias, idt, y, Bc, s), "conv23");
           if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "conv23 layer1.%d %d pairs", b, Bc); prof_mark(h, nm, s, 2); }
-        } else if (st == 1 && Ho == 32 && Wo == 32 && Bc >= knob(KN_CONV23M_MIN_PAIRS)) {
+        } else if (st == 1 && Ho == 32 && Wo == 32 && Bc >= knob(KN_CONV23M_MIN_PAIRS) && conv23m_fill_ok(Bc)) {
           // many pairs: the same fusion for layer2 (conv23m.hip)
           KCHK(h, launch_conv23m(b_t1, c2.w, c2.scale, c2.bias, c3.w, c3.scale, c3.bias, idt, y, Bc, stride, s), "conv23m");
           if (h->prof >= 2) { char nm[64]; snprintf(nm, sizeof nm, "conv23m layer2.%d %d pairs", b, Bc); prof_mark(h, nm, s, 2); }
@@ -944,7 +983,7 @@ namespace {
 
 struct DecPlan {
   int q_chunk = 0, nb_max = 0;
-  size_t Rmax = 0, hid_per_row = 0;
+  size_t Rmax = 0, hid_cap = 0;   // most rows of a pass; floats behind `hid`
   float *qpos = nullptr, *tgt = nullptr, *q = nullptr, *ao = nullptr, *pre2 = nullptr, *t2 = nullptr, *pre3 = nullptr,
         *hid = nullptr, *part = nullptr;
   bool single_chunk = false;
@@ -956,10 +995,14 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
   d.nb_max = B < pairs_per ? B : pairs_per;
   d.Rmax = (size_t)d.nb_max * d.q_chunk;
   d.single_chunk = d.nb_max >= B && d.q_chunk >= Q;
-  const size_t hid_per_row = d.Rmax <= (size_t)knob(KN_FFN_FUSION_MAX_ROWS) ? 4 * FFN : FFN;  // fused FFN: up to 16 partial outputs
-  const size_t part_per_row = d.Rmax <= (size_t)knob(KN_ATTENTION_FUSION_MAX_ROWS) ? 8 * D : 0;  // per-head partials of attention + out_proj
-  d.hid_per_row = hid_per_row;
-  int r = ensure(h, h->dec_scr, d.Rmax * (7 * D + hid_per_row + part_per_row));
+  // A pass has at most Rmax rows - and with batch_split a small remainder follows a large first pass: `hid` (FFN hidden activations, FFN
+  // floats per row; or the fused FFN's up to 16 partial outputs, 4 * FFN per row) and `part` (per-head partials of attention + out_proj,
+  // 8 * D per row) are sized for the largest pass of EITHER kind that the fusion thresholds admit
+  const size_t fr = d.Rmax < (size_t)knob(KN_FFN_FUSION_MAX_ROWS) ? d.Rmax : (size_t)knob(KN_FFN_FUSION_MAX_ROWS);
+  const size_t ar = d.Rmax < (size_t)knob(KN_ATTENTION_FUSION_MAX_ROWS) ? d.Rmax : (size_t)knob(KN_ATTENTION_FUSION_MAX_ROWS);
+  d.hid_cap = d.Rmax * FFN > fr * 4 * FFN ? d.Rmax * FFN : fr * 4 * FFN;
+  const size_t part_cap = ar * 8 * D;
+  int r = ensure(h, h->dec_scr, d.Rmax * 7 * D + d.hid_cap + part_cap);
   if (r) return r;
   float* p = h->dec_scr.ptr;
   d.qpos = p; p += d.Rmax * D;
@@ -969,8 +1012,8 @@ int dec_plan(cotr_ctx* h, int B, int Q, DecPlan& d) {
   d.pre2 = p; p += d.Rmax * D;
   d.t2 = p; p += d.Rmax * D;
   d.pre3 = p; p += d.Rmax * D;
-  d.hid = p; p += d.Rmax * hid_per_row;
-  d.part = part_per_row ? p : nullptr; p += d.Rmax * part_per_row;
+  d.hid = p; p += d.hid_cap;
+  d.part = part_cap ? p : nullptr; p += part_cap;
   return COTR_OK;
 }
 
@@ -999,7 +1042,7 @@ int decode_chunk(cotr_ctx* h, const DecPlan& d0, size_t row0, const float* qsrc,
   const int KVLD = L * 2 * D;
   const int R = nb * nq;
   int r;
-  const size_t hid_cap = d0.Rmax * d0.hid_per_row;
+  const size_t hid_cap = d0.hid_cap;
   bool fused = d.part != nullptr && att_fused_applies(R) && ffn_fused_applies(R) && (size_t)ffn_fused_chunks(R) * R * D <= hid_cap;
   bool hs_normed = false;
   const bool rows = !fused && att_rows_applies(nb, nq);   // many rows: q projection, attention, out_proj, residual, norm2 in one launch
@@ -1057,8 +1100,8 @@ int decode_impl(cotr_ctx* h, const float* queries, int B, int Q, float* out, hip
   const int KVLD = L * 2 * D;
   const float* kv = h->memkv.ptr + (size_t)B * TOK * D;
   prof_mark(h, "dec_begin", s);
-  for (int b0 = 0; b0 < B; b0 += d.nb_max) {
-    const int nb = (B - b0) < d.nb_max ? (B - b0) : d.nb_max;
+  for (int b0 = 0, nb = 0; b0 < B; b0 += nb) {
+    nb = dec_next_pairs(B - b0, d.nb_max, d.q_chunk);
     for (int q0 = 0; q0 < Q; q0 += d.q_chunk) {
       const int nq = (Q - q0) < d.q_chunk ? (Q - q0) : d.q_chunk;
       const int R = nb * nq;
@@ -1110,7 +1153,7 @@ static int forward_impl(cotr_ctx* h, const float* img, const float* queries, int
     // cotr_forward returns: the caller sees one stream.
     side = knob(KN_SIDE_STREAM);
     if (h->dec.size() < 2) side &= ~2;
-    if (h->prof || h->keep_taps || B > knob(KN_ENCODE_CHUNK) || (long)B * Q > 8192) side = 0;
+    if (h->prof || h->keep_taps || B > knob(KN_ENCODE_CHUNK) || (long)B * Q > 8192 || enc_next_chunk(B, knob(KN_ENCODE_CHUNK)) != B) side = 0;
     if (side) {
       if (!h->side) {   // the handle's second stream and its events, created at first use
         HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -1139,6 +1182,31 @@ int cotr_forward(cotr_handle h, const float* img, const float* queries, int B, i
   if (int r = decode_check(h, queries, B, Q, out)) return r;
   DEVICE_SCOPE(h);
   return forward_impl(h, img, queries, B, Q, out, static_cast<hipStream_t>(stream));
+}
+
+// the passes a (B, Q) call is cut into under the handle's knobs (tests, tools): which = 0 encode passes, 1 decode passes; pairs per pass
+int cotr_batch_chunks(cotr_handle h, int B, int Q, int which, int* sizes, int cap) {
+  if (!h || B <= 0 || Q < 0 || (which != 0 && which != 1) || (cap > 0 && !sizes)) return COTR_ERR_ARG;
+  KnobScope knob_scope_(&h->knobs);
+  int n = 0;
+  if (which == 0) {
+    for (int b0 = 0, c = 0; b0 < B; b0 += c) {
+      c = enc_next_chunk(B - b0, knob(KN_ENCODE_CHUNK));
+      if (n < cap) sizes[n] = c;
+      ++n;
+    }
+  } else {
+    if (Q == 0) return 0;
+    const int q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
+    const int pairs_per = Q < DEC_ROWS ? (DEC_ROWS / Q) : 1;
+    const int nb_max = B < pairs_per ? B : pairs_per;
+    for (int b0 = 0, c = 0; b0 < B; b0 += c) {
+      c = dec_next_pairs(B - b0, nb_max, q_chunk);
+      if (n < cap) sizes[n] = c;
+      ++n;
+    }
+  }
+  return n;
 }
 
 // bytes of the three arenas a call of that size carves (each rounded up to 256 B): what cotr_set_workspace must be given
@@ -1218,10 +1286,13 @@ int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes) {
   const size_t q_chunk = Q < DEC_ROWS ? Q : DEC_ROWS;
   const size_t pairs_per = (Q > 0 && Q < DEC_ROWS) ? (DEC_ROWS / Q) : 1;
   const size_t nb = (size_t)B < pairs_per ? B : pairs_per;
+  const size_t thr_a = kn[KN_ATTENTION_FUSION_MAX_ROWS] > 1024 ? kn[KN_ATTENTION_FUSION_MAX_ROWS] : 1024;
+  const size_t R = nb * q_chunk;
+  const size_t fr = R < (size_t)kn[KN_FFN_FUSION_MAX_ROWS] ? R : (size_t)kn[KN_FFN_FUSION_MAX_ROWS];
+  const size_t ar = R < (size_t)kn[KN_ATTENTION_FUSION_MAX_ROWS] ? R : (size_t)kn[KN_ATTENTION_FUSION_MAX_ROWS];
   size_t fl = h->wfloats + (size_t)TOK * D + (size_t)B * TOK * (D + L * 2 * D) + per_pair * Bc +
-              (Bc * TOK <= (size_t)kn[KN_ATTENTION_FUSION_MAX_ROWS] ? 8 * Bc * TOK * D : 0) +
-              nb * q_chunk * (7 * D + (nb * q_chunk <= (size_t)kn[KN_FFN_FUSION_MAX_ROWS] ? 4 * FFN : FFN) +
-                              (nb * q_chunk <= (size_t)kn[KN_ATTENTION_FUSION_MAX_ROWS] ? 8 * D : 0));
+              8 * (Bc * TOK < thr_a ? Bc * TOK : thr_a) * D +
+              R * 7 * D + (R * FFN > fr * 4 * FFN ? R * FFN : fr * 4 * FFN) + ar * 8 * D;
   *bytes = fl * sizeof(float);
   return COTR_OK;
 }

@@ -98,6 +98,7 @@ enum KnobId {
                                  // (bit 0: the query encoding beside the backbone; bit 1: the K/V projections of decoder layers 1-5 beside decoder layer 0)
   KN_FFN_FUSED_MAX_CHUNKS,       // fused FFN (ffn.hip): most hidden-unit chunks = partial output slabs per row tile (16; 8 = half as many, twice as large
                                  // producers - round 6: measured with its ln_reduce, slower)
+  KN_BATCH_SPLIT,                // 1: a batch is walked in the chunks the measured staircase prefers (17 pairs = 16 + 1, 33 = 32 + 1: enc_split.inc, api.hip enc_next_chunk / dec_next_pairs); 0: in chunks of encode_chunk pairs / 32768 query rows only
   KN_COUNT
 };
 struct KnobSet {

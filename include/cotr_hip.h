@@ -115,6 +115,11 @@ int cotr_workspace_bytes(cotr_handle h, int B, int Q, size_t* bytes);
 int cotr_scratch_bytes(cotr_handle h, int B, int Q, size_t* bytes);
 int cotr_set_workspace(cotr_handle h, void* ws, size_t bytes, int keep_encode, cotr_stream stream);
 
+/* How a (B, Q) call is cut into passes under the handle's knobs (knob batch_split): which = 0 the encode passes, 1 the decode passes;
+ * sizes[0 .. min(return, cap)) = pairs per pass; returns the number of passes or < 0.  Pairs are independent, so a call computes each
+ * pass exactly as a call on those pairs alone would (tests/test_parity_gpu.py). */
+int cotr_batch_chunks(cotr_handle h, int B, int Q, int which, int* sizes, int cap);
+
 /* ---- test / profiling hooks (not needed by a binding) ------------------------------------ */
 
 /* Keep copies of scratch intermediates for cotr_debug_tap (off by default: costs D2D copies). */
@@ -385,13 +390,18 @@ int cotr_resize_f32(const float* src, int Hs, int Ws, int C, float* dst, int Hd,
  *   conv1x1_dense              1 (default): a 1x1 stride-1 convolution is launched as the dense product of its pixel rows
  *   ws_flags                   wave-specialised large tiles (configurations 40 / 41): bit 0 priority for the MFMA wavefronts' loop,
  *                              bit 1 (default) for the loaders
- *   bottleneck_max_pairs       layer1's bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass (default 4)
+ *   bottleneck_max_pairs       layer1's bottlenecks as ONE launch each (bottleneck.hip) up to this many pairs per pass (default 5)
  *   train_attention_form       training attention backward: 0 (default) = by shape, 1-3 = force the first / second / one-pass form
  *   att_rows_min_rows, ffn_rows_min_rows   query rows / rows from which the attention sub-layer / the FFN block run as ONE launch
  *                              (att_rows.hip / ffn_rows.hip; default 8192), and
  *   rows_min_fill              the least fill, in percent, of the last round of their 64-row tiles over the CUs (default 75)
  *   conv23_min_pairs, conv23m_min_pairs, expand_min_rows   layer1 / layer2 conv2 -> conv3 and layer1.0's downsample + conv1 as one
- *                              launch from this many pairs per pass / rows (defaults 5 / 16 / 65536)
+ *                              launch from this many pairs per pass / rows (defaults 5 / 16 / 65536; conv23 above bottleneck_max_pairs only;
+ *                              conv23m not where its single round fills the CUs unevenly: 17 ... 27 pairs on 256 CUs)
+ *   batch_split                1 (default): a batch is walked in the passes the measured time-against-pairs staircase prefers - encode
+ *                              passes from a measured table (csrc/enc_split.inc, tools/batch_cost.py: 17 pairs = 16 + 1, 33 = 32 + 1),
+ *                              decode passes where a prefix of the pairs fills the one-launch rows kernels and the whole does not;
+ *                              0: passes of encode_chunk pairs / 32768 query rows only (cotr_batch_chunks reports the passes)
  *   side_stream                cotr_forward with few rows (B * Q <= 8192, one pass): bit 0 the query encoding, bit 1 the K/V projections of
  *                              decoder layers 1-5 run on a second stream owned by the handle, beside the chain; joined before the
  *                              call returns (default 0: measured, profiles/r6_ab_side_stream_*.txt)

@@ -125,7 +125,7 @@ def test_knob_registry_round_trip_without_a_gpu():
     op-level entry points read.  count / name / get / set / reset need no device; the model object remembers knobs set before
     its handle exists.  The product library does not know the knobs of the measured dead ends."""
     k0 = _lib.knobs()
-    assert len(k0) == 26 and all(cur == dflt for cur, dflt in k0.values())
+    assert len(k0) == 27 and all(cur == dflt for cur, dflt in k0.values())
     assert k0['attention_fusion_max_rows'] == (4096, 4096) and k0['encode_chunk'] == (64, 64)
     for exp_only in ('head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail', 'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs'):
         assert exp_only not in k0
@@ -161,7 +161,7 @@ def test_experimental_library_has_the_dead_ends_and_their_knobs():
     assert _lib.load_library().cotr_is_experimental() == 0
     lib.cotr_knob_name.restype = ctypes.c_char_p
     names = [lib.cotr_knob_name(i).decode() for i in range(lib.cotr_knob_count())]
-    assert names[:26] == list(_lib.knobs()) and names[26:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
+    assert names[:27] == list(_lib.knobs()) and names[27:] == ['head_fusion_max_rows', 'ffn_preln', 'ffn_tail', 'coop_tail',
                                                                  'coop_tail_spin', 'gemm_ln_min_rows', 'l2_warm', 'split_f16', 'split_f16_min_pairs',
                                                                  'linear_rows_min_rows']
     for n, want in (('head_fusion_max_rows', 0), ('ffn_preln', 0), ('ffn_tail', 0), ('coop_tail', 0), ('gemm_ln_min_rows', 1 << 30),
