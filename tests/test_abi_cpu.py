@@ -213,3 +213,22 @@ def test_first_run_kit_applies_the_one_line_switch(tmp_path):
     spec.loader.exec_module(mod)                                    # cotr_amd is importable here: the try branch wins
     from cotr_amd.models import build_model as ours
     assert mod.build_model is ours
+
+
+def test_encode_split_table_is_well_formed():
+    """csrc/enc_split.inc (knob batch_split; written by tools/batch_cost.py from measured encode times): kEncFirst[n] is the first
+    pass of n pairs - between 1 and n, and following it to the end covers n pairs in passes that are themselves unsplit first
+    passes (what api.hip enc_next_chunk walks); the recorded times it was derived from are there for the reader."""
+    import re
+    src = open(os.path.join(os.path.dirname(LIB), 'enc_split.inc')).read()
+    body = re.search(r'kEncFirst\[65\] = \{([^}]*)\}', src).group(1)
+    first = [int(x) for x in body.split(',')]
+    assert len(first) == 65 and first[0] == 0
+    for n in range(1, 65):
+        assert 1 <= first[n] <= n
+        r, passes = n, []
+        while r:
+            passes.append(first[r])
+            r -= first[r]
+        assert sum(passes) == n and all(first[c] == c for c in passes[:1]), (n, passes)
+    assert first[1] == 1 and first[16] == 16 and first[32] == 32 and first[64] == 64
