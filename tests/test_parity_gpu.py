@@ -246,6 +246,9 @@ def _passes(m, b, q, which):
     import ctypes
     from cotr_amd import _lib
     sizes = (ctypes.c_int * 64)()
+    if m._handle is None:   # the handle is made by the first call
+        img0, qs0 = synth_inputs(1, 1, seed=1)
+        m(img0.cuda(), qs0.cuda())
     n = _lib.load_library().cotr_batch_chunks(m._handle, b, q, which, sizes, 64)
     assert 0 < n <= 64
     return list(sizes[:n])
@@ -278,6 +281,30 @@ def test_batch_split_walks_a_batch_as_independent_passes(b, q):
     assert cotr_oracle.px_err(out, one) < SHAPE_NOISE_PX
     idx = [0, 1, b - 1]
     assert cotr_oracle.px_err(out[idx], cotr_oracle.cotr_forward(sd, img[idx], qs[idx])) < PX_BAR
+
+
+def test_random_shapes_against_the_oracle_and_the_one_pass_schedule():
+    """Fuzz of the dispatch along both axes (round 6: the measured table, the fill rules, conv23m's gap, the passes of batch_split all
+    key on the shape): 24 random (pairs, queries) shapes, 1 ... 70 pairs x 1 ... 1200 queries, in random order on ONE model object (so the
+    workspace grows and is re-carved as it goes).  Each: the passes cover the batch; bit-repeatable; the one-pass schedule gives the
+    same numbers to summation-order noise; three of its pairs within the bar of the oracle."""
+    import random
+    rng = random.Random(20260930)
+    sd = synth_state_dict(0)
+    m = hip_model()
+    shapes = [(rng.randint(1, 70), rng.choice([1, rng.randint(2, 300), rng.randint(300, 1200)])) for _ in range(24)]
+    for i, (b, q) in enumerate(shapes):
+        img, qs = synth_inputs(b, q, seed=500 + i)
+        enc, dec = _passes(m, b, q, 0), _passes(m, b, q, 1)
+        assert sum(enc) == b and sum(dec) == b, (b, q, enc, dec)
+        out = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+        assert torch.isfinite(out).all(), (b, q)
+        assert torch.equal(out, m(img.cuda(), qs.cuda())['pred_corrs'].cpu()), (b, q)
+        with G.model_knobs(m, batch_split=0):
+            one = m(img.cuda(), qs.cuda())['pred_corrs'].cpu()
+        assert cotr_oracle.px_err(out, one) < SHAPE_NOISE_PX, (b, q, enc, dec)
+        idx = sorted(set([0, b // 2, b - 1]))
+        assert cotr_oracle.px_err(out[idx], cotr_oracle.cotr_forward(sd, img[idx], qs[idx])) < PX_BAR, (b, q, enc, dec)
 
 
 @pytest.mark.parametrize('side_stream', [0, 3])
