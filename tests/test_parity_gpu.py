@@ -307,14 +307,15 @@ def test_random_shapes_against_the_oracle_and_the_one_pass_schedule():
         assert cotr_oracle.px_err(out[idx], cotr_oracle.cotr_forward(sd, img[idx], qs[idx])) < PX_BAR, (b, q, enc, dec)
 
 
-@pytest.mark.parametrize('side_stream', [0, 3])
-def test_eval_forward_replays_as_a_captured_hip_graph(side_stream):
+@pytest.mark.parametrize('side_stream,b,q', [(0, 1, 200), (3, 1, 200), (0, 17, 1000)])
+def test_eval_forward_replays_as_a_captured_hip_graph(side_stream, b, q):
     """The whole forward captured in a HIP graph (torch.cuda.graph around model(img, q): the library only enqueues kernels on the
     caller's stream - no allocation, no synchronisation once the workspace is sized) and replayed on new inputs: the eager call's bits.
     With knob side_stream = 3 the handle's second stream is forked and joined inside the capture (hipEventRecord /
-    hipStreamWaitEvent are captured as graph edges): same bits again."""
+    hipStreamWaitEvent are captured as graph edges): same bits again.  17 pairs x 1000 queries: a call that knob batch_split walks in
+    two encode and two decode passes (16 + 1) is a longer chain of launches on the same stream, captured and replayed the same way."""
     m = hip_model()
-    img0, qs0 = synth_inputs(1, 200, seed=61)
+    img0, qs0 = synth_inputs(b, q, seed=61)
     simg, sqs = img0.cuda().clone(), qs0.cuda().clone()
     with G.model_knobs(m, side_stream=side_stream):
         s = torch.cuda.Stream()
@@ -327,7 +328,7 @@ def test_eval_forward_replays_as_a_captured_hip_graph(side_stream):
         with torch.cuda.graph(g):
             sout = m(simg, sqs)['pred_corrs']
         for seed in (62, 63):
-            img, qs = synth_inputs(1, 200, seed=seed)
+            img, qs = synth_inputs(b, q, seed=seed)
             simg.copy_(img.cuda())
             sqs.copy_(qs.cuda())
             g.replay()
