@@ -81,6 +81,8 @@ _PROTOS = {
     'cotr_train_gemm_tn_splits': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'cotr_train_gemm_tn': (ctypes.c_int, [c_float_p] * 5 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_train_gemm_tn_parts': (ctypes.c_int, [c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    'cotr_train_conv_wgrad_parts': (ctypes.c_int, [c_float_p] * 3 + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
+    'cotr_train_sum_parts': (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_size_t, c_float_p, ctypes.c_void_p]),
     'cotr_train_reduce_jobs': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_train_perm_jobs': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cotr_train_adam': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.POINTER(ctypes.c_float), ctypes.c_int,

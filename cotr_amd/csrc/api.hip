@@ -1684,6 +1684,15 @@ int cotr_train_gemm_tn_parts(const float* A, const float* B, float* part, int M,
   const int r = train_gemm_tn_parts(A, B, part, M, N, K, with_colsum, TS);     // >= 0: number of partials written
   return r >= 0 ? r : op_ret(r);
 }
+int cotr_train_sum_parts(const float* part, int nparts, size_t n, float* out, cotr_stream stream) {
+  if (!part || !out || nparts < 1) return COTR_ERR_ARG;
+  return op_ret(train_sum_parts(part, nparts, n, out, TS));
+}
+int cotr_train_conv_wgrad_parts(const float* dz, const float* x, float* part, int B, int Hin, int Win, int Cin, int Cout, int ksize,
+                                int stride, cotr_stream stream) {
+  const int r = train_conv_wgrad_parts(dz, x, part, B, Hin, Win, Cin, Cout, ksize, stride, TS);   // >= 0: partials written; -1: not this form
+  return r >= -1 ? r : op_ret(r);
+}
 static_assert(sizeof(cotr_reduce_src) == sizeof(TrainReduceSrc) && sizeof(cotr_reduce_job) == sizeof(TrainReduceJob),
               "include/cotr_hip.h and train.h disagree on the reduction records");
 int cotr_train_reduce_jobs(const cotr_reduce_job* jobs, const cotr_reduce_src* srcs, const unsigned* chunk_job, int njobs, int nchunks,

@@ -60,7 +60,7 @@ struct TrainPermJob {
   const float* scale;          // [R] or nullptr
   unsigned Z, R, C;            // batches, rows, columns of the source view
   unsigned sz, sr, sc, dz, dc; // element strides (the destination's row stride is 1)
-  unsigned tile0, tiles_r, tiles_c, pad;
+  unsigned tile0, tiles_r, tiles_c, pad;   // pad: flags - bit 0: source batch Z-1-z feeds destination batch z
 };
 int train_perm_jobs(const TrainPermJob* jobs, const unsigned* tile_job, int njobs, int ntiles, hipStream_t s);
 struct TrainAdamJob {
@@ -78,6 +78,9 @@ int train_colsum_parts(int M);
 int train_colsum(const float* x, float* part, float* out, int M, int N, hipStream_t s);
 int train_transpose(const float* src, float* dst, int R, int C, hipStream_t s);
 int train_im2col(const float* x, float* col, int B, int Hin, int Win, int Cin, int ksize, int stride, hipStream_t s);
+// weight-gradient partials of a convolution straight from x (no im2col image); -1 where that form does not apply (train.hip)
+int train_conv_wgrad_parts(const float* dz, const float* x, float* part, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride,
+                           hipStream_t s);
 int train_col2im(const float* dcol, float* dx, int B, int Hin, int Win, int Cin, int ksize, int stride, hipStream_t s);
 int train_scale_rows(const float* w, const float* scale, float* out, int rows, int cols, hipStream_t s);
 int train_transpose_batched(const float* src, float* dst, int batch, int R, int C, hipStream_t s);

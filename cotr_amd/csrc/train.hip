@@ -486,9 +486,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 // is stored unpadded (a fragment read is 32 consecutive dwords per half-wave: conflict-free at any row stride) - two stages,
 // two workgroups per CU.  Column sums of A (bias gradient) by the k-tile-0 workgroups from the landed A tile.
 // ---------------------------------------------------------------------------------------------------------------------
+// CONV (round 6): B is not a matrix but the NHWC side-by-side activation x of a convolution, and "row m, columns k0 .. k0+127" of
+// its im2col image is gathered by the DMA itself - pixel m shifted by the tap of this column block, 128 of its channels; zeros
+// where the tap leaves the half (the same zeros im2col_kernel writes).  The weight gradient of a 3x3 / strided convolution then
+// needs no im2col launch and no [M][k*k*Cin] buffer (75 MB per layer3 convolution at 16 pairs): same operands in the same order
+// as gemm_tn on the explicit image - the same bits.  Needs Cin % 128 == 0 (a column block lies inside one tap).
+struct ConvGeo {
+  int B, Hin, Win, Cin, Hout, Wout, ksize, stride, pad;
+};
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_big_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                              float* __restrict__ part, int M, int N, int K, int rows_per_split,
-                                                             int with_colsum, const float* __restrict__ zeros) {
+                                                             int with_colsum, const float* __restrict__ zeros, const ConvGeo g) {
   extern __shared__ __attribute__((aligned(16))) float tn_smem[];      // [2 stages][A 32 x 128 | B 32 x 128]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
@@ -509,6 +518,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_big_kernel(const float* __rest
   const bool do_colsum = with_colsum && k0 == 0;
   float csum = 0.f;                                      // threads 0..127: column n0 + t of A over this split's rows
 
+  // CONV: the tap (ky, kx) and first channel c0 of this workgroup's column block (wave-uniform)
+  int ky = 0, kx = 0, c0 = 0;
+  if constexpr (CONV) {
+    const int tap = k0 / g.Cin;
+    c0 = k0 - tap * g.Cin;
+    ky = tap / g.ksize;
+    kx = tap - ky * g.ksize;
+  }
   // wavefront w moves tile rows 8w .. 8w+7 of both operands: 4 DMA instructions per operand, each two rows
   auto dma_chunk = [&](int m, int st) {
     float* As = tn_smem + st * (2 * 32 * 128);
@@ -519,7 +536,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_big_kernel(const float* __rest
       const int row = m + r + hh;
       const bool ok = row < m_end;
       const float* sa = ok ? A + (size_t)row * N + n0 + l31 * 4 : zeros;
-      const float* sb = ok ? B + (size_t)row * K + k0 + l31 * 4 : zeros;
+      const float* sb;
+      if constexpr (CONV) {
+        // output pixel `row` = (b, ho, side, wl) of [B][Hout][2*Wout]; its input pixel under this tap
+        const int w2o = 2 * g.Wout, rr = ok ? row : 0;
+        const int bq = rr / (g.Hout * w2o), rem = rr - bq * (g.Hout * w2o);
+        const int ho = rem / w2o, wo = rem - ho * w2o;
+        const int side = wo >= g.Wout ? 1 : 0, wl = wo - side * g.Wout;
+        const int hi = ho * g.stride - g.pad + ky, wi = wl * g.stride - g.pad + kx;
+        const bool in = ok && hi >= 0 && hi < g.Hin && wi >= 0 && wi < g.Win;
+        sb = in ? B + (((size_t)bq * g.Hin + hi) * (2 * g.Win) + side * g.Win + wi) * g.Cin + c0 + l31 * 4 : zeros;
+      } else {
+        sb = ok ? B + (size_t)row * K + k0 + l31 * 4 : zeros;
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
                                        (__attribute__((address_space(3))) void*)(As + r * 128), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
@@ -572,10 +601,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_big_kernel(const float* __rest
 //     dgrad   dcol = dz . W ,  dx[pixel] = sum of the dcol entries that read it   (GEMM + col2im gather, fixed tap order)
 // Geometry as in GemmParams: activations NHWC side-by-side [B][Hin][2*Win][Cin], outputs [B][Hout][2*Wout].
 // ---------------------------------------------------------------------------------------------------------------------
-struct ConvGeo {
-  int B, Hin, Win, Cin, Hout, Wout, ksize, stride, pad;
-};
-
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, ConvGeo g, size_t total4) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
@@ -780,7 +805,7 @@ __global__ __launch_bounds__(256) void perm_jobs_kernel(const TrainPermJob* __re
   const unsigned tr = t / j.tiles_c, tc = t - tr * j.tiles_c;
   const unsigned r0 = tr * 32, c0 = tc * 32;
   const unsigned tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const float* src = j.src + (size_t)z * j.sz;
+  const float* src = j.src + (size_t)((j.pad & 1) ? j.Z - 1 - z : z) * j.sz;   // flag bit 0: the source's batches in reverse (a flipped 3x3 kernel)
   float* dst = j.dst + (size_t)z * j.dz;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -951,16 +976,45 @@ int train_gemm_tn_parts(const float* A, const float* B, float* part, int M, int 
     static PerDeviceFlag attr_set;
     constexpr size_t smem = 2 * 2 * 32 * 128 * sizeof(float);
     if (!attr_set.get()) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem) != hipSuccess)
         return -2;
       attr_set.set();
     }
-    hipLaunchKernelGGL(gemm_tn_big_kernel, dim3((N / 128) * (K / 128), nsplit), dim3(256), smem, s, A, B, part, M, N, K, per,
-                       with_colsum ? 1 : 0, zeros);
+    hipLaunchKernelGGL(gemm_tn_big_kernel<false>, dim3((N / 128) * (K / 128), nsplit), dim3(256), smem, s, A, B, part, M, N, K, per,
+                       with_colsum ? 1 : 0, zeros, ConvGeo{});
   } else
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((N / 64) * (K / 64), nsplit), dim3(256), 0, s, A, B, part, M, N, K, per,
                        with_colsum ? 1 : 0);
+  if (hipGetLastError() != hipSuccess) return -2;
+  return nsplit;
+}
+
+// The weight gradient of a convolution WITHOUT its im2col image: part[split][Cout][k*k*Cin] = dz[rows of the split]^T . im2col(x)[same
+// rows], the image gathered by the kernel (gemm_tn_big_kernel<true>).  -> number of splits (the same as train_gemm_tn_splits(M, Cout,
+// k*k*Cin): the caller sizes `part` with it), or -1 where this form does not apply (Cin % 128, the small-shape kernel's territory):
+// the caller then forms the image (train_im2col) and calls train_gemm_tn_parts - the two give the same bits.
+int train_conv_wgrad_parts(const float* dz, const float* x, float* part, int B, int Hin, int Win, int Cin, int Cout, int ksize, int stride,
+                           hipStream_t s) {
+  if (B <= 0 || Cin % 128 != 0 || ksize < 1 || stride < 1) return -1;
+  const ConvGeo g = conv_geo(B, Hin, Win, Cin, ksize, stride);
+  const int M = B * g.Hout * 2 * g.Wout, N = Cout, K = ksize * ksize * Cin;
+  if (!gemm_tn_use_big(M, N, K)) return -1;
+  const int splits = train_gemm_tn_splits(M, N, K);
+  int per = (M + splits - 1) / splits;
+  per = (per + 31) / 32 * 32;
+  const int nsplit = (M + per - 1) / per;
+  const float* zeros = gemm_zero_buffer();
+  if (zeros == nullptr) return -2;
+  static PerDeviceFlag attr_set;
+  constexpr size_t smem = 2 * 2 * 32 * 128 * sizeof(float);
+  if (!attr_set.get()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return -2;
+    attr_set.set();
+  }
+  hipLaunchKernelGGL(gemm_tn_big_kernel<true>, dim3((N / 128) * (K / 128), nsplit), dim3(256), smem, s, dz, x, part, M, N, K, per, 0, zeros, g);
   if (hipGetLastError() != hipSuccess) return -2;
   return nsplit;
 }

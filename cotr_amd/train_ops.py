@@ -8,6 +8,7 @@ gets a fresh 32-bit seed from ``next_seed()`` in the forward and hands the same 
 recomputes the mask.
 """
 import ctypes
+import os
 
 import torch
 
@@ -377,6 +378,32 @@ def gemm_tn_parts(dy, x, with_colsum=False):
     return part, rc, pstride
 
 
+def conv_wgrad_parts(dz2, x, b, h, wd, cin, cout, k, stride):
+    """The split-M partials of a convolution's weight gradient straight from its input x (no im2col image: the kernel gathers the
+    shifted pixels itself; csrc/train.hip gemm_tn_big_kernel<true>) -> (part, number of partials, floats per partial), the same
+    values ``gemm_tn_parts(dz2, im2col(x))`` returns; None where that form does not apply (Cin % 128, small shapes)."""
+    lib = _lib.load_library()
+    m, kk = dz2.shape[0], k * k * cin
+    assert dz2.is_contiguous() and x.is_contiguous() and dz2.shape[1] == cout
+    part = _empty((max(1, lib.cotr_train_gemm_tn_splits(m, cout, kk)) * cout * kk,), dz2)
+    with _on(dz2.device):
+        rc = lib.cotr_train_conv_wgrad_parts(_P(dz2), _P(x), _P(part), b, h, wd, cin, cout, k, stride, _sp())
+    if rc == -1:
+        return None
+    if rc < 0:
+        _chk(rc, f'cotr_train_conv_wgrad_parts {m}x{cout}x{kk}')
+    return part, rc, cout * kk
+
+
+def sum_parts(part, nparts, n):
+    """part [nparts][n] summed in split order -> [n] (what gemm_tn does behind its partials)."""
+    lib = _lib.load_library()
+    out = _empty((n,), part)
+    with _on(part.device):
+        _chk(lib.cotr_train_sum_parts(_P(part), nparts, n, _P(out), _sp()), 'cotr_train_sum_parts')
+    return out
+
+
 def colsum(x, out):
     lib = _lib.load_library()
     m, n = x.shape
@@ -439,9 +466,10 @@ class _Derived:
         tile = 0
         owners = []
         for i, e in enumerate(entries):
-            Z, R, C, sz, sr, sc, dz, dc = e['spec']
+            Z, R, C, sz, sr, sc, dz, dc = e['spec'][:8]
+            flags = e['spec'][8] if len(e['spec']) > 8 else 0                # bit 0: source batch Z-1-z -> destination batch z
             tr, tc = (R + 31) // 32, (C + 31) // 32
-            jobs[i] = (e['src'], e['dst'].data_ptr(), e['scale'], Z, R, C, sz, sr, sc, dz, dc, tile, tr, tc, 0)
+            jobs[i] = (e['src'], e['dst'].data_ptr(), e['scale'], Z, R, C, sz, sr, sc, dz, dc, tile, tr, tc, flags)
             owners.append(np.full(Z * tr * tc, i, dtype=np.uint32))
             tile += Z * tr * tc
         cmap = np.concatenate(owners) if owners else np.zeros(0, np.uint32)
@@ -568,6 +596,15 @@ def conv_scaled_t(w, scale):
     cout, cin, k, _ = w.shape
     kk = k * k
     return _derived.get(_base_of(w), w.detach(), 'S', scale, (kk, cout, cin, 1, cin * kk, kk, cin * cout, cout), (kk * cin, cout))
+
+
+def conv_dgrad_w(w, scale):
+    """The data gradient of a 3 x 3 stride-1 convolution IS a 3 x 3 stride-1 convolution of dz with the kernel flipped and its channel
+    axes exchanged: dx = conv(dz, W'), W'[cin][2-ky][2-kx][cout] = W[cout][cin][ky][kx] * scale[cout] - in the kernels' packed
+    layout [Cin rows][k*k*Cout], derived once per optimiser step like the other weight-shaped operands."""
+    cout, cin, k, _ = w.shape
+    kk = k * k
+    return _derived.get(_base_of(w), w.detach(), 'D', scale, (kk, cout, cin, 1, cin * kk, kk, cout, kk * cout, 1), (cin, kk * cout))
 
 
 class Proj(torch.autograd.Function):
@@ -913,6 +950,12 @@ class Attention(torch.autograd.Function):
         return None, dq, dk, dv, None, None, None, None
 
 
+IMPLICIT_WGRAD = os.environ.get('COTR_IMPLICIT_WGRAD', '1') not in ('', '0')   # tools / tests: 0 = the explicit im2col image everywhere (A/B, bit-identity check)
+
+
+IMPLICIT_DGRAD = os.environ.get('COTR_IMPLICIT_DGRAD', '1') not in ('', '0')   # 0 = dz . W^T + col2im everywhere (A/B)
+
+
 class ConvBN(torch.autograd.Function):
     """One convolution of a trainable bottleneck (layer2 / layer3: COTR/models/backbone.py:66-69 trains only these) with its
     FrozenBatchNorm2d affine (backbone.py:46-56), optional residual and ReLU, on the NHWC side-by-side layout of the inference
@@ -953,18 +996,22 @@ class ConvBN(torch.autograd.Function):
                 _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dz), dy.numel(), 0.0, _sp()), 'cotr_train_relu_drop_bwd')
             dz2 = dz.view(m, cout)
             direct = k == 1 and stride == 1
-            if direct:
-                col = x.view(m, cin)
-            else:
-                col = _empty((m, kk), x)
-                _chk(lib.cotr_train_im2col(_P(x), _P(col), b, h, wd, cin, k, stride, _sp()), 'cotr_train_im2col')
+            # weight-gradient partials: 1 x 1 stride-1 - the activation matrix is its own im2col image; else straight from x where the
+            # implicit form applies (round 6: no im2col launch, no [m, k*k*cin] image - the same bits), else from an explicit image
+            wparts = None
+            if ctx.needs_input_grad[1]:
+                wparts = gemm_tn_parts(dz2, x.view(m, cin)) if direct else (IMPLICIT_WGRAD and conv_wgrad_parts(dz2, x, b, h, wd, cin, cout, k, stride)) or None
+                if wparts is None:
+                    col = _empty((m, kk), x)
+                    _chk(lib.cotr_train_im2col(_P(x), _P(col), b, h, wd, cin, k, stride, _sp()), 'cotr_train_im2col')
+                    wparts = gemm_tn_parts(dz2, col)
             dw = None
             gw = _sink.grad_of(ctx.weight) if (_sink is not None and ctx.needs_input_grad[1]) else None
             if gw is not None:                                                # scale + layout inside the deferred reduction
-                part, nparts, pstride = gemm_tn_parts(dz2, col)
+                part, nparts, pstride = wparts
                 _sink.add(gw, part, 0, nparts, pstride, cout * kk, scale=scale, row_len=kk, cin=cin, taps=k * k)
             elif ctx.needs_input_grad[1]:
-                dwp, _ = gemm_tn(dz2, col)                                    # d(W * scale), packed layout
+                dwp = sum_parts(wparts[0], wparts[1], cout * kk).view(cout, kk)   # d(W * scale), packed layout
                 _chk(lib.cotr_train_scale_rows(_P(dwp), _P(scale), _P(dwp), cout, kk, _sp()), 'cotr_train_scale_rows')
                 if k == 1:
                     dw = dwp.view(cout, cin, 1, 1)
@@ -972,7 +1019,13 @@ class ConvBN(torch.autograd.Function):
                     dw = _empty((cout, cin, k, k), x)
                     _chk(lib.cotr_train_transpose_batched(_P(dwp), _P(dw), cout, k * k, cin, _sp()), 'cotr_train_transpose_batched')
             dx = None
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and IMPLICIT_DGRAD and k == 3 and stride == 1:
+                # round 6: the data gradient as ONE implicit-GEMM launch of the forward's convolution kernel on the flipped kernel - no
+                # [m, 9 * cin] image of partial products (75 MB per layer3 convolution at 16 pairs) and no col2im pass over it
+                dx = torch.empty_like(x)
+                _chk(lib.cotr_op_conv(_P(dz), _P(conv_dgrad_w(ctx.weight, scale)), None, None, None, 0, _P(dx), b, ho, wo, cout, cin, 3, 1, _sp()),
+                     'cotr_op_conv (dgrad)')
+            elif ctx.needs_input_grad[0]:
                 wst = conv_scaled_t(ctx.weight, scale)                        # (W * scale)^T, derived once per optimiser step
                 dcol = gemm(dz2, wst)                                         # [m, k*k*cin]
                 if direct:

@@ -272,6 +272,15 @@ typedef struct cotr_reduce_job {
   unsigned row_len, cin, taps, vec;
 } cotr_reduce_job;
 int cotr_train_gemm_tn_parts(const float* A, const float* B, float* part, int M, int N, int K, int with_colsum, cotr_stream stream);
+/* The same partials for the weight gradient of a convolution WITHOUT its im2col image (round 6): A = dz [B*Hout*2*Wout][Cout], the
+ * second operand is gathered from x [B][Hin][2*Win][Cin] by the kernel (zeros where a tap leaves the half) - the bits of
+ * cotr_train_im2col + cotr_train_gemm_tn_parts(dz, col, ..., 0).  part as for cotr_train_gemm_tn_parts with M = B*Hout*2*Wout,
+ * N = Cout, K = ksize*ksize*Cin.  Returns the number of partials, or -1 where this form does not apply (Cin % 128 != 0, small
+ * shapes): form the image and call cotr_train_gemm_tn_parts. */
+int cotr_train_conv_wgrad_parts(const float* dz, const float* x, float* part, int B, int Hin, int Win, int Cin, int Cout, int ksize,
+                                int stride, cotr_stream stream);
+/* out[i] = part[0][i] + part[1][i] + ... in split order (i < n; part [nparts][n]): what cotr_train_gemm_tn does after its partials */
+int cotr_train_sum_parts(const float* part, int nparts, size_t n, float* out, cotr_stream stream);
 int cotr_train_reduce_jobs(const cotr_reduce_job* jobs, const cotr_reduce_src* srcs, const unsigned* chunk_job, int njobs, int nchunks,
                            cotr_stream stream);
 /* torch.optim.Adam's update (train_cotr.py:49-57: betas (0.9, 0.999), eps 1e-8, no weight decay / amsgrad) over EVERY trainable

@@ -257,7 +257,10 @@ def test_relu_dropout_backward_and_transpose():
 
 @pytest.mark.parametrize('B,H,cin,cout,k,stride,res,relu', [(2, 16, 128, 128, 3, 1, False, True), (1, 32, 256, 128, 3, 2, False, True),
                                                             (2, 16, 256, 512, 1, 2, False, False), (1, 16, 128, 512, 1, 1, True, True),
-                                                            (3, 8, 512, 256, 1, 1, False, True)])
+                                                            (3, 8, 512, 256, 1, 1, False, True),
+                                                            # shapes whose weight gradient takes the implicit form (no im2col image, round 6)
+                                                            (2, 32, 128, 128, 3, 1, True, True), (2, 64, 128, 128, 3, 2, False, True),
+                                                            (4, 16, 256, 256, 3, 1, False, True), (4, 32, 512, 1024, 1, 2, False, False)])
 def test_conv_frozenbn_forward_backward(B, H, cin, cout, k, stride, res, relu):
     """train_ops.ConvBN (layer2 / layer3 of the trainable backbone): forward = the inference conv kernel, backward = im2col +
     transpose-free wgrad + GEMM / col2im dgrad on the NHWC side-by-side layout; against F.conv2d on each 256-wide half (NCHW,
@@ -288,6 +291,43 @@ def test_conv_frozenbn_forward_backward(B, H, cin, cout, k, stride, res, relu):
     assert _rel(grads[1], refs[1]) < 5e-5
     if res:
         assert _rel(grads[2], nhwc(refs[2])) < 5e-5
+
+
+@pytest.mark.parametrize('B,H,cin,cout,k,stride', [(2, 32, 128, 128, 3, 1), (2, 64, 128, 128, 3, 2), (4, 16, 256, 256, 3, 1),
+                                                    (4, 32, 256, 256, 3, 2), (4, 32, 512, 1024, 1, 2), (16, 16, 256, 256, 3, 1),
+                                                    (3, 32, 128, 128, 3, 1)])
+def test_implicit_conv_wgrad_is_the_explicit_one_bit_for_bit(B, H, cin, cout, k, stride):
+    """cotr_train_conv_wgrad_parts (round 6): the split-M partials of a convolution's weight gradient with the im2col image gathered by the
+    kernel's own LDS-DMA (zeros where a tap leaves the 256-wide half) - the same operands in the same order as cotr_train_im2col +
+    cotr_train_gemm_tn_parts: the same number of partials, the same bits; and the gradient they sum to against F.conv2d's in fp64."""
+    from cotr_amd import _lib
+    lib = _lib.load_library()
+    sp = _lib.current_stream_ptr()
+    g = _g(B + H + cin + cout + k + stride)
+    pad = k // 2
+    Ho = (H + 2 * pad - k) // stride + 1
+    x = torch.randn(B, H, 2 * H, cin, generator=g).cuda()
+    dz = torch.randn(B, Ho, 2 * Ho, cout, generator=g).cuda()
+    m, kk = B * Ho * 2 * Ho, k * k * cin
+    dz2 = dz.view(m, cout)
+    got = T.conv_wgrad_parts(dz2, x, B, H, H, cin, cout, k, stride)
+    assert got is not None, 'a shape of the trainable backbone at which the implicit form must apply'
+    part, nparts, pstride = got
+    col = torch.empty(m, kk, device='cuda')
+    assert lib.cotr_train_im2col(x.data_ptr(), col.data_ptr(), B, H, H, cin, k, stride, sp) == 0
+    part2, nparts2, pstride2 = T.gemm_tn_parts(dz2, col)
+    assert (nparts, pstride) == (nparts2, pstride2)
+    assert torch.equal(part[:nparts * pstride], part2[:nparts * pstride])
+    dw = T.sum_parts(part, nparts, cout * kk).view(cout, k, k, cin).permute(0, 3, 1, 2)
+    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(False)
+    w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    dzr = dz.permute(0, 3, 1, 2).double().cpu()
+    y = torch.cat([F.conv2d(xr[..., :H], w, stride=stride, padding=pad), F.conv2d(xr[..., H:], w, stride=stride, padding=pad)], dim=-1)
+    (ref,) = torch.autograd.grad(y, w, dzr)
+    assert _rel(dw, ref) < 5e-5
+    # where the form does not apply the caller is told so (and forms the image): 64 input channels, a small product
+    assert T.conv_wgrad_parts(torch.zeros(2 * 16 * 32, 64, device='cuda'), torch.zeros(2, 16, 32, 64, device='cuda'), 2, 16, 16, 64, 64, 3, 1) is None
+    assert T.conv_wgrad_parts(torch.zeros(1 * 8 * 16, 256, device='cuda'), torch.zeros(1, 8, 16, 256, device='cuda'), 1, 8, 8, 256, 256, 3, 1) is None
 
 
 def test_reduce_jobs_kernel():
