@@ -73,16 +73,17 @@ def next_seed():
 
 
 # ---- contractions ------------------------------------------------------------------------------------------------------
-def gemm(a, w, bias=None, relu=False):
-    """y[M,N] = relu?(a[M,K] . w[N,K]^T + bias) on the library's fp32-MFMA GEMM kernels."""
+def gemm(a, w, bias=None, relu=False, residual=None):
+    """y[M,N] = relu?(a[M,K] . w[N,K]^T + bias (+ residual[M,N])) on the library's fp32-MFMA GEMM kernels."""
     lib = _lib.load_library()
     m, k = a.shape
     n = w.shape[0]
     assert a.is_contiguous() and w.is_contiguous() and w.shape[1] == k and k % 32 == 0 and n % 16 == 0, (a.shape, w.shape)
+    assert residual is None or (residual.is_contiguous() and residual.numel() == m * n)
     y = _empty((m, n), a)
     if m:
         with _on(a.device):
-            _chk(lib.cotr_op_linear(_P(a), None, 0, _P(w), None, _P(bias), None, int(relu), _P(y), m, n, k, _sp()),
+            _chk(lib.cotr_op_linear(_P(a), None, 0, _P(w), None, _P(bias), _P(residual), int(relu), _P(y), m, n, k, _sp()),
                  f'cotr_op_linear {m}x{n}x{k}')
     return y
 
@@ -984,56 +985,123 @@ class ConvBN(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _lib.load_library()
-        b, h, wd, cin, cout, k, stride, ho, wo, relu, has_res = ctx.meta
         x, scale, y = ctx.saved_tensors
-        m, kk = b * ho * 2 * wo, k * k * cin
-        dy = dy.contiguous()
-        dz = dy
-        with _on(dy.device):
-            if relu:
-                dz = torch.empty_like(dy)
-                _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dz), dy.numel(), 0.0, _sp()), 'cotr_train_relu_drop_bwd')
-            dz2 = dz.view(m, cout)
-            direct = k == 1 and stride == 1
-            # weight-gradient partials: 1 x 1 stride-1 - the activation matrix is its own im2col image; else straight from x where the
-            # implicit form applies (round 6: no im2col launch, no [m, k*k*cin] image - the same bits), else from an explicit image
-            wparts = None
-            if ctx.needs_input_grad[1]:
-                wparts = gemm_tn_parts(dz2, x.view(m, cin)) if direct else (IMPLICIT_WGRAD and conv_wgrad_parts(dz2, x, b, h, wd, cin, cout, k, stride)) or None
-                if wparts is None:
-                    col = _empty((m, kk), x)
-                    _chk(lib.cotr_train_im2col(_P(x), _P(col), b, h, wd, cin, k, stride, _sp()), 'cotr_train_im2col')
-                    wparts = gemm_tn_parts(dz2, col)
-            dw = None
-            gw = _sink.grad_of(ctx.weight) if (_sink is not None and ctx.needs_input_grad[1]) else None
-            if gw is not None:                                                # scale + layout inside the deferred reduction
-                part, nparts, pstride = wparts
-                _sink.add(gw, part, 0, nparts, pstride, cout * kk, scale=scale, row_len=kk, cin=cin, taps=k * k)
-            elif ctx.needs_input_grad[1]:
-                dwp = sum_parts(wparts[0], wparts[1], cout * kk).view(cout, kk)   # d(W * scale), packed layout
-                _chk(lib.cotr_train_scale_rows(_P(dwp), _P(scale), _P(dwp), cout, kk, _sp()), 'cotr_train_scale_rows')
-                if k == 1:
-                    dw = dwp.view(cout, cin, 1, 1)
-                else:
-                    dw = _empty((cout, cin, k, k), x)
-                    _chk(lib.cotr_train_transpose_batched(_P(dwp), _P(dw), cout, k * k, cin, _sp()), 'cotr_train_transpose_batched')
-            dx = None
-            if ctx.needs_input_grad[0] and IMPLICIT_DGRAD and k == 3 and stride == 1:
-                # round 6: the data gradient as ONE implicit-GEMM launch of the forward's convolution kernel on the flipped kernel - no
-                # [m, 9 * cin] image of partial products (75 MB per layer3 convolution at 16 pairs) and no col2im pass over it
+        dx, dw, dz = _conv_backward(ctx.meta, x, scale, y, ctx.weight, dy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dw, None, None, (dz if ctx.meta[10] else None), None, None
+
+
+def _conv_backward(meta, x, scale, y, weight, dy, need_dx, need_dw, dx_residual=None):
+    """Backward of y = relu?(conv(x, W) * scale + bias (+ res)) -> (dx, dW or None, dz): dz = dy * (y > 0) (the gradient of a residual
+    input, if there was one); the weight gradient goes to the GradSink where one is installed (dW is None then); ``dx_residual`` (1 x 1
+    stride-1 convolutions) is added to dx in the epilogue of the data-gradient GEMM - a gradient that arrives at x by another path
+    (the bottleneck's identity branch) without an add launch of its own, the same single fp32 addition."""
+    lib = _lib.load_library()
+    b, h, wd, cin, cout, k, stride, ho, wo, relu, has_res = meta
+    m, kk = b * ho * 2 * wo, k * k * cin
+    dy = dy.contiguous()
+    dz = dy
+    with _on(dy.device):
+        if relu:
+            dz = torch.empty_like(dy)
+            _chk(lib.cotr_train_relu_drop_bwd(_P(dy), _P(y), _P(dz), dy.numel(), 0.0, _sp()), 'cotr_train_relu_drop_bwd')
+        dz2 = dz.view(m, cout)
+        direct = k == 1 and stride == 1
+        assert dx_residual is None or direct
+        # weight-gradient partials: 1 x 1 stride-1 - the activation matrix is its own im2col image; else straight from x where the
+        # implicit form applies (round 6: no im2col launch, no [m, k*k*cin] image - the same bits), else from an explicit image
+        wparts = None
+        if need_dw:
+            wparts = gemm_tn_parts(dz2, x.view(m, cin)) if direct else (IMPLICIT_WGRAD and conv_wgrad_parts(dz2, x, b, h, wd, cin, cout, k, stride)) or None
+            if wparts is None:
+                col = _empty((m, kk), x)
+                _chk(lib.cotr_train_im2col(_P(x), _P(col), b, h, wd, cin, k, stride, _sp()), 'cotr_train_im2col')
+                wparts = gemm_tn_parts(dz2, col)
+        dw = None
+        gw = _sink.grad_of(weight) if (_sink is not None and need_dw) else None
+        if gw is not None:                                                # scale + layout inside the deferred reduction
+            part, nparts, pstride = wparts
+            _sink.add(gw, part, 0, nparts, pstride, cout * kk, scale=scale, row_len=kk, cin=cin, taps=k * k)
+        elif need_dw:
+            dwp = sum_parts(wparts[0], wparts[1], cout * kk).view(cout, kk)   # d(W * scale), packed layout
+            _chk(lib.cotr_train_scale_rows(_P(dwp), _P(scale), _P(dwp), cout, kk, _sp()), 'cotr_train_scale_rows')
+            if k == 1:
+                dw = dwp.view(cout, cin, 1, 1)
+            else:
+                dw = _empty((cout, cin, k, k), x)
+                _chk(lib.cotr_train_transpose_batched(_P(dwp), _P(dw), cout, k * k, cin, _sp()), 'cotr_train_transpose_batched')
+        dx = None
+        if need_dx and IMPLICIT_DGRAD and k == 3 and stride == 1:
+            # round 6: the data gradient as ONE implicit-GEMM launch of the forward's convolution kernel on the flipped kernel - no
+            # [m, 9 * cin] image of partial products (75 MB per layer3 convolution at 16 pairs) and no col2im pass over it
+            dx = torch.empty_like(x)
+            _chk(lib.cotr_op_conv(_P(dz), _P(conv_dgrad_w(weight, scale)), None, None, None, 0, _P(dx), b, ho, wo, cout, cin, 3, 1, _sp()),
+                 'cotr_op_conv (dgrad)')
+        elif need_dx:
+            wst = conv_scaled_t(weight, scale)                            # (W * scale)^T, derived once per optimiser step
+            dcol = gemm(dz2, wst, residual=None if dx_residual is None else dx_residual.contiguous())   # [m, k*k*cin]
+            if direct:
+                dx = dcol.view(b, h, 2 * wd, cin)
+            else:
                 dx = torch.empty_like(x)
-                _chk(lib.cotr_op_conv(_P(dz), _P(conv_dgrad_w(ctx.weight, scale)), None, None, None, 0, _P(dx), b, ho, wo, cout, cin, 3, 1, _sp()),
-                     'cotr_op_conv (dgrad)')
-            elif ctx.needs_input_grad[0]:
-                wst = conv_scaled_t(ctx.weight, scale)                        # (W * scale)^T, derived once per optimiser step
-                dcol = gemm(dz2, wst)                                         # [m, k*k*cin]
-                if direct:
-                    dx = dcol.view(b, h, 2 * wd, cin)
-                else:
-                    dx = torch.empty_like(x)
-                    _chk(lib.cotr_train_col2im(_P(dcol), _P(dx), b, h, wd, cin, k, stride, _sp()), 'cotr_train_col2im')
-        return dx, dw, None, None, (dz if has_res else None), None, None
+                _chk(lib.cotr_train_col2im(_P(dcol), _P(dx), b, h, wd, cin, k, stride, _sp()), 'cotr_train_col2im')
+    return dx, dw, dz
+
+
+def _conv_forward(x, w, scale, bias, res, relu, stride):
+    """-> (y, meta) of one convolution + FrozenBN affine (+ residual) (+ ReLU) on the inference kernel (cotr_op_conv)."""
+    lib = _lib.load_library()
+    b, h, w2, cin = x.shape
+    wd = w2 // 2
+    cout, _, k, _ = w.shape
+    pad = k // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+    y = _empty((b, ho, 2 * wo, cout), x)
+    with _on(x.device):
+        _chk(lib.cotr_op_conv(_P(x), _P(conv_packed(w)), _P(scale), _P(bias), _P(None if res is None else res.contiguous()), int(relu), _P(y),
+                              b, h, wd, cin, cout, k, stride, _sp()), 'cotr_op_conv')
+    return y, (b, h, wd, cin, cout, k, stride, ho, wo, bool(relu), res is not None)
+
+
+BOTTLENECK_FN = os.environ.get('COTR_BOTTLENECK_FN', '1') not in ('', '0')   # 0 = four ConvBN nodes per block (A/B, bit-identity check)
+
+
+class Bottleneck(torch.autograd.Function):
+    """One trainable ResNet bottleneck (torchvision v1.5: stride on the 3x3; FrozenBN; COTR/models/backbone.py:46-56, 66-69) as ONE
+    autograd node: conv1 1x1 + ReLU, conv2 3x3 (stride) + ReLU, [downsample 1x1 (stride)], conv3 1x1 + identity + ReLU - the same
+    twelve-odd launches forward and backward as four ConvBN nodes, minus the add launch autograd makes where the two paths meet at
+    the block's input: the identity branch's gradient enters conv1's data-gradient GEMM as its residual (one fp32 addition either
+    way: the same bits).  Arguments: x, then (weight, scale, bias) of conv1, conv2, conv3 and of the downsample (None x 3 without
+    one), then the stride."""
+
+    @staticmethod
+    def forward(ctx, x, w1, s1, b1, w2, s2, b2, w3, s3, b3, wd, sd, bd, stride):
+        x = x.contiguous()
+        t1, m1 = _conv_forward(x, w1, s1, b1, None, True, 1)
+        t2, m2 = _conv_forward(t1, w2, s2, b2, None, True, stride)
+        idt, md = (x, None) if wd is None else _conv_forward(x, wd, sd, bd, None, False, stride)
+        y, m3 = _conv_forward(t2, w3, s3, b3, idt, True, 1)
+        ctx.metas = (m1, m2, m3, md)
+        ctx.weights = (w1, w2, w3, wd)
+        ctx.save_for_backward(x, t1, t2, y, s1, s2, s3, *((sd,) if wd is not None else ()))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, t1, t2, y, s1, s2, s3, *rest = ctx.saved_tensors
+        m1, m2, m3, md = ctx.metas
+        w1, w2, w3, wd = ctx.weights
+        need = ctx.needs_input_grad
+        # conv3 (+ identity + ReLU): dz3 is also the gradient of the identity input
+        dt2, dw3, dz3 = _conv_backward(m3, t2, s3, y, w3, dy, True, need[7])
+        # identity branch: the block input itself, or the downsample convolution of it
+        dwd = None
+        if wd is None:
+            didt = dz3
+        else:
+            didt, dwd, _ = _conv_backward(md, x, rest[0], None, wd, dz3, need[0], need[10])
+        dt1, dw2, _ = _conv_backward(m2, t1, s2, t2, w2, dt2, True, need[4])
+        dx, dw1, _ = _conv_backward(m1, x, s1, t1, w1, dt1, need[0], need[1], dx_residual=didt if need[0] else None)
+        return dx, dw1, None, None, dw2, None, None, dw3, None, None, dwd, None, None, None
 
 
 class Head(torch.autograd.Function):

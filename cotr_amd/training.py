@@ -185,6 +185,10 @@ def _bottleneck_hip(x, blk):
     forward and backward on the HIP kernels (train_ops.ConvBN)."""
     from . import train_ops as T
     stride = blk.conv2.stride[0]
+    if T.BOTTLENECK_FN:   # the block as one autograd node (round 6): the identity gradient rides in conv1's data-gradient GEMM
+        ds = (blk.downsample[0].weight, *_frozen_bn_affine(blk.downsample[1])) if hasattr(blk, 'downsample') else (None, None, None)
+        return T.Bottleneck.apply(x, blk.conv1.weight, *_frozen_bn_affine(blk.bn1), blk.conv2.weight, *_frozen_bn_affine(blk.bn2),
+                                  blk.conv3.weight, *_frozen_bn_affine(blk.bn3), *ds, stride)
     out = T.ConvBN.apply(x, blk.conv1.weight, *_frozen_bn_affine(blk.bn1), None, True, 1)
     out = T.ConvBN.apply(out, blk.conv2.weight, *_frozen_bn_affine(blk.bn2), None, True, stride)
     idt = x

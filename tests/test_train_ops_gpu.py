@@ -330,6 +330,45 @@ def test_implicit_conv_wgrad_is_the_explicit_one_bit_for_bit(B, H, cin, cout, k,
     assert T.conv_wgrad_parts(torch.zeros(1 * 8 * 16, 256, device='cuda'), torch.zeros(1, 8, 16, 256, device='cuda'), 1, 8, 8, 256, 256, 3, 1) is None
 
 
+@pytest.mark.parametrize('B,H,cin,planes,stride,down', [(2, 32, 512, 128, 1, False), (2, 64, 256, 128, 2, True), (4, 16, 1024, 256, 1, False),
+                                                         (2, 32, 512, 256, 2, True)])
+def test_bottleneck_as_one_autograd_node_is_the_four_convbn_nodes_bit_for_bit(B, H, cin, planes, stride, down):
+    """train_ops.Bottleneck (round 6): a trainable ResNet bottleneck as ONE autograd node - the identity branch's gradient enters conv1's
+    data-gradient GEMM as its residual instead of meeting conv1's gradient in an add launch of autograd's.  The same launches
+    otherwise and one fp32 addition either way: output, input gradient and all weight gradients equal those of the four-ConvBN
+    composition bit for bit (layer2 / layer3 shapes, with and without the downsample branch)."""
+    g = _g(B + H + cin + planes + stride)
+    cout = 4 * planes
+
+    def wgt(o, i, k):
+        return (torch.randn(o, i, k, k, generator=g) / math.sqrt(i * k * k)).cuda()
+
+    def aff(c):
+        return (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+    ws = [wgt(planes, cin, 1), wgt(planes, planes, 3), wgt(cout, planes, 1)] + ([wgt(cout, cin, 1)] if down else [])
+    affs = [aff(planes), aff(planes), aff(cout)] + ([aff(cout)] if down else [])
+    x0 = torch.randn(B, H, 2 * H, cin, generator=g).cuda()
+    Ho = H // stride
+    dy = torch.randn(B, Ho, 2 * Ho, cout, generator=g).cuda()
+
+    def run(one_node):
+        x = x0.clone().requires_grad_()
+        w = [t.clone().requires_grad_() for t in ws]
+        if one_node:
+            ds = (w[3], *affs[3]) if down else (None, None, None)
+            y = T.Bottleneck.apply(x, w[0], *affs[0], w[1], *affs[1], w[2], *affs[2], *ds, stride)
+        else:
+            o = T.ConvBN.apply(x, w[0], *affs[0], None, True, 1)
+            o = T.ConvBN.apply(o, w[1], *affs[1], None, True, stride)
+            idt = T.ConvBN.apply(x, w[3], *affs[3], None, False, stride) if down else x
+            y = T.ConvBN.apply(o, w[2], *affs[2], idt, True, 1)
+        return [y.detach()] + list(torch.autograd.grad(y, [x] + w, dy))
+    a, b = run(True), run(False)
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
 def test_reduce_jobs_kernel():
     """cotr_train_reduce_jobs against torch: several jobs in one launch - plain (vector path), a tail that is not a multiple of
     the chunk, two sources accumulating into one destination that already holds a value, misaligned records (scalar path: the
