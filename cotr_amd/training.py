@@ -13,8 +13,9 @@ What runs where:
   allocates tensors and records the tape; it computes nothing.  The loss (two ``mse_loss`` and a mask, cotr_trainer.py:
   124-135) and Adam stay torch;
 * stages 2-3 (``--lr_backbone > 0``): conv1 + layer1 (frozen, backbone.py:66-69) on the inference kernels, layer2 / layer3
-  under autograd on the HIP kernels as well (``train_ops.ConvBN``: implicit-GEMM forward, dX as a GEMM on the cached W^T +
-  col2im, dW by the transpose-free TN kernel on an explicit im2col); the torch-convolution form is kept as a cross-check only
+  under autograd on the HIP kernels as well (``train_ops.Bottleneck``, one autograd node per block: implicit-GEMM forward; dW by the
+  transpose-free TN kernel that gathers its im2col operand itself; dX of the 3x3 stride-1 convolutions as one implicit-GEMM launch
+  on the flipped kernel, of the others as a GEMM on the cached W^T [+ col2im]); the torch-convolution form is kept as a cross-check only
   (``backbone_features_trainable(..., use_torch_convs=True)``).
 ``forward_train_torch`` is the round-1 tape (HIP GEMMs + torch ops for everything else); it is kept as an independent
 cross-check of the kernels (tests) and is not used by the product path.
@@ -182,7 +183,7 @@ def _frozen_bn_affine(bn):
 
 def _bottleneck_hip(x, blk):
     """torchvision ResNet v1.5 Bottleneck (stride on the 3x3) with FrozenBN on the NHWC side-by-side layout, every convolution
-    forward and backward on the HIP kernels (train_ops.ConvBN)."""
+    forward and backward on the HIP kernels (train_ops.Bottleneck: the block as one autograd node; train_ops.ConvBN: one node per convolution)."""
     from . import train_ops as T
     stride = blk.conv2.stride[0]
     if T.BOTTLENECK_FN:   # the block as one autograd node (round 6): the identity gradient rides in conv1's data-gradient GEMM
