@@ -387,7 +387,8 @@ int dec_next_pairs(int remaining, int cap, int nq) {
   const int n = remaining < cap ? remaining : cap;
   if (!knob(KN_BATCH_SPLIT) || n < 2) return n;
   if (att_rows_applies(n, nq) && ffn_rows_applies(n * nq)) return n;
-  for (int k = n - 1; k >= 1 && (long)k * nq >= 8192; --k)
+  const long min_rows = knob(KN_ATT_ROWS_MIN_ROWS) > knob(KN_FFN_ROWS_MIN_ROWS) ? knob(KN_ATT_ROWS_MIN_ROWS) : knob(KN_FFN_ROWS_MIN_ROWS);
+  for (int k = n - 1; k >= 1 && (long)k * nq >= min_rows; --k)   // (below either threshold no prefix can take both rows kernels)
     if (att_rows_applies(k, nq) && ffn_rows_applies(k * nq)) return k;
   return n;
 }
